@@ -1,0 +1,230 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own python files on CPU.
+
+Container-only (needs /root/reference).  Run:  python tests/golden/make_golden.py
+The fixtures are data (inputs + the reference's outputs); tests read only the .npz files.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import _ref_import as R  # noqa: E402
+from oracle import fcos_oracle as O  # noqa: E402
+
+SUP_CFG = '/root/reference/configs/fcos_semi/r50_caffe_mslonger_tricks_0.Xdata.py'
+torch.set_num_threads(8)
+
+
+def npify(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    return out
+
+
+def save(name, **d):
+    np.savez_compressed(os.path.join(HERE, name), **npify(d))
+    print('wrote', name, {k: getattr(v, 'shape', None) for k, v in d.items()})
+
+
+def gts_for(rng, H, W, n, lo=8.0, hi=None):
+    b = O.synth_boxes(rng, n, H=H, W=W, lo=lo, hi=hi or max(H, W))
+    return torch.from_numpy(b), torch.from_numpy(rng.randint(0, 80, len(b)).astype('int64'))
+
+
+def head_of(model):
+    return model.bbox_head
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_assign(model):
+    head = head_of(model)
+    # (1) crafted small case: 5 levels of a 128x160 canvas; ties in area, point exactly on a box
+    # edge / centre-box edge, nested boxes, degenerate box, box outside all regress ranges
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    pts = head.get_points(sizes, torch.float32, 'cpu')
+    gtb = [torch.tensor([[0., 0., 64., 64.], [32., 32., 96., 96.], [0., 0., 64., 64.],   # tie 0/2
+                         [4., 4., 20., 20.], [4., 4., 36., 36.], [60., 20., 60., 90.],
+                         [10., 12., 150., 120.], [100., 4., 108., 12.]]),
+           torch.zeros(0, 4),
+           torch.tensor([[12., 12., 28., 28.], [12., 12., 28., 28.]])]
+    gtl = [torch.tensor([1, 2, 3, 4, 5, 6, 7, 8]), torch.zeros(0, dtype=torch.long),
+           torch.tensor([9, 10])]
+    labels, tg = head.get_targets(pts, gtb, gtl)
+    save('assign_small.npz', sizes=np.array(sizes), n_img=3,
+         gt0=gtb[0], gt1=gtb[1], gt2=gtb[2], gl0=gtl[0], gl1=gtl[1], gl2=gtl[2],
+         labels=torch.cat(labels).to(torch.int16), bbox_targets=torch.cat(tg),
+         points=torch.cat(pts))
+    # (2) full size canvas 800x1344, G up to 40
+    sizes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    pts = head.get_points(sizes, torch.float32, 'cpu')
+    rng = np.random.RandomState(2024)
+    gtb, gtl = [], []
+    for n in (7, 40):
+        b, l = gts_for(rng, 800, 1333, n, lo=16.0, hi=600.0)
+        gtb.append(b)
+        gtl.append(l)
+    labels, tg = head.get_targets(pts, gtb, gtl)
+    save('assign_full.npz', sizes=np.array(sizes), n_img=2, gt0=gtb[0], gt1=gtb[1], gl0=gtl[0],
+         gl1=gtl[1], labels=torch.cat(labels).to(torch.int16), bbox_targets=torch.cat(tg))
+
+
+def rand_head_outputs(g, B, sizes, cls_bias=-2.0):
+    cls = [(torch.randn(B, 80, h, w, generator=g) * 1.5 + cls_bias).requires_grad_() for h, w in sizes]
+    reg = [(torch.rand(B, 4, h, w, generator=g) * 6.0 * (torch.rand(B, 4, h, w, generator=g) > 0.1)
+            ).requires_grad_() for h, w in sizes]
+    ctr = [torch.randn(B, 1, h, w, generator=g).requires_grad_() for h, w in sizes]
+    return cls, reg, ctr
+
+
+def gen_loss(model):
+    head = head_of(model)
+    sizes = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]       # 128 x 192 canvas
+    rng = np.random.RandomState(7)
+    for name, B, lw, sw, warm, with_ig in (('loss_sup', 2, 1.0, 0.0, 0, False),
+                                           ('loss_sup_ig', 2, 1.0, 0.0, 0, True),
+                                           ('loss_dsl', 3, 3.0, 1.0, 0, True),
+                                           ('loss_dsl_warm', 3, 3.0, 1.0, 5, True),
+                                           ('loss_dsl_even', 2, 3.0, 1.0, 0, True),
+                                           ('loss_nopos', 2, 1.0, 0.0, 0, False)):
+        g = torch.Generator().manual_seed(hash(name) & 0xFFFF if False else sum(map(ord, name)))
+        cls, reg, ctr = rand_head_outputs(g, B, sizes)
+        gtb, gtl, igb = [], [], []
+        for i in range(B):
+            n = 0 if name == 'loss_nopos' else int(rng.randint(1, 6))
+            b, l = gts_for(rng, 128, 192, n, lo=8.0, hi=160.0)
+            gtb.append(b)
+            gtl.append(l)
+            ib, _ = gts_for(rng, 128, 192, int(rng.randint(0, 4)), lo=8.0, hi=100.0)
+            igb.append(ib)
+        if name.startswith('loss_dsl') and B == 3:
+            gtb[2], gtl[2], igb[2] = gtb[1] / 2, gtl[1], igb[1] / 2
+        head.loss_weight, head.soft_weight, head.soft_warm_up, head.cur_iter = lw, sw, warm, 0
+        metas = [dict(img_shape=(128, 192, 3))] * B
+        losses = head.loss(cls, reg, ctr, gtb, gtl, metas, gt_bboxes_ignore=igb if with_ig else None)
+        total = sum(v for v in losses.values())
+        total.backward()
+        d = dict(sizes=np.array(sizes), B=B, loss_weight=lw, soft_weight=sw, soft_warm_up=warm,
+                 with_ig=int(with_ig))
+        for i in range(B):
+            d[f'gt{i}'], d[f'gl{i}'], d[f'ig{i}'] = gtb[i], gtl[i], igb[i]
+        for i in range(5):
+            d[f'cls{i}'], d[f'reg{i}'], d[f'ctr{i}'] = cls[i], reg[i], ctr[i]
+            d[f'gcls{i}'], d[f'greg{i}'], d[f'gctr{i}'] = cls[i].grad, reg[i].grad, ctr[i].grad
+        for k, v in losses.items():
+            d[k] = np.float64(float(v))
+        save(name + '.npz', **d)
+    head.loss_weight, head.soft_weight, head.soft_warm_up, head.cur_iter = 1.0, 0.0, 0, 0
+
+
+def gen_net(model):
+    """Whole detector, tiny canvas, synthetic key-addressed weights (oracle.synth_state_dict)."""
+    sd = O.synth_state_dict(0)
+    missing = model.load_state_dict(sd, strict=True)
+    print('load_state_dict', missing)
+    model.train()
+    tk = O.trainable_keys(sd)
+    ref_tk = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert sorted(tk) == sorted(ref_tk), (set(tk) ^ set(ref_tk))
+    rng = np.random.RandomState(11)
+    for name, B, H, W, dsl in (('net_tiny', 2, 64, 96, False), ('net_small_dsl', 2, 96, 128, True)):
+        g = torch.Generator().manual_seed(5 + B + H)
+        img = torch.randn(B, 3, H, W, generator=g) * 40.0
+        gtb, gtl, igb = [], [], []
+        for i in range(B):
+            b, l = gts_for(rng, H, W, int(rng.randint(1, 4)), lo=8.0, hi=80.0)
+            gtb.append(b)
+            gtl.append(l)
+            ib, _ = gts_for(rng, H, W, int(rng.randint(1, 3)), lo=8.0, hi=60.0)
+            igb.append(ib)
+        head = head_of(model)
+        if dsl:
+            head.loss_weight, head.soft_weight, head.soft_warm_up, head.cur_iter = 3.0, 1.0, 0, 1
+            img, gtb, gtl, igb = O.append_half_scale(img, gtb, gtl, igb)
+        model.zero_grad()
+        metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), scale_factor=1.0)] * len(gtb)
+        feats = model.extract_feat(img)
+        outs = model.bbox_head(feats)
+        losses = model.bbox_head.loss(*outs, gtb, gtl, metas, gt_bboxes_ignore=igb if dsl else None)
+        sum(losses.values()).backward()
+        d = dict(img=img, B=len(gtb), dsl=int(dsl))
+        for i in range(len(gtb)):
+            d[f'gt{i}'], d[f'gl{i}'], d[f'ig{i}'] = gtb[i], gtl[i], igb[i]
+        for i in range(5):
+            d[f'feat{i}'] = feats[i]
+            d[f'cls{i}'], d[f'reg{i}'], d[f'ctr{i}'] = outs[0][i], outs[1][i], outs[2][i]
+        for k, v in losses.items():
+            d[k] = np.float64(float(v))
+        named = dict(model.named_parameters())
+        d['grad_keys'] = np.array(tk)
+        d['grad_norms'] = np.array([float(named[k].grad.norm()) for k in tk], dtype=np.float64)
+        for k in ('bbox_head.conv_reg.weight', 'bbox_head.conv_cls.bias', 'bbox_head.scales.0.scale',
+                  'bbox_head.scales.3.scale', 'bbox_head.cls_convs.0.gn.weight',
+                  'bbox_head.reg_convs.3.gn.bias', 'neck.lateral_convs.2.conv.bias',
+                  'backbone.layer2.0.conv1.weight'):
+            d['grad/' + k] = named[k].grad
+        save(name + '.npz', **d)
+        head.loss_weight, head.soft_weight, head.soft_warm_up, head.cur_iter = 1.0, 0.0, 0, 0
+    # teacher sweep on the tiny net (eval mode: bbox_pred * stride); raise the focal prior so that
+    # some scores pass score_thr (recorded in the fixture as cls_bias)
+    sd2 = dict(sd)
+    sd2['bbox_head.conv_cls.bias'] = torch.full((80,), -1.5)
+    model.load_state_dict(sd2, strict=True)
+    model.eval()
+    g = torch.Generator().manual_seed(99)
+    img = torch.randn(2, 3, 96, 128, generator=g) * 40.0
+    sf = np.array([1.25, 1.25, 1.25, 1.25], dtype=np.float32)
+    metas = [dict(img_shape=(90, 120, 3), pad_shape=(96, 128, 3), scale_factor=sf)] * 2
+    with torch.no_grad():
+        feats = model.extract_feat(img)
+        outs = model.bbox_head(feats)
+        dets = model.bbox_head.get_bboxes(*outs, metas, rescale=True)
+    d = dict(img=img, scale_factor=sf, img_shape=np.array([90, 120, 3]), cls_bias=-1.5)
+    for i in range(5):
+        d[f'cls{i}'], d[f'reg{i}'], d[f'ctr{i}'] = outs[0][i], outs[1][i], outs[2][i]
+    for i, (b, l) in enumerate(dets):
+        d[f'det{i}'], d[f'lab{i}'] = b, l
+        print('dets', i, b.shape)
+    save('sweep_tiny.npz', **d)
+
+
+def gen_bboxes(model):
+    """get_bboxes on synthetic head outputs with enough confident scores to exercise top-k + NMS."""
+    head = head_of(model)
+    model.eval()
+    sizes = [(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)]     # 320 x 448 canvas, P3 has 2240 > 1000
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    cls = [torch.randn(B, 80, h, w, generator=g) * 2.0 - 3.0 for h, w in sizes]
+    reg = [torch.rand(B, 4, h, w, generator=g) * 8.0 * s for (h, w), s in zip(sizes, O.STRIDES)]
+    ctr = [torch.randn(B, 1, h, w, generator=g) for h, w in sizes]
+    sf = np.array([0.5, 0.5, 0.5, 0.5], dtype=np.float32)
+    metas = [dict(img_shape=(310, 440, 3), scale_factor=sf)] * B
+    dets = head.get_bboxes(cls, reg, ctr, metas, rescale=True)
+    d = dict(sizes=np.array(sizes), scale_factor=sf, img_shape=np.array([310, 440, 3]))
+    for i in range(5):
+        d[f'cls{i}'], d[f'reg{i}'], d[f'ctr{i}'] = cls[i], reg[i], ctr[i]
+    for i, (b, l) in enumerate(dets):
+        d[f'det{i}'], d[f'lab{i}'] = b, l
+        print('dets', i, b.shape)
+    save('bboxes_synth.npz', **d)
+
+
+if __name__ == '__main__':
+    model = R.build_fcos(SUP_CFG)
+    model.train()
+    which = sys.argv[1:] or ['assign', 'loss', 'bboxes', 'net']
+    if 'assign' in which:
+        gen_assign(model)
+    if 'loss' in which:
+        gen_loss(model)
+    if 'bboxes' in which:
+        gen_bboxes(model)
+    if 'net' in which:
+        gen_net(model)
