@@ -1,0 +1,134 @@
+"""ctypes binding of libdsl_hip.so (include/dsl_hip.h).  There is NO fallback: if the HIP library is
+missing, importing this module raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libdsl_hip.so')
+MAX_SEG = 5
+
+if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f'{LIB_PATH} not found: the MI355X kernels are not built. Run `python -m dsl_amd.build` '
+        '(needs hipcc); dsl_amd has no CPU or PyTorch fallback for its hot path.')
+lib = C.CDLL(LIB_PATH)
+
+I5 = C.c_int32 * MAX_SEG
+F5 = C.c_float * MAX_SEG
+
+# conv flags / op kinds (mirror the enums of dsl_hip.h)
+CONV_RELU_OUT, CONV_RELU_IN, CONV_OUT_F32, CONV_MASK_FIRST, CONV_MASK_LAST, CONV_ADD_UPSAMPLE, \
+    CONV_SMALL_C = 1, 2, 4, 8, 16, 32, 64
+(OP_CONV, OP_WGRAD, OP_GN_FWD, OP_GN_BWD, OP_MAXPOOL, OP_SUM2X2, OP_COLSUM, OP_MEMSET, OP_PACK_IMAGE,
+ OP_ASSIGN, OP_LOSS) = range(1, 12)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('nseg', C.c_int32), ('n', C.c_int32),
+                ('gh', I5), ('gw', I5), ('sh', I5), ('sw', I5), ('dh', I5), ('dw', I5), ('ah', I5), ('aw', I5),
+                ('cs', C.c_int32), ('cd', C.c_int32), ('cd_pad', C.c_int32),
+                ('ldd', C.c_int32), ('lda', C.c_int32), ('ldm', C.c_int32),
+                ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
+                ('mode', C.c_int32), ('os', C.c_int32), ('flags', C.c_int32),
+                ('src', C.c_void_p), ('wgt', C.c_void_p), ('dst', C.c_void_p),
+                ('scale', C.c_void_p), ('bias', C.c_void_p), ('addend', C.c_void_p), ('mask', C.c_void_p)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('nseg', C.c_int32), ('n', C.c_int32),
+                ('gh', I5), ('gw', I5), ('sh', I5), ('sw', I5),
+                ('cs', C.c_int32), ('cy', C.c_int32), ('cd', C.c_int32),
+                ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
+                ('splits', C.c_int32),
+                ('dy', C.c_void_p), ('x', C.c_void_p), ('scale', C.c_void_p), ('dw', C.c_void_p),
+                ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+
+
+class GnDesc(C.Structure):
+    _fields_ = [('nseg', C.c_int32), ('n', C.c_int32), ('c', C.c_int32), ('groups', C.c_int32),
+                ('h', I5), ('w', I5), ('eps', C.c_float),
+                ('x', C.c_void_p), ('y', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('stats', C.c_void_p), ('dy', C.c_void_p), ('dx', C.c_void_p), ('dgamma', C.c_void_p),
+                ('dbeta', C.c_void_p), ('red', C.c_void_p)]
+
+
+class FcosDesc(C.Structure):
+    _fields_ = [('nlvl', C.c_int32), ('n', C.c_int32),
+                ('h', I5), ('w', I5), ('stride', I5), ('range_lo', F5), ('range_hi', F5),
+                ('radius', C.c_float), ('num_classes', C.c_int32),
+                ('gt_boxes', C.c_void_p), ('gt_labels', C.c_void_p), ('gt_off', C.c_void_p),
+                ('ig_boxes', C.c_void_p), ('ig_off', C.c_void_p),
+                ('labels', C.c_void_p), ('bbox_targets', C.c_void_p), ('assign_idx', C.c_void_p),
+                ('cls_weight', C.c_void_p), ('pos_weight', C.c_void_p), ('stats', C.c_void_p),
+                ('loss_weight', C.c_float),
+                ('cls_logits', C.c_void_p), ('regctr', C.c_void_p),
+                ('ld_cls', C.c_int32), ('ld_rc', C.c_int32),
+                ('scales', C.c_void_p), ('norm', C.c_void_p),
+                ('g_cls', C.c_void_p), ('ld_gcls', C.c_int32), ('g_rc', C.c_void_p), ('ld_grc', C.c_int32),
+                ('g_scales', C.c_void_p), ('losses', C.c_void_p),
+                ('soft_weight', C.c_float), ('grad_scale', C.c_float), ('inv_world', C.c_float)]
+
+
+class DetDesc(C.Structure):
+    _fields_ = [('nlvl', C.c_int32), ('n', C.c_int32),
+                ('h', I5), ('w', I5), ('stride', I5),
+                ('num_classes', C.c_int32), ('nms_pre', C.c_int32), ('max_per_img', C.c_int32),
+                ('score_thr', C.c_float), ('iou_thr', C.c_float),
+                ('cls_logits', C.c_void_p), ('ld_cls', C.c_int32),
+                ('regctr', C.c_void_p), ('ld_rc', C.c_int32),
+                ('scales', C.c_void_p), ('img_shapes', C.c_void_p), ('scale_factors', C.c_void_p),
+                ('dets', C.c_void_p), ('det_labels', C.c_void_p), ('det_count', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+
+
+class Op(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 7), ('desc', C.c_void_p),
+                ('p', C.c_void_p * 4), ('l', C.c_int64 * 2)]
+
+
+lib.dsl_last_error.restype = C.c_char_p
+lib.dsl_wgrad_workspace_bytes.restype = C.c_size_t
+if hasattr(lib, 'dsl_detect_workspace_bytes'):
+    lib.dsl_detect_workspace_bytes.restype = C.c_size_t
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+_SIGS = {
+    'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
+    'dsl_wgrad_workspace_bytes': [_vp],
+    'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
+    'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp],
+    'dsl_sum2x2': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], 'dsl_colsum': [_vp, _vp, _l, _i, _i, _vp],
+    'dsl_fcos_points': [_vp, _vp, _vp], 'dsl_fcos_assign': [_vp, _vp], 'dsl_fcos_loss': [_vp, _vp],
+    'dsl_sumsq': [_vp, _l, _vp, _vp],
+    'dsl_sgd_step': [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _i, _vp],
+    'dsl_ema_lerp': [_vp, _vp, _l, _f, _vp], 'dsl_cast_bf16': [_vp, _vp, _l, _vp],
+    'dsl_pack_dgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'dsl_detect_workspace_bytes': [_vp], 'dsl_fcos_detect': [_vp, _vp],
+    'dsl_run_ops': [_vp, _i, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp],
+}
+MISSING = []
+for _name, _args in _SIGS.items():
+    try:
+        getattr(lib, _name).argtypes = _args
+    except AttributeError:      # reported by tests/test_abi.py; calling it raises AttributeError
+        MISSING.append(_name)
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise RuntimeError(f'libdsl_hip {what} failed ({rc}): {lib.dsl_last_error().decode()}')
+
+
+def seg5(vals):
+    a = I5()
+    for i, v in enumerate(vals):
+        a[i] = int(v)
+    return a
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,58 @@
+"""Build libdsl_hip.so (gfx950) in-tree with hipcc.  No torch extension machinery: the library is a
+plain C-ABI shared object (include/dsl_hip.h) loaded through ctypes."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libdsl_hip.so')
+SOURCES = ['api.hip', 'conv.hip', 'misc.hip', 'fcos_loss.hip', 'optim.hip', 'detect.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, 'common.hpp'), os.path.join(HERE, '..', 'include', 'dsl_hip.h')]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objs = [os.path.join(LIBDIR, os.path.basename(s)[:-4] + '.o') for s in srcs]
+    hipcc = _hipcc()
+
+    def compile_one(so):
+        s, o = so
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return o
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(compile_one, zip(srcs, objs)))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build_lib(force='--force' in sys.argv)
+    print(LIB)

@@ -1,0 +1,64 @@
+// libdsl_hip.so: error reporting, op-list executor, hardware probes.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void dsl_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* dsl_last_error(void) { return g_err; }
+extern "C" int dsl_version(void) { return 100; }
+
+extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
+  DSL_CHECK(ops || n_ops == 0, "dsl_run_ops: null op list");
+  hipStream_t st = (hipStream_t)stream;
+  for (int k = 0; k < n_ops; ++k) {
+    const dsl_op& o = ops[k];
+    int rc = 0;
+    switch (o.kind) {
+      case DSL_OP_CONV: rc = dsl_conv2d((const dsl_conv_desc*)o.desc, stream); break;
+      case DSL_OP_WGRAD: rc = dsl_conv2d_wgrad((const dsl_wgrad_desc*)o.desc, stream); break;
+      case DSL_OP_GN_FWD: rc = dsl_groupnorm_relu_fwd((const dsl_gn_desc*)o.desc, stream); break;
+      case DSL_OP_GN_BWD: rc = dsl_groupnorm_relu_bwd((const dsl_gn_desc*)o.desc, stream); break;
+      case DSL_OP_MAXPOOL: rc = dsl_maxpool3x3s2(o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], stream); break;
+      case DSL_OP_SUM2X2: rc = dsl_sum2x2(o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], stream); break;
+      case DSL_OP_COLSUM: rc = dsl_colsum(o.p[0], (float*)o.p[1], (long)o.l[0], o.i[0], o.i[1], stream); break;
+      case DSL_OP_MEMSET:
+        if (hipMemsetAsync(o.p[0], o.i[0], (size_t)o.l[0], st) != hipSuccess) {
+          dsl_set_error("dsl_run_ops: memset failed at op %d", k);
+          rc = -2;
+        }
+        break;
+      case DSL_OP_PACK_IMAGE: rc = dsl_pack_image((const float*)o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], stream); break;
+      case DSL_OP_ASSIGN: rc = dsl_fcos_assign((const dsl_fcos_desc*)o.desc, stream); break;
+      case DSL_OP_LOSS: rc = dsl_fcos_loss((const dsl_fcos_desc*)o.desc, stream); break;
+      default:
+        dsl_set_error("dsl_run_ops: unknown op kind %d at index %d", o.kind, k);
+        return -1;
+    }
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+// ---- probe: semantics of ds_read_b64_tr_b16 (used by tests/test_probe_gpu.py) -------------------
+__global__ void probe_tr16_kernel(const uint16_t* img, const int* lane_off, uint16_t* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = img[i];
+  __syncthreads();
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(lds + lane_off[threadIdx.x]));
+  for (int e = 0; e < 4; ++e) out[threadIdx.x * 4 + e] = (uint16_t)v[e];
+}
+
+extern "C" int dsl_probe_tr16(const uint16_t* img, const int32_t* lane_off, uint16_t* out, void* stream) {
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, img, lane_off, out);
+  DSL_LAUNCH_CHECK("probe_tr16_kernel");
+  return 0;
+}

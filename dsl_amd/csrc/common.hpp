@@ -1,0 +1,80 @@
+// Shared device/host helpers for libdsl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dsl_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+void dsl_set_error(const char* fmt, ...);
+#define DSL_CHECK(cond, ...)          \
+  do {                                \
+    if (!(cond)) {                    \
+      dsl_set_error(__VA_ARGS__);     \
+      return -1;                      \
+    }                                 \
+  } while (0)
+#define DSL_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      dsl_set_error("%s launch failed: %s", name, hipGetErrorString(e_));   \
+      return -2;                                                            \
+    }                                                                       \
+  } while (0)
+
+// ---- bf16 <-> fp32 (round to nearest even, as torch .bfloat16()) -------------------------------
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- exact division of p < 2^20 by d < 2^20 via a 40-bit reciprocal ----------------------------
+struct FastDiv {
+  uint64_t m;
+  uint32_t d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d ? d : 1;
+  f.m = ((1ull << 40) + f.d - 1) / f.d;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t p, const FastDiv& f) {
+  return (uint32_t)(((uint64_t)p * f.m) >> 40);
+}
+
+// ---- wave / block reductions ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh /* >= 16 floats */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += sh[i];
+  return r;
+}

@@ -1,0 +1,434 @@
+// Memory-bound layers of the FCOS R50-FPN step on gfx950: image pack, max pool, GroupNorm+ReLU
+// (forward / backward), FPN upsample backward, column sums.  All NHWC bf16, 16-byte accesses.
+#include "common.hpp"
+
+namespace {
+
+// ---- NCHW fp32 -> NHWC8 bf16 -------------------------------------------------------------------
+__global__ void pack_image_kernel(const float* __restrict__ img, uint16_t* __restrict__ out, int n,
+                                  int h, int w) {
+  const long long hw = (long long)h * w;
+  const long long total = (long long)n * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / hw, r = i - b * hw;
+    const float* src = img + b * 3 * hw + r;
+    u32x4 v = {pack2bf(src[0], src[hw]), pack2bf(src[2 * hw], 0.f), 0u, 0u};
+    *reinterpret_cast<u32x4*>(out + i * 8) = v;
+  }
+}
+
+// ---- 3x3 s2 p1 max pool (resnet.py:610) ---------------------------------------------------------
+__device__ __forceinline__ uint32_t max2bf(uint32_t a, uint32_t b) {
+  const float lo = fmaxf(bflo(a), bflo(b)), hi = fmaxf(bfhi(a), bfhi(b));
+  return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+}
+__global__ void maxpool_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int n, int h,
+                               int w, int c, int oh, int ow) {
+  const int c8 = c / 8;
+  const long long total = (long long)n * oh * ow * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    long long t = i / c8;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const int b = (int)(t / oh);
+    u32x4 m = {0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};   // -inf pairs
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if ((unsigned)iy >= (unsigned)h) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((long long)b * h + iy) * w + ix) * c + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = max2bf(m[e], v[e]);
+      }
+    }
+    *reinterpret_cast<u32x4*>(y + i * 8) = m;
+  }
+}
+
+// ---- GroupNorm(32) + ReLU ------------------------------------------------------------------------
+struct GnK {
+  int nseg, n, c, groups, cpg8;   // cpg8 = 16-byte chunks per group (channels per group / 8)
+  int h[DSL_MAX_SEG], w[DSL_MAX_SEG];
+  long long off[DSL_MAX_SEG];    // pixel offset of segment start
+  float eps;
+  const uint16_t* x;
+  uint16_t* y;
+  const float* gamma;
+  const float* beta;
+  float* stats;
+  const uint16_t* dy;
+  uint16_t* dx;
+  float* dgamma;
+  float* dbeta;
+  float* red;
+};
+
+constexpr int GN_PPB = 512;   // pixels per block
+
+// pass 1 of forward: sum / sumsq per (seg, img, group) -> red (pre-zeroed)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
+  __shared__ float sh[2][256];
+  const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
+  const int hw = p.h[seg] * p.w[seg];
+  const int px0 = blockIdx.x * GN_PPB;
+  if (px0 >= hw) return;
+  const int cpr = p.c / 8;                 // 16-byte chunks per pixel (32 for C=256)
+  const int ppi = 256 / cpr;               // pixels per iteration
+  const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
+  const uint16_t* base = p.x + (p.off[seg] + (long long)img * hw) * p.c;
+  float s = 0.f, ss = 0.f;
+  const int px1 = min(px0 + GN_PPB, hw);
+  for (int px = px0 + prow; px < px1; px += ppi) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long long)px * p.c + chunk * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = bflo(v[e]), b = bfhi(v[e]);
+      s += a + b;
+      ss += a * a + b * b;
+    }
+  }
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = ss;
+  __syncthreads();
+  // threads [0, groups): reduce over the cpg8 chunks of the group and the ppi pixel rows
+  if (threadIdx.x < p.groups) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < ppi; ++r)
+      for (int k = 0; k < p.cpg8; ++k) {
+        a += sh[0][r * cpr + threadIdx.x * p.cpg8 + k];
+        b += sh[1][r * cpr + threadIdx.x * p.cpg8 + k];
+      }
+    float* dst = p.red + ((long long)si * p.groups + threadIdx.x) * 2;
+    atomicAdd(dst, a);
+    atomicAdd(dst + 1, b);
+  }
+}
+
+// pass 2 of forward: y = relu((x-mean)*rstd*gamma+beta); also writes (mean, rstd) to stats
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
+  const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
+  const int hw = p.h[seg] * p.w[seg];
+  const int px0 = blockIdx.x * GN_PPB;
+  if (px0 >= hw) return;
+  const int cpr = p.c / 8, ppi = 256 / cpr;
+  const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
+  const int grp = chunk / p.cpg8;
+  const float cnt = (float)hw * (float)(p.c / p.groups);
+  const float* rd = p.red + ((long long)si * p.groups + grp) * 2;
+  const float mean = rd[0] / cnt;
+  const float var = fmaxf(rd[1] / cnt - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + p.eps);
+  if (blockIdx.x == 0 && prow == 0 && (chunk % p.cpg8) == 0) {
+    float* st = p.stats + ((long long)si * p.groups + grp) * 2;
+    st[0] = mean;
+    st[1] = rstd;
+  }
+  float ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ga[e] = p.gamma[chunk * 8 + e] * rstd;
+    be[e] = p.beta[chunk * 8 + e] - mean * ga[e];
+  }
+  const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
+  const int px1 = min(px0 + GN_PPB, hw);
+  for (int px = px0 + prow; px < px1; px += ppi) {
+    const long long o = ibase + (long long)px * p.c + chunk * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + o);
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = fmaxf(bflo(v[e]) * ga[2 * e] + be[2 * e], 0.f);
+      const float b = fmaxf(bfhi(v[e]) * ga[2 * e + 1] + be[2 * e + 1], 0.f);
+      r[e] = pack2bf(a, b);
+    }
+    *reinterpret_cast<u32x4*>(p.y + o) = r;
+  }
+}
+
+// backward pass 1: per (seg,img,group) s1 = sum dz*gamma, s2 = sum dz*gamma*xhat -> red;
+// per channel dgamma += sum dz*xhat, dbeta += sum dz   (dz = dy * [gamma*xhat+beta > 0])
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnK p) {
+  __shared__ float sh[256 * 18];
+  const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
+  const int hw = p.h[seg] * p.w[seg];
+  const int px0 = blockIdx.x * GN_PPB;
+  if (px0 >= hw) return;
+  const int cpr = p.c / 8, ppi = 256 / cpr;
+  const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
+  const int grp = chunk / p.cpg8;
+  const float* st = p.stats + ((long long)si * p.groups + grp) * 2;
+  const float mean = st[0], rstd = st[1];
+  float ga[8], be[8], dg[8], db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ga[e] = p.gamma[chunk * 8 + e];
+    be[e] = p.beta[chunk * 8 + e];
+    dg[e] = 0.f;
+    db[e] = 0.f;
+  }
+  float s1 = 0.f, s2 = 0.f;
+  const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
+  const int px1 = min(px0 + GN_PPB, hw);
+  for (int px = px0 + prow; px < px1; px += ppi) {
+    const long long o = ibase + (long long)px * p.c + chunk * 8;
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + o);
+    const u32x4 gv = *reinterpret_cast<const u32x4*>(p.dy + o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xx = (e & 1) ? bfhi(xv[e >> 1]) : bflo(xv[e >> 1]);
+      const float gg = (e & 1) ? bfhi(gv[e >> 1]) : bflo(gv[e >> 1]);
+      const float xh = (xx - mean) * rstd;
+      const float dz = (xh * ga[e] + be[e] > 0.f) ? gg : 0.f;
+      dg[e] += dz * xh;
+      db[e] += dz;
+      s1 += dz * ga[e];
+      s2 += dz * ga[e] * xh;
+    }
+  }
+  float* my = sh + threadIdx.x * 18;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    my[e] = dg[e];
+    my[8 + e] = db[e];
+  }
+  my[16] = s1;
+  my[17] = s2;
+  __syncthreads();
+  // channel sums: thread t < c handles channel t
+  for (int ch = threadIdx.x; ch < p.c; ch += 256) {
+    const int ck = ch / 8, e = ch % 8;
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < ppi; ++r) {
+      a += sh[(r * cpr + ck) * 18 + e];
+      b += sh[(r * cpr + ck) * 18 + 8 + e];
+    }
+    atomicAdd(p.dgamma + ch, a);
+    atomicAdd(p.dbeta + ch, b);
+  }
+  if (threadIdx.x < p.groups) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < ppi; ++r)
+      for (int k = 0; k < p.cpg8; ++k) {
+        a += sh[(r * cpr + threadIdx.x * p.cpg8 + k) * 18 + 16];
+        b += sh[(r * cpr + threadIdx.x * p.cpg8 + k) * 18 + 17];
+      }
+    float* dst = p.red + ((long long)si * p.groups + threadIdx.x) * 2;
+    atomicAdd(dst, a);
+    atomicAdd(dst + 1, b);
+  }
+}
+
+// backward pass 2: dx = rstd * (dz*gamma - (s1 + xhat*s2)/cnt)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnK p) {
+  const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
+  const int hw = p.h[seg] * p.w[seg];
+  const int px0 = blockIdx.x * GN_PPB;
+  if (px0 >= hw) return;
+  const int cpr = p.c / 8, ppi = 256 / cpr;
+  const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
+  const int grp = chunk / p.cpg8;
+  const float* st = p.stats + ((long long)si * p.groups + grp) * 2;
+  const float mean = st[0], rstd = st[1];
+  const float cnt = (float)hw * (float)(p.c / p.groups);
+  const float* rd = p.red + ((long long)si * p.groups + grp) * 2;
+  const float m1 = rd[0] / cnt, m2 = rd[1] / cnt;
+  float ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ga[e] = p.gamma[chunk * 8 + e];
+    be[e] = p.beta[chunk * 8 + e];
+  }
+  const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
+  const int px1 = min(px0 + GN_PPB, hw);
+  for (int px = px0 + prow; px < px1; px += ppi) {
+    const long long o = ibase + (long long)px * p.c + chunk * 8;
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + o);
+    const u32x4 gv = *reinterpret_cast<const u32x4*>(p.dy + o);
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xx = (e & 1) ? bfhi(xv[e >> 1]) : bflo(xv[e >> 1]);
+      const float gg = (e & 1) ? bfhi(gv[e >> 1]) : bflo(gv[e >> 1]);
+      const float xh = (xx - mean) * rstd;
+      const float dz = (xh * ga[e] + be[e] > 0.f) ? gg : 0.f;
+      r[e] = rstd * (dz * ga[e] - m1 - xh * m2);
+    }
+    u32x4 ov = {pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7])};
+    *reinterpret_cast<u32x4*>(p.dx + o) = ov;
+  }
+}
+
+// ---- backward of nearest upsample: out(h,w) = sum of children in g(ch,cw) ----------------------
+__global__ void sum_children_kernel(const uint16_t* __restrict__ g, uint16_t* __restrict__ out, int n,
+                                    int h, int w, int ch, int cw, int c) {
+  const int c8 = c / 8;
+  const long long total = (long long)n * h * w * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    long long t = i / c8;
+    const int x = (int)(t % w);
+    t /= w;
+    const int y = (int)(t % h);
+    const int b = (int)(t / h);
+    // child (cy,cx) reads parent (cy*h/ch, cx*w/cw): children of y are cy in [ceil(y*ch/h), ceil((y+1)*ch/h))
+    const int cy0 = (y * ch + h - 1) / h, cy1 = ((y + 1) * ch + h - 1) / h;
+    const int cx0 = (x * cw + w - 1) / w, cx1 = ((x + 1) * cw + w - 1) / w;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int cy = cy0; cy < cy1 && cy < ch; ++cy)
+      for (int cx = cx0; cx < cx1 && cx < cw; ++cx) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(g + (((long long)b * ch + cy) * cw + cx) * c + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[2 * e] += bflo(v[e]);
+          a[2 * e + 1] += bfhi(v[e]);
+        }
+      }
+    u32x4 o = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(a[4], a[5]), pack2bf(a[6], a[7])};
+    *reinterpret_cast<u32x4*>(out + i * 8) = o;
+  }
+}
+
+// ---- column sums of a bf16 [rows][ld] matrix ---------------------------------------------------
+constexpr int CS_RPB = 1024;
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ x, float* __restrict__ out,
+                                                      long long rows, int c, int ld) {
+  __shared__ float sh[256 * 8];
+  const int cpr = (c + 7) / 8;                 // chunks per row actually needed
+  const int ppi = 256 / cpr;
+  const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long r0 = (long long)blockIdx.x * CS_RPB, r1 = min(r0 + CS_RPB, rows);
+  if (prow < ppi)
+    for (long long r = r0 + prow; r < r1; r += ppi) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ld + chunk * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[2 * e] += bflo(v[e]);
+        a[2 * e + 1] += bfhi(v[e]);
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh[threadIdx.x * 8 + e] = (prow < ppi) ? a[e] : 0.f;
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    float s = 0.f;
+    for (int r = 0; r < ppi; ++r) s += sh[(r * cpr + ch / 8) * 8 + (ch % 8)];
+    atomicAdd(out + ch, s);
+  }
+}
+
+int fill_gn(const dsl_gn_desc* d, GnK& k, long long* total_px) {
+  memset(&k, 0, sizeof(k));
+  k.nseg = d->nseg; k.n = d->n; k.c = d->c; k.groups = d->groups;
+  k.cpg8 = d->c / d->groups / 8;
+  long long off = 0;
+  for (int s = 0; s < d->nseg; ++s) {
+    k.h[s] = d->h[s]; k.w[s] = d->w[s]; k.off[s] = off;
+    off += (long long)d->n * d->h[s] * d->w[s];
+  }
+  *total_px = off;
+  k.eps = d->eps;
+  k.x = (const uint16_t*)d->x; k.y = (uint16_t*)d->y; k.gamma = d->gamma; k.beta = d->beta;
+  k.stats = d->stats; k.dy = (const uint16_t*)d->dy; k.dx = (uint16_t*)d->dx;
+  k.dgamma = d->dgamma; k.dbeta = d->dbeta; k.red = d->red;
+  return 0;
+}
+
+int gn_check(const dsl_gn_desc* d, const char* who) {
+  DSL_CHECK(d && d->nseg >= 1 && d->nseg <= DSL_MAX_SEG, "%s: bad descriptor", who);
+  DSL_CHECK(d->c % 8 == 0 && d->c <= 256 * 8 && 256 % (d->c / 8) == 0, "%s: unsupported C=%d", who, d->c);
+  DSL_CHECK(d->groups > 0 && d->c % d->groups == 0 && (d->c / d->groups) % 8 == 0 && d->groups <= 256,
+            "%s: channels per group must be a multiple of 8 (C=%d groups=%d)", who, d->c, d->groups);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dsl_pack_image(const float* img, void* out, int n, int h, int w, void* stream) {
+  DSL_CHECK(img && out && n > 0 && h > 0 && w > 0, "dsl_pack_image: bad arguments");
+  const long long total = (long long)n * h * w;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_image_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, (uint16_t*)out, n, h, w);
+  DSL_LAUNCH_CHECK("pack_image_kernel");
+  return 0;
+}
+
+extern "C" int dsl_maxpool3x3s2(const void* x, void* y, int n, int h, int w, int c, void* stream) {
+  DSL_CHECK(x && y && c % 8 == 0, "dsl_maxpool3x3s2: bad arguments (C=%d)", c);
+  const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
+  const long long total = (long long)n * oh * ow * (c / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                     (uint16_t*)y, n, h, w, c, oh, ow);
+  DSL_LAUNCH_CHECK("maxpool_kernel");
+  return 0;
+}
+
+extern "C" int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream) {
+  if (gn_check(d, "dsl_groupnorm_relu_fwd")) return -1;
+  DSL_CHECK(d->x && d->y && d->gamma && d->beta && d->stats && d->red, "dsl_groupnorm_relu_fwd: null pointer");
+  GnK k;
+  long long tot;
+  fill_gn(d, k, &tot);
+  int maxhw = 0;
+  for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
+  dim3 grid((maxhw + GN_PPB - 1) / GN_PPB, d->nseg * d->n);
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(d->red, 0, sizeof(float) * 2 * d->nseg * d->n * d->groups, st);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, k);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, st, k);
+  DSL_LAUNCH_CHECK("gn forward");
+  return 0;
+}
+
+extern "C" int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream) {
+  if (gn_check(d, "dsl_groupnorm_relu_bwd")) return -1;
+  DSL_CHECK(d->x && d->dy && d->dx && d->gamma && d->beta && d->stats && d->red && d->dgamma && d->dbeta,
+            "dsl_groupnorm_relu_bwd: null pointer");
+  GnK k;
+  long long tot;
+  fill_gn(d, k, &tot);
+  int maxhw = 0;
+  for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
+  dim3 grid((maxhw + GN_PPB - 1) / GN_PPB, d->nseg * d->n);
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(d->red, 0, sizeof(float) * 2 * d->nseg * d->n * d->groups, st);
+  hipMemsetAsync(d->dgamma, 0, sizeof(float) * d->c, st);
+  hipMemsetAsync(d->dbeta, 0, sizeof(float) * d->c, st);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, st, k);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, st, k);
+  DSL_LAUNCH_CHECK("gn backward");
+  return 0;
+}
+
+extern "C" int dsl_sum2x2(const void* g, void* out, int n, int h, int w, int ch, int cw, int c, void* stream) {
+  DSL_CHECK(g && out && c % 8 == 0, "dsl_sum2x2: bad arguments");
+  const long long total = (long long)n * h * w * (c / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(sum_children_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)g,
+                     (uint16_t*)out, n, h, w, ch, cw, c);
+  DSL_LAUNCH_CHECK("sum_children_kernel");
+  return 0;
+}
+
+extern "C" int dsl_colsum(const void* x, float* out, long rows, int c, int ld, void* stream) {
+  DSL_CHECK(x && out && c > 0 && c <= 2048 && ld % 8 == 0 && ld >= c, "dsl_colsum: bad arguments c=%d ld=%d", c, ld);
+  DSL_CHECK((c + 7) / 8 <= 256, "dsl_colsum: too many channels");
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(out, 0, sizeof(float) * c, st);
+  const int blocks = (int)((rows + CS_RPB - 1) / CS_RPB);
+  if (blocks > 0)
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)x, out, (long long)rows, c, ld);
+  DSL_LAUNCH_CHECK("colsum_kernel");
+  return 0;
+}

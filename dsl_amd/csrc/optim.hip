@@ -1,0 +1,142 @@
+// Flat-buffer optimizer / EMA kernels (HBM-bound, float4).  Replace torch.optim.SGD +
+// clip_grad_norm_ (mmcv OptimizerHook wired at mmdet/apis/train.py:111,157-166) and the EMA teacher
+// lerp of mmdet/runner/hooks/semi_epoch_based_runner.py:368-409 of the reference.
+#include "common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long i = n4 * 4; i < n; ++i) s += x[i] * x[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ m, uint16_t* __restrict__ p16,
+                                                  const uint8_t* __restrict__ group, long long n, float lr,
+                                                  float mom, float wd, float blr, float bwd,
+                                                  const float* gnorm_sq, float max_norm, int first) {
+  float clip = 1.f;
+  if (gnorm_sq) clip = fminf(max_norm / (sqrtf(*gnorm_sq) + 1e-6f), 1.f);
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 pv = *reinterpret_cast<const f32x4*>(p + 4 * i);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 4 * i);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + 4 * i);
+    const uint32_t gr = *reinterpret_cast<const uint32_t*>(group + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool b = ((gr >> (8 * e)) & 0xff) != 0;
+      const float l = b ? lr * blr : lr, w = b ? wd * bwd : wd;
+      const float d = gv[e] * clip + w * pv[e];
+      mv[e] = first ? d : mom * mv[e] + d;
+      pv[e] -= l * mv[e];
+    }
+    *reinterpret_cast<f32x4*>(p + 4 * i) = pv;
+    *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
+    if (p16) *reinterpret_cast<u32x2*>(p16 + 4 * i) = u32x2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+  }
+}
+
+__global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long long n, float keep) {
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 tv = *reinterpret_cast<const f32x4*>(t + 4 * i);
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(s + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tv[e] = tv[e] * keep + sv[e] * (1.f - keep);
+    *reinterpret_cast<f32x4*>(t + 4 * i) = tv;
+  }
+}
+
+__global__ void cast_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, long long n) {
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    *reinterpret_cast<u32x2*>(y + 4 * i) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+  }
+}
+
+// KRSC fp32 [cout][taps][cin] -> CRSK bf16 [cin][taps][cout_pad], out[ci][t][co] = w[co][t][ci]*scale[co]
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                  uint16_t* __restrict__ out, int cout, int cout_pad, int taps, int cin) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < cout && ci < cin) {
+      v = w[((long long)co * taps + t) * cin + ci];
+      if (scale) v *= scale[co];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < cin && co < cout_pad) out[((long long)ci * taps + t) * cout_pad + co] = f2bf(tile[tx][r]);
+  }
+}
+
+int nblocks(long long n4, int cap) {
+  long long b = (n4 + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int dsl_sumsq(const float* x, long n, float* out, void* stream) {
+  DSL_CHECK(x && out && n >= 0, "dsl_sumsq: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n / 4, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
+  DSL_LAUNCH_CHECK("sumsq_kernel");
+  return 0;
+}
+
+extern "C" int dsl_sgd_step(float* p, const float* g, float* m, void* p16, const uint8_t* group, long n, float lr,
+                            float momentum, float wd, float bias_lr_mult, float bias_decay_mult,
+                            const float* gnorm_sq, float max_norm, int first_step, void* stream) {
+  DSL_CHECK(p && g && m && group && n % 4 == 0, "dsl_sgd_step: bad arguments (n must be a multiple of 4)");
+  hipLaunchKernelGGL(sgd_kernel, dim3(nblocks(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                     (uint16_t*)p16, group, (long long)n, lr, momentum, wd, bias_lr_mult, bias_decay_mult, gnorm_sq,
+                     max_norm, first_step);
+  DSL_LAUNCH_CHECK("sgd_kernel");
+  return 0;
+}
+
+extern "C" int dsl_ema_lerp(float* teacher, const float* student, long n, float keep, void* stream) {
+  DSL_CHECK(teacher && student && n % 4 == 0, "dsl_ema_lerp: bad arguments");
+  hipLaunchKernelGGL(ema_kernel, dim3(nblocks(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream, teacher, student,
+                     (long long)n, keep);
+  DSL_LAUNCH_CHECK("ema_kernel");
+  return 0;
+}
+
+extern "C" int dsl_cast_bf16(const float* x, void* y, long n, void* stream) {
+  DSL_CHECK(x && y && n % 4 == 0, "dsl_cast_bf16: bad arguments");
+  hipLaunchKernelGGL(cast_kernel, dim3(nblocks(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y,
+                     (long long)n);
+  DSL_LAUNCH_CHECK("cast_kernel");
+  return 0;
+}
+
+extern "C" int dsl_pack_dgrad(const float* w, const float* scale, void* out, int cout, int cout_pad, int taps, int cin,
+                              void* stream) {
+  DSL_CHECK(w && out && cout > 0 && cout_pad >= cout && taps > 0 && cin > 0, "dsl_pack_dgrad: bad arguments");
+  dim3 grid((cin + 31) / 32, (cout_pad + 31) / 32, taps);
+  hipLaunchKernelGGL(pack_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, scale, (uint16_t*)out, cout,
+                     cout_pad, taps, cin);
+  DSL_LAUNCH_CHECK("pack_dgrad_kernel");
+  return 0;
+}

@@ -1,0 +1,106 @@
+"""Descriptor builders for the libdsl_hip.so entry points, over torch CUDA tensors used purely as
+device memory.  Every function returns the ctypes descriptor (keep it alive while it is referenced
+from an op list) and, unless `launch=False`, enqueues the kernel on the current stream."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+lib = L.lib
+
+
+def _segs(shapes):
+    return L.seg5([s[0] for s in shapes]), L.seg5([s[1] for s in shapes])
+
+
+def conv_desc(src, wgt, dst, *, n, grid, src_hw, dst_hw, cs, cd, cd_pad, ldd, kh, kw, stride=1, pad=0,
+              mode=0, os=1, flags=0, scale=None, bias=None, addend=None, lda=0, add_hw=None, mask=None,
+              ldm=0):
+    """grid/src_hw/dst_hw/add_hw: list of (h, w) per level segment."""
+    d = L.ConvDesc()
+    d.nseg, d.n = len(grid), n
+    d.gh, d.gw = _segs(grid)
+    d.sh, d.sw = _segs(src_hw)
+    d.dh, d.dw = _segs(dst_hw)
+    if add_hw is not None:
+        d.ah, d.aw = _segs(add_hw)
+    d.cs, d.cd, d.cd_pad, d.ldd, d.lda, d.ldm = cs, cd, cd_pad, ldd, lda, ldm
+    d.kh, d.kw, d.stride, d.pad, d.mode, d.os, d.flags = kh, kw, stride, pad, mode, os, flags
+    d.src, d.wgt, d.dst = L.ptr(src), L.ptr(wgt), L.ptr(dst)
+    d.scale, d.bias, d.addend, d.mask = L.ptr(scale), L.ptr(bias), L.ptr(addend), L.ptr(mask)
+    d._keep = (src, wgt, dst, scale, bias, addend, mask)
+    return d
+
+
+def conv2d(*a, **k):
+    d = conv_desc(*a, **k)
+    L.check(lib.dsl_conv2d(C.byref(d), L.stream_ptr()), 'dsl_conv2d')
+    return d
+
+
+def wgrad_desc(dy, x, dw, *, n, grid, src_hw, cs, cy, cd, kh, kw, stride=1, pad=0, scale=None, db=None,
+               workspace=None):
+    d = L.WgradDesc()
+    d.nseg, d.n = len(grid), n
+    d.gh, d.gw = _segs(grid)
+    d.sh, d.sw = _segs(src_hw)
+    d.cs, d.cy, d.cd, d.kh, d.kw, d.stride, d.pad = cs, cy, cd, kh, kw, stride, pad
+    d.splits = 0
+    d.splits = lib.dsl_wgrad_splits(C.byref(d))
+    d.dy, d.x, d.scale, d.dw, d.db = L.ptr(dy), L.ptr(x), L.ptr(scale), L.ptr(dw), L.ptr(db)
+    need = lib.dsl_wgrad_workspace_bytes(C.byref(d))
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dy.device)
+    assert workspace.numel() * workspace.element_size() >= need, (workspace.numel(), need)
+    d.workspace, d.workspace_bytes = L.ptr(workspace), workspace.numel() * workspace.element_size()
+    d._keep = (dy, x, dw, scale, db, workspace)
+    return d
+
+
+def wgrad_workspace_bytes(*, n, grid, src_hw, cs, cy, cd, kh, kw, stride=1, pad=0):
+    d = L.WgradDesc()
+    d.nseg, d.n = len(grid), n
+    d.gh, d.gw = _segs(grid)
+    d.sh, d.sw = _segs(src_hw)
+    d.cs, d.cy, d.cd, d.kh, d.kw, d.stride, d.pad = cs, cy, cd, kh, kw, stride, pad
+    d.splits = 0
+    return lib.dsl_wgrad_workspace_bytes(C.byref(d))
+
+
+def conv2d_wgrad(*a, **k):
+    d = wgrad_desc(*a, **k)
+    L.check(lib.dsl_conv2d_wgrad(C.byref(d), L.stream_ptr()), 'dsl_conv2d_wgrad')
+    return d
+
+
+def gn_desc(x, y, gamma, beta, stats, red, *, n, hw, c=256, groups=32, eps=1e-5, dy=None, dx=None,
+            dgamma=None, dbeta=None):
+    d = L.GnDesc()
+    d.nseg, d.n, d.c, d.groups = len(hw), n, c, groups
+    d.h, d.w = _segs(hw)
+    d.eps = eps
+    d.x, d.y, d.gamma, d.beta, d.stats, d.red = (L.ptr(t) for t in (x, y, gamma, beta, stats, red))
+    d.dy, d.dx, d.dgamma, d.dbeta = (L.ptr(t) for t in (dy, dx, dgamma, dbeta))
+    d._keep = (x, y, gamma, beta, stats, red, dy, dx, dgamma, dbeta)
+    return d
+
+
+def fcos_desc(*, n, sizes, strides, ranges, radius=1.5, num_classes=80):
+    d = L.FcosDesc()
+    d.nlvl, d.n = len(sizes), n
+    d.h, d.w = _segs(sizes)
+    d.stride = L.seg5(strides)
+    for i, (lo, hi) in enumerate(ranges):
+        d.range_lo[i], d.range_hi[i] = float(lo), float(hi)
+    d.radius, d.num_classes = radius, num_classes
+    d.loss_weight, d.soft_weight, d.grad_scale, d.inv_world = 1.0, 0.0, 1.0, 1.0
+    d._keep = {}
+    return d
+
+
+def set_ptrs(d, **tensors):
+    for k, t in tensors.items():
+        setattr(d, k, L.ptr(t))
+        d._keep[k] = t
+    return d

@@ -1,0 +1,246 @@
+/* dsl_hip.h — C ABI of libdsl_hip.so: the MI355X (gfx950) kernels behind the FCOS R50-FPN
+ * teacher–student training step of chenbinghui1/DSL.
+ *
+ * Nothing like this exists in the reference (it is pure Python over torch/cuDNN/mmcv ops); each
+ * entry point below names the reference call it replaces (paths relative to /root/reference).
+ *
+ * Conventions:
+ *   - every function returns 0 on success, <0 on error; dsl_last_error() gives a thread-local text
+ *   - the caller owns every buffer; the library never allocates device memory; workspace sizes
+ *     are queried (dsl_*_workspace_bytes)
+ *   - kernels are enqueued on the given hipStream_t (passed as void*), no implicit device sync
+ *   - activations are NHWC bf16; tensors that span the 5 FPN levels are stored level-major:
+ *     [level][image][y][x][channel] ("segments"), which is exactly the flattened location order
+ *     of mmdet/models/dense_heads/fcos_head.py:239-258
+ *   - weights: fp32 master in KRSC = [Cout][kh][kw][Cin]; bf16 packed copies in the same order
+ *     ("fwd pack", rows padded to 64) and in CRSK = [Cin][kh][kw][CoutPad] ("dgrad pack")
+ */
+#ifndef DSL_HIP_H
+#define DSL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSL_MAX_SEG 5
+
+int dsl_version(void);
+const char* dsl_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on MFMA (forward, data-gradient) — replaces F.conv2d / cuDNN in
+ * mmdet/models/backbones/resnet.py:262-301,598-645, necks/fpn.py:150-202,
+ * dense_heads/anchor_free_head.py:197-217, fcos_head.py:154-156 and their autograd backward.
+ * One "compute grid" pixel (seg, n, y, x) gathers, per tap (r, s), a contiguous channel vector of
+ * the source:   mode 0 (forward):   (sy, sx) = (y*stride + r - pad, x*stride + s - pad)
+ *               mode 1 (transposed): (sy, sx) = ((y + pad - r)/stride, (x + pad - s)/stride) if divisible
+ * and writes to destination pixel (y*os, x*os).
+ * Epilogue: v = acc*scale[c] + bias[c]; [mask_first: v *= (mask>0)]; v += addend (same index, or
+ * nearest-upsampled from (ah, aw) when DSL_CONV_ADD_UPSAMPLE); [mask_last: v *= (mask>0)];
+ * [relu]; store bf16 or fp32.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+  DSL_CONV_RELU_OUT = 1,      /* ReLU in the epilogue */
+  DSL_CONV_RELU_IN = 2,       /* ReLU applied to the gathered source (FPN P7 = conv(relu(P6))) */
+  DSL_CONV_OUT_F32 = 4,       /* destination is fp32 (head logits) instead of bf16 */
+  DSL_CONV_MASK_FIRST = 8,    /* v = acc*(mask>0) + addend */
+  DSL_CONV_MASK_LAST = 16,    /* v = (acc + addend)*(mask>0) */
+  DSL_CONV_ADD_UPSAMPLE = 32, /* addend is nearest-upsampled (fpn.py:163-172) */
+  DSL_CONV_SMALL_C = 64       /* source has 8 channels (stem, image packed NHWC8) */
+};
+
+typedef struct dsl_conv_desc {
+  int32_t nseg, n;                                   /* level segments, images */
+  int32_t gh[DSL_MAX_SEG], gw[DSL_MAX_SEG];          /* compute grid per segment */
+  int32_t sh[DSL_MAX_SEG], sw[DSL_MAX_SEG];          /* source spatial size */
+  int32_t dh[DSL_MAX_SEG], dw[DSL_MAX_SEG];          /* destination spatial size */
+  int32_t ah[DSL_MAX_SEG], aw[DSL_MAX_SEG];          /* addend spatial size (ADD_UPSAMPLE) */
+  int32_t cs;                                        /* source channels (GEMM-K per tap) */
+  int32_t cd;                                        /* real destination channels */
+  int32_t cd_pad;                                    /* weight rows (multiple of 64) */
+  int32_t ldd, lda, ldm;                             /* row strides (elements) of dst/addend/mask */
+  int32_t kh, kw, stride, pad, mode, os, flags;
+  const void* src;                                   /* bf16 */
+  const void* wgt;                                   /* bf16 [cd_pad][kh*kw*cs] */
+  void* dst;                                         /* bf16 or fp32 */
+  const float* scale;                                /* [cd] or NULL (=1) */
+  const float* bias;                                 /* [cd] or NULL (=0) */
+  const void* addend;                                /* bf16 or NULL */
+  const void* mask;                                  /* bf16 or NULL */
+} dsl_conv_desc;
+
+int dsl_conv2d(const dsl_conv_desc* d, void* stream);
+
+/* Weight gradient: dW[co][r][s][ci] = scale[co] * sum_p dY[p][co] * X[p@(r,s)][ci]  (fp32, KRSC).
+ * Split-K over pixels into a caller-owned workspace, then a reduce pass.  Optionally also
+ * db[co] = sum_p dY[p][co].  Replaces the autograd backward of the same F.conv2d calls. */
+typedef struct dsl_wgrad_desc {
+  int32_t nseg, n;
+  int32_t gh[DSL_MAX_SEG], gw[DSL_MAX_SEG];          /* dY spatial size (conv output grid) */
+  int32_t sh[DSL_MAX_SEG], sw[DSL_MAX_SEG];          /* X spatial size (conv input) */
+  int32_t cs;                                        /* X channels (Cin) */
+  int32_t cy;                                        /* dY channels = row stride (multiple of 64) */
+  int32_t cd;                                        /* real Cout (rows of dW written) */
+  int32_t kh, kw, stride, pad;
+  int32_t splits;                                    /* from dsl_wgrad_splits() */
+  const void* dy;                                    /* bf16 */
+  const void* x;                                     /* bf16 */
+  const float* scale;                                /* [cd] or NULL */
+  float* dw;                                         /* fp32 [cd][kh*kw*cs] */
+  float* db;                                         /* fp32 [cd] or NULL */
+  void* workspace;
+  size_t workspace_bytes;
+} dsl_wgrad_desc;
+
+int dsl_wgrad_splits(const dsl_wgrad_desc* d);
+size_t dsl_wgrad_workspace_bytes(const dsl_wgrad_desc* d);
+int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Memory-bound fused layers
+ * ---------------------------------------------------------------------------------------- */
+/* NCHW fp32 image -> NHWC8 bf16 (channels 3..7 zero).  Replaces the implicit layout of
+ * SingleStageDetector.extract_feat's input (detectors/single_stage.py:40-45). */
+int dsl_pack_image(const float* img_nchw, void* out_nhwc8, int n, int h, int w, void* stream);
+
+/* 3x3 stride-2 pad-1 max pool, NHWC bf16 (resnet.py:610,638). */
+int dsl_maxpool3x3s2(const void* x, void* y, int n, int h, int w, int c, void* stream);
+
+/* GroupNorm(32 groups, eps) + ReLU over level-major NHWC bf16 (mmcv ConvModule norm+act as used at
+ * anchor_free_head.py:104-133).  stats = [nseg*n*groups][2] fp32 (mean, rstd), written by fwd. */
+typedef struct dsl_gn_desc {
+  int32_t nseg, n, c, groups;
+  int32_t h[DSL_MAX_SEG], w[DSL_MAX_SEG];
+  float eps;
+  const void* x;          /* bf16 pre-norm conv output */
+  void* y;                /* bf16 relu(gn(x)) */
+  const float* gamma;
+  const float* beta;
+  float* stats;
+  /* backward only */
+  const void* dy;         /* bf16 grad wrt y */
+  void* dx;               /* bf16 grad wrt x */
+  float* dgamma;          /* fp32 [c], overwritten */
+  float* dbeta;           /* fp32 [c], overwritten */
+  float* red;             /* fp32 scratch [nseg*n*groups][2] */
+} dsl_gn_desc;
+int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream);
+int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream);
+
+/* out[n][y][x][c] = sum over the children of (y,x) in g (backward of the FPN nearest upsample,
+ * fpn.py:163-172).  out is (h, w), g is (ch, cw) (normally 2h x 2w); bf16. */
+int dsl_sum2x2(const void* g, void* out, int n, int h, int w, int ch, int cw, int c, void* stream);
+
+/* per-channel column sum of a bf16 [rows][ld] matrix -> fp32 [c]  (conv bias gradient) */
+int dsl_colsum(const void* x, float* out, long rows, int c, int ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FCOS targets and losses (fcos_head.py:170-338,550-726; losses/focal_loss.py:11-56;
+ * losses/iou_loss.py:85-102; losses/cross_entropy_loss.py:73-112)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dsl_fcos_desc {
+  int32_t nlvl, n;                     /* levels, images */
+  int32_t h[DSL_MAX_SEG], w[DSL_MAX_SEG], stride[DSL_MAX_SEG];
+  float range_lo[DSL_MAX_SEG], range_hi[DSL_MAX_SEG];
+  float radius;                        /* center_sample_radius (1.5) */
+  int32_t num_classes;                 /* 80 */
+  /* ground truth, concatenated over images; gt_off[n+1] prefix offsets (device int32) */
+  const float* gt_boxes;               /* [G][4] xyxy */
+  const int64_t* gt_labels;            /* [G] */
+  const int32_t* gt_off;               /* [n+1] */
+  const float* ig_boxes;               /* ignore boxes or NULL */
+  const int32_t* ig_off;               /* [n+1] or NULL */
+  /* outputs of assign, level-major [lvl][img][y][x] */
+  int64_t* labels;                     /* [M] in [0, num_classes] */
+  float* bbox_targets;                 /* [M][4], already / stride (norm_on_bbox) */
+  int32_t* assign_idx;                 /* [M] argmin gt index within the image, -1 = background */
+  float* cls_weight;                   /* [M] ignore weight * stream weight */
+  float* pos_weight;                   /* [M] stream weight (bbox / centerness) */
+  float* stats;                        /* [8]: 0 num_pos, 1 sum ctr targets (this rank) ... */
+  float loss_weight;                   /* unlabeled-stream weight (DSL) ; 1.0 = off */
+  /* head outputs */
+  const float* cls_logits;             /* [M][ld_cls] fp32 */
+  const float* regctr;                 /* [M][ld_rc] fp32: raw conv_reg (4) + centerness logit (1) */
+  int32_t ld_cls, ld_rc;
+  const float* scales;                 /* [nlvl] Scale parameters */
+  /* [0] = sum over ranks of num_pos, [1] = sum over ranks of sum(ctr targets); the kernel applies
+   * max(x*inv_world, 1) and max(x*inv_world, 1e-6)  (reduce_mean, fcos_head.py:264-274) */
+  const float* norm;
+  /* gradients (bf16, padded rows) and loss sums */
+  void* g_cls;  int32_t ld_gcls;       /* bf16 [M][ld_gcls] */
+  void* g_rc;   int32_t ld_grc;        /* bf16 [M][ld_grc] */
+  float* g_scales;                     /* fp32 [DSL_MAX_SEG], overwritten */
+  float* losses;                       /* fp32 [4]: cls, bbox, centerness, sisoft (overwritten) */
+  float soft_weight;                   /* effective sisoft weight (0 = off) */
+  float grad_scale;                    /* d(total)/d(each loss), normally 1 */
+  float inv_world;                     /* 1/world_size: norm[] holds the SUM over ranks of stats[0:2] */
+} dsl_fcos_desc;
+
+int dsl_fcos_points(const dsl_fcos_desc* d, float* points /* [P][2] */, void* stream);
+int dsl_fcos_assign(const dsl_fcos_desc* d, void* stream);
+int dsl_fcos_loss(const dsl_fcos_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer / EMA over flat fp32 buffers (mmcv OptimizerHook + torch SGD, wired at
+ * apis/train.py:111,157-166; EMA at runner/hooks/semi_epoch_based_runner.py:368-409)
+ * ---------------------------------------------------------------------------------------- */
+int dsl_sumsq(const float* x, long n, float* out /* [1], accumulated */, void* stream);
+/* p -= lr*lr_mult[i] * (m = mom*m + (g*clip + wd*wd_mult[i]*p)); also writes bf16(p) to p16.
+ * clip = min(max_norm/(sqrt(*gnorm_sq)+1e-6), 1) when gnorm_sq != NULL.  group[i] in {0,1}:
+ * 1 = bias group (lr*bias_lr_mult, wd*bias_decay_mult). */
+int dsl_sgd_step(float* p, const float* g, float* m, void* p16, const uint8_t* group, long n,
+                 float lr, float momentum, float wd, float bias_lr_mult, float bias_decay_mult,
+                 const float* gnorm_sq, float max_norm, int first_step, void* stream);
+int dsl_ema_lerp(float* teacher, const float* student, long n, float keep, void* stream);
+int dsl_cast_bf16(const float* x, void* y, long n, void* stream);
+/* KRSC fp32 -> CRSK bf16 ("dgrad pack"), optional per-cout scale fold. */
+int dsl_pack_dgrad(const float* w, const float* scale, void* out, int cout, int cout_pad, int taps,
+                   int cin, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Teacher sweep post-processing (fcos_head.py:406-548, core/post_processing/bbox_nms.py:7-94)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dsl_det_desc {
+  int32_t nlvl, n;
+  int32_t h[DSL_MAX_SEG], w[DSL_MAX_SEG], stride[DSL_MAX_SEG];
+  int32_t num_classes, nms_pre, max_per_img;
+  float score_thr, iou_thr;
+  const float* cls_logits; int32_t ld_cls;
+  const float* regctr; int32_t ld_rc;        /* raw conv_reg; scale, relu, *stride applied here */
+  const float* scales;
+  const float* img_shapes;                   /* [n][2] (h, w) clip bounds */
+  const float* scale_factors;                /* [n][4] */
+  float* dets;                               /* [n][max_per_img][5] */
+  int64_t* det_labels;                       /* [n][max_per_img] */
+  int32_t* det_count;                        /* [n] */
+  void* workspace; size_t workspace_bytes;
+} dsl_det_desc;
+size_t dsl_detect_workspace_bytes(const dsl_det_desc* d);
+int dsl_fcos_detect(const dsl_det_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Op-list executor: run a prebuilt sequence of the ops above with one call (keeps the per-step
+ * host cost of ~400 launches out of Python).
+ * ---------------------------------------------------------------------------------------- */
+enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, DSL_OP_MAXPOOL = 5,
+       DSL_OP_SUM2X2 = 6, DSL_OP_COLSUM = 7, DSL_OP_MEMSET = 8, DSL_OP_PACK_IMAGE = 9,
+       DSL_OP_ASSIGN = 10, DSL_OP_LOSS = 11 };
+typedef struct dsl_op {
+  int32_t kind;
+  int32_t i[7];            /* small integer arguments for the simple ops */
+  const void* desc;        /* pointer to the op's descriptor (host memory, must stay alive) */
+  void* p[4];              /* device pointers for the simple ops */
+  int64_t l[2];
+} dsl_op;
+int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream);
+
+/* hardware probes used by the tests */
+int dsl_probe_tr16(const uint16_t* lds_image /* 4096 u16 */, const int32_t* lane_off /* 64 u16-offsets */,
+                   uint16_t* out /* [64][4] */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,361 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain fp32 torch-CPU
+restatements of the same op on identical (bf16-representable) inputs."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    from dsl_amd import _lib as L
+    from dsl_amd import ops
+    assert torch.cuda.is_available()
+    return L, ops
+
+
+def bf(t):
+    return t.bfloat16().float()
+
+
+def nhwc(t, dev='cuda'):     # NCHW fp32 -> NHWC bf16 on device
+    return t.permute(0, 2, 3, 1).contiguous().bfloat16().to(dev)
+
+
+def from_nhwc(t):            # NHWC (bf16/fp32) device -> NCHW fp32 cpu
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def pack_w(w, cd_pad):       # OIHW fp32 -> [cd_pad][kh][kw][cin] bf16
+    co, ci, kh, kw = w.shape
+    out = torch.zeros(cd_pad, kh, kw, ci)
+    out[:co] = w.permute(0, 2, 3, 1)
+    return out.bfloat16().cuda()
+
+
+def pack_w_dgrad(w, cy):     # OIHW fp32 -> [cin][kh][kw][cy] bf16 (cout padded to cy)
+    co, ci, kh, kw = w.shape
+    out = torch.zeros(ci, kh, kw, cy)
+    out[..., :co] = w.permute(1, 2, 3, 0)
+    return out.bfloat16().cuda()
+
+
+def rnd(*shape, g=None, scale=1.0):
+    return bf(torch.randn(*shape, generator=g) * scale)
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_probe_tr16(K):
+    """Documents the ds_read_b64_tr_b16 semantics the weight-gradient kernel relies on:
+    within each 16-lane group, out[lane i][j] = in[lane 4j + (i>>2)][i & 3]."""
+    L, _ = K
+    img = torch.arange(4096, dtype=torch.int16, device='cuda')
+    off = (torch.arange(64, dtype=torch.int32) * 4).cuda()       # lane l reads u16[4l .. 4l+3]
+    out = torch.zeros(64, 4, dtype=torch.int16, device='cuda')
+    L.check(L.lib.dsl_probe_tr16(L.ptr(img), L.ptr(off), L.ptr(out), L.stream_ptr()))
+    sync()
+    got = out.cpu().numpy()
+    exp = np.zeros((64, 4), dtype=np.int16)
+    for l in range(64):
+        g, i = l // 16, l % 16
+        for j in range(4):
+            src_lane = g * 16 + 4 * j + (i >> 2)
+            exp[l, j] = src_lane * 4 + (i & 3)
+    print('tr16 lanes 0..3, 16..17:', got[:4].tolist(), got[16:18].tolist())
+    assert (got == exp).all(), got[:20].tolist()
+
+
+CONV_CASES = [
+    # name, N, Cin, Cout, H, W, k, stride, pad, flags-ish
+    ('3x3_s1', 2, 64, 128, 13, 21, 3, 1, 1),
+    ('1x1_s1', 2, 128, 64, 9, 11, 1, 1, 0),
+    ('1x1_s2', 1, 64, 256, 14, 18, 1, 2, 0),
+    ('3x3_s2', 2, 128, 128, 13, 21, 3, 2, 1),
+    ('3x3_big', 1, 256, 256, 25, 42, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_forward(K, case):
+    L, ops = K
+    _, N, Ci, Co, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case[0]) % 1000)
+    x, w = rnd(N, Ci, H, W, g=g), rnd(Co, Ci, k, k, g=g, scale=1 / math.sqrt(Ci * k * k))
+    scale, bias = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = rnd(N, Co, Ho, Wo, g=g)
+    ref = F.relu(F.conv2d(x, w, None, s, p) * scale[None, :, None, None] + bias[None, :, None, None] + res)
+    cd_pad = (Co + 63) // 64 * 64
+    y = torch.empty(N, Ho, Wo, Co, dtype=torch.bfloat16, device='cuda')
+    ops.conv2d(nhwc(x), pack_w(w, cd_pad), y, n=N, grid=[(Ho, Wo)], src_hw=[(H, W)], dst_hw=[(Ho, Wo)],
+               cs=Ci, cd=Co, cd_pad=cd_pad, ldd=Co, kh=k, kw=k, stride=s, pad=p,
+               flags=L.CONV_RELU_OUT, scale=scale.cuda(), bias=bias.cuda(), addend=nhwc(res), lda=Co)
+    sync()
+    got = from_nhwc(y)
+    assert torch.allclose(got, ref, rtol=1e-2, atol=1e-2), (got - ref).abs().max()
+    assert (got - bf(ref)).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+def test_conv_stem_small_c(K):
+    L, ops = K
+    g = torch.Generator().manual_seed(1)
+    N, H, W = 2, 37, 45
+    x, w = rnd(N, 3, H, W, g=g), rnd(64, 3, 7, 7, g=g, scale=0.1)
+    ref = F.relu(F.conv2d(x, w, None, 2, 3))
+    Ho, Wo = ref.shape[2:]
+    x8 = torch.empty(N, H, W, 8, dtype=torch.bfloat16, device='cuda')
+    L.check(L.lib.dsl_pack_image(L.ptr(x.cuda()), L.ptr(x8), N, H, W, L.stream_ptr()))
+    sync()
+    assert torch.equal(x8.float().cpu()[..., :3], x.permute(0, 2, 3, 1)) and float(x8[..., 3:].abs().max()) == 0
+    wp = torch.zeros(64, 7 * 64)      # K = 49 taps * 8 channels = 392, padded to 448
+    wp[:, :392] = torch.cat([w.permute(0, 2, 3, 1), torch.zeros(64, 7, 7, 5)], -1).reshape(64, 392)
+    y = torch.empty(N, Ho, Wo, 64, dtype=torch.bfloat16, device='cuda')
+    ops.conv2d(x8, wp.bfloat16().cuda(), y, n=N, grid=[(Ho, Wo)], src_hw=[(H, W)], dst_hw=[(Ho, Wo)], cs=8, cd=64,
+               cd_pad=64, ldd=64, kh=7, kw=7, stride=2, pad=3, flags=L.CONV_RELU_OUT | L.CONV_SMALL_C)
+    sync()
+    assert torch.allclose(from_nhwc(y), ref, rtol=1e-2, atol=1e-2)
+
+
+def _multiseg(tensors):      # list of NCHW fp32 -> level-major flat NHWC bf16 on device
+    return torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in tensors]).bfloat16().cuda()
+
+
+def test_conv_multilevel_fp32_out_ragged_channels(K):
+    """Shared-weight head predictor over 5 level segments, fp32 output with 5 real channels (ldd 8)
+    and 80 channels (ldd 80), RELU_IN on the source."""
+    L, ops = K
+    g = torch.Generator().manual_seed(2)
+    N, sizes = 2, [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)]
+    xs = [rnd(N, 256, h, w, g=g) for h, w in sizes]
+    for Co, ldd, cd_pad in ((5, 8, 64), (80, 80, 128)):
+        w = rnd(Co, 256, 3, 3, g=g, scale=0.02)
+        b = torch.randn(Co, generator=g)
+        P = sum(h * w_ for h, w_ in sizes) * N
+        y = torch.full((P, ldd), -7.0, dtype=torch.float32, device='cuda')
+        ops.conv2d(_multiseg(xs), pack_w(w, cd_pad), y, n=N, grid=sizes, src_hw=sizes, dst_hw=sizes, cs=256, cd=Co,
+                   cd_pad=cd_pad, ldd=ldd, kh=3, kw=3, stride=1, pad=1, flags=L.CONV_OUT_F32 | L.CONV_RELU_IN,
+                   bias=b.cuda())
+        sync()
+        ref = torch.cat([F.conv2d(F.relu(x), w, b, 1, 1).permute(0, 2, 3, 1).reshape(-1, Co) for x in xs])
+        got = y.cpu()
+        assert torch.allclose(got[:, :Co], ref, rtol=2e-3, atol=2e-3), (got[:, :Co] - ref).abs().max()
+        if ldd > Co:
+            assert float((got[:, Co:] + 7.0).abs().max()) == 0.0     # padding columns untouched
+
+
+def test_conv_fpn_lateral_upsample_add(K):
+    L, ops = K
+    g = torch.Generator().manual_seed(3)
+    N = 2
+    x, top = rnd(N, 128, 10, 14, g=g), rnd(N, 64, 5, 7, g=g)
+    w, b = rnd(64, 128, 1, 1, g=g, scale=0.1), torch.randn(64, generator=g)
+    ref = F.conv2d(x, w, b) + F.interpolate(top, size=(10, 14), mode='nearest')
+    y = torch.empty(N, 10, 14, 64, dtype=torch.bfloat16, device='cuda')
+    ops.conv2d(nhwc(x), pack_w(w, 64), y, n=N, grid=[(10, 14)], src_hw=[(10, 14)], dst_hw=[(10, 14)], cs=128, cd=64,
+               cd_pad=64, ldd=64, kh=1, kw=1, bias=b.cuda(), addend=nhwc(top), lda=64, add_hw=[(5, 7)],
+               flags=L.CONV_ADD_UPSAMPLE)
+    sync()
+    assert torch.allclose(from_nhwc(y), ref, rtol=1e-2, atol=1e-2)
+
+
+DGRAD_CASES = [('3x3_s1', 2, 128, 64, 11, 13, 3, 1, 1), ('3x3_s2', 1, 128, 128, 13, 21, 3, 2, 1),
+               ('1x1_s1', 2, 256, 128, 7, 9, 1, 1, 0), ('3x3_s1_pad80', 1, 256, 80, 9, 9, 3, 1, 1)]
+
+
+@pytest.mark.parametrize('case', DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
+def test_conv_dgrad_transposed(K, case):
+    """mode 1 gather == autograd input-gradient; epilogue (acc + addend) * (mask > 0)."""
+    L, ops = K
+    _, N, Ci, Co, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(len(case[0]))
+    x = rnd(N, Ci, H, W, g=g).requires_grad_()
+    w = rnd(Co, Ci, k, k, g=g, scale=1 / math.sqrt(Co * k * k))
+    yref = F.conv2d(x, w, None, s, p)
+    Ho, Wo = yref.shape[2:]
+    dy = rnd(N, Co, Ho, Wo, g=g)
+    yref.backward(dy)
+    add, msk = rnd(N, Ci, H, W, g=g), rnd(N, Ci, H, W, g=g)
+    ref = (x.grad + add) * (msk > 0)
+    cy = (Co + 63) // 64 * 64
+    dyp = torch.zeros(N, Ho, Wo, cy)
+    dyp[..., :Co] = dy.permute(0, 2, 3, 1)
+    dx = torch.empty(N, H, W, Ci, dtype=torch.bfloat16, device='cuda')
+    ops.conv2d(dyp.bfloat16().cuda(), pack_w_dgrad(w, cy), dx, n=N, grid=[(H, W)], src_hw=[(Ho, Wo)], dst_hw=[(H, W)],
+               cs=cy, cd=Ci, cd_pad=Ci, ldd=Ci, kh=k, kw=k, stride=s, pad=p, mode=1, addend=nhwc(add), lda=Ci,
+               mask=nhwc(msk), ldm=Ci, flags=L.CONV_MASK_LAST)
+    sync()
+    got = from_nhwc(dx)
+    assert torch.allclose(got, ref, rtol=1e-2, atol=2e-2), (got - ref).abs().max()
+
+
+def test_conv_dgrad_1x1_s2_scatter(K):
+    """1x1 stride-2 data gradient as a 1x1 conv on the dY grid scattered with os=2 into a zeroed dX."""
+    L, ops = K
+    g = torch.Generator().manual_seed(9)
+    N, Ci, Co, H, W = 2, 128, 64, 13, 18
+    x = rnd(N, Ci, H, W, g=g).requires_grad_()
+    w = rnd(Co, Ci, 1, 1, g=g, scale=0.1)
+    y = F.conv2d(x, w, None, 2, 0)
+    Ho, Wo = y.shape[2:]
+    dy = rnd(N, Co, Ho, Wo, g=g)
+    y.backward(dy)
+    msk = rnd(N, Ci, H, W, g=g)
+    ref = x.grad * (msk > 0)
+    dx = torch.zeros(N, H, W, Ci, dtype=torch.bfloat16, device='cuda')
+    ops.conv2d(nhwc(dy), pack_w_dgrad(w, 64), dx, n=N, grid=[(Ho, Wo)], src_hw=[(Ho, Wo)], dst_hw=[(H, W)], cs=64,
+               cd=Ci, cd_pad=Ci, ldd=Ci, kh=1, kw=1, stride=1, pad=0, mode=1, os=2, mask=nhwc(msk), ldm=Ci,
+               flags=L.CONV_MASK_FIRST)
+    sync()
+    assert torch.allclose(from_nhwc(dx), ref, rtol=1e-2, atol=1e-2)
+
+
+WG_CASES = [('3x3_s1', 2, 128, 128, 12, 17, 3, 1, 1), ('1x1_s2', 2, 256, 128, 14, 18, 1, 2, 0),
+            ('3x3_s2', 1, 128, 256, 13, 21, 3, 2, 1), ('1x1_s1_co64', 2, 128, 64, 9, 10, 1, 1, 0)]
+
+
+@pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_wgrad(K, case):
+    L, ops = K
+    _, N, Ci, Co, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(7 + len(case[0]))
+    x = rnd(N, Ci, H, W, g=g)
+    w = rnd(Co, Ci, k, k, g=g).requires_grad_()
+    y = F.conv2d(x, w, None, s, p)
+    Ho, Wo = y.shape[2:]
+    dy = rnd(N, Co, Ho, Wo, g=g)
+    y.backward(dy)
+    scale = torch.rand(Co, generator=g) + 0.5
+    ref = (w.grad * scale[:, None, None, None]).permute(0, 2, 3, 1)      # KRSC
+    dw = torch.empty(Co, k, k, Ci, dtype=torch.float32, device='cuda')
+    db = torch.empty(Co, dtype=torch.float32, device='cuda')
+    ops.conv2d_wgrad(nhwc(dy), nhwc(x), dw, n=N, grid=[(Ho, Wo)], src_hw=[(H, W)], cs=Ci, cy=Co, cd=Co, kh=k, kw=k,
+                     stride=s, pad=p, scale=scale.cuda(), db=db)
+    sync()
+    got = dw.cpu()
+    tol = 2e-2 * float(ref.abs().max())
+    assert torch.allclose(got, ref, rtol=1e-2, atol=tol), (got - ref).abs().max()
+    assert torch.allclose(db.cpu(), dy.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+
+
+def test_wgrad_multilevel_padded_cout(K):
+    """Head predictor weight gradient: 5 level segments, dY rows padded 80 -> 128 channels."""
+    L, ops = K
+    g = torch.Generator().manual_seed(21)
+    N, sizes, Co, cy = 2, [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)], 80, 128
+    xs = [rnd(N, 256, h, w, g=g) for h, w in sizes]
+    dys = [rnd(N, Co, h, w, g=g) for h, w in sizes]
+    w = torch.zeros(Co, 256, 3, 3, requires_grad=True)
+    sum((F.conv2d(x, w, None, 1, 1) * dy).sum() for x, dy in zip(xs, dys)).backward()
+    ref = w.grad.permute(0, 2, 3, 1)
+    dyp = torch.cat([torch.cat([d.permute(0, 2, 3, 1), torch.zeros(N, d.shape[2], d.shape[3], cy - Co)], -1)
+                     .reshape(-1, cy) for d in dys]).bfloat16().cuda()
+    dw = torch.empty(Co, 3, 3, 256, dtype=torch.float32, device='cuda')
+    ops.conv2d_wgrad(dyp, _multiseg(xs), dw, n=N, grid=sizes, src_hw=sizes, cs=256, cy=cy, cd=Co, kh=3, kw=3, stride=1,
+                     pad=1)
+    sync()
+    assert torch.allclose(dw.cpu(), ref, rtol=1e-2, atol=2e-2 * float(ref.abs().max()))
+
+
+def test_groupnorm_relu_fwd_bwd(K):
+    L, ops = K
+    g = torch.Generator().manual_seed(4)
+    N, sizes, Cc = 2, [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)], 256
+    xs = [rnd(N, Cc, h, w, g=g, scale=2.0).requires_grad_() for h, w in sizes]
+    gamma = (1 + 0.2 * torch.randn(Cc, generator=g)).requires_grad_()
+    beta = (0.3 * torch.randn(Cc, generator=g)).requires_grad_()
+    ys = [F.relu(F.group_norm(x, 32, gamma, beta, 1e-5)) for x in xs]
+    dys = [rnd(N, Cc, h, w, g=g) for h, w in sizes]
+    sum((y * d).sum() for y, d in zip(ys, dys)).backward()
+    P = sum(h * w for h, w in sizes) * N
+    x_d = _multiseg([x.detach() for x in xs])
+    y_d = torch.empty(P, Cc, dtype=torch.bfloat16, device='cuda')
+    stats = torch.empty(5 * N * 32, 2, device='cuda')
+    red = torch.empty(5 * N * 32, 2, device='cuda')
+    ga, be = gamma.detach().cuda(), beta.detach().cuda()
+    d = ops.gn_desc(x_d, y_d, ga, be, stats, red, n=N, hw=sizes)
+    L.check(L.lib.dsl_groupnorm_relu_fwd(C.byref(d), L.stream_ptr()))
+    sync()
+    ref_y = torch.cat([y.detach().permute(0, 2, 3, 1).reshape(-1, Cc) for y in ys])
+    assert torch.allclose(y_d.float().cpu(), ref_y, rtol=1e-2, atol=1e-2)
+    dy_d = _multiseg(dys)
+    dx_d = torch.empty_like(y_d)
+    dgam, dbet = torch.empty(Cc, device='cuda'), torch.empty(Cc, device='cuda')
+    d = ops.gn_desc(x_d, y_d, ga, be, stats, red, n=N, hw=sizes, dy=dy_d, dx=dx_d, dgamma=dgam, dbeta=dbet)
+    L.check(L.lib.dsl_groupnorm_relu_bwd(C.byref(d), L.stream_ptr()))
+    sync()
+    ref_dx = torch.cat([x.grad.permute(0, 2, 3, 1).reshape(-1, Cc) for x in xs])
+    got = dx_d.float().cpu()
+    assert torch.allclose(got, ref_dx, rtol=2e-2, atol=2e-2 * float(ref_dx.abs().max())), (got - ref_dx).abs().max()
+    assert torch.allclose(dgam.cpu(), gamma.grad, rtol=1e-2, atol=1e-2 * float(gamma.grad.abs().max()))
+    assert torch.allclose(dbet.cpu(), beta.grad, rtol=1e-2, atol=1e-2 * float(beta.grad.abs().max()))
+
+
+def test_maxpool_sum2x2_colsum(K):
+    L, _ = K
+    g = torch.Generator().manual_seed(5)
+    x = rnd(2, 64, 37, 45, g=g)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    y = torch.empty(2, ref.shape[2], ref.shape[3], 64, dtype=torch.bfloat16, device='cuda')
+    L.check(L.lib.dsl_maxpool3x3s2(L.ptr(nhwc(x)), L.ptr(y), 2, 37, 45, 64, L.stream_ptr()))
+    gch = rnd(2, 64, 10, 14, g=g)
+    top = torch.zeros(2, 64, 5, 7, requires_grad=True)
+    (F.interpolate(top, size=(10, 14), mode='nearest') * gch).sum().backward()
+    out = torch.empty(2, 5, 7, 64, dtype=torch.bfloat16, device='cuda')
+    L.check(L.lib.dsl_sum2x2(L.ptr(nhwc(gch)), L.ptr(out), 2, 5, 7, 10, 14, 64, L.stream_ptr()))
+    m = rnd(1000, 80, g=g)
+    mp = torch.cat([m, torch.ones(1000, 48)], 1).bfloat16().cuda()
+    cs = torch.empty(80, device='cuda')
+    L.check(L.lib.dsl_colsum(L.ptr(mp), L.ptr(cs), 1000, 80, 128, L.stream_ptr()))
+    sync()
+    assert torch.equal(from_nhwc(y), ref)
+    assert torch.allclose(from_nhwc(out), top.grad, rtol=1e-2, atol=1e-2)
+    assert torch.allclose(cs.cpu(), m.sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_sgd_ema_cast_packdgrad(K):
+    L, _ = K
+    from oracle import fcos_oracle as O
+    g = torch.Generator().manual_seed(6)
+    n = 4096
+    p0, m0 = torch.randn(n, generator=g), torch.zeros(n)
+    grp = (torch.rand(n, generator=g) < 0.1).to(torch.uint8)
+    p, m = p0.clone().cuda(), m0.clone().cuda()
+    p16 = torch.empty(n, dtype=torch.bfloat16, device='cuda')
+    pr, mr = p0.clone(), m0.clone()
+    for step in range(3):
+        gr = torch.randn(n, generator=g) * 30
+        gn = torch.zeros(1, device='cuda')
+        L.check(L.lib.dsl_sumsq(L.ptr(gr.cuda()), n, L.ptr(gn), L.stream_ptr()))
+        L.check(L.lib.dsl_sgd_step(L.ptr(p), L.ptr(gr.cuda()), L.ptr(m), L.ptr(p16), L.ptr(grp.cuda()), n, 0.01, 0.9, 1e-4,
+                                   2.0, 0.0, L.ptr(gn), 35.0, int(step == 0), L.stream_ptr()))
+        coef = min(35.0 / (float(gr.double().norm()) + 1e-6), 1.0)
+        lr = torch.where(grp.bool(), torch.tensor(0.02), torch.tensor(0.01))
+        wd = torch.where(grp.bool(), torch.tensor(0.0), torch.tensor(1e-4))
+        d = gr * coef + wd * pr
+        mr = d if step == 0 else 0.9 * mr + d
+        pr = pr - lr * mr
+    sync()
+    assert torch.allclose(p.cpu(), pr, rtol=1e-5, atol=1e-6)
+    assert torch.equal(p16.cpu(), p.cpu().bfloat16())
+    t, s = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    td = t.clone().cuda()
+    L.check(L.lib.dsl_ema_lerp(L.ptr(td), L.ptr(s.cuda()), n, 0.99, L.stream_ptr()))
+    sync()
+    assert torch.allclose(td.cpu(), O.ema_update({'w': t}, {'w': s}, 0.99)['w'], rtol=1e-6, atol=1e-7)
+    w = torch.randn(80, 3, 3, 256, generator=g)
+    sc = torch.rand(80, generator=g) + 0.5
+    out = torch.full((256, 3, 3, 128), 5.0).bfloat16().cuda()
+    L.check(L.lib.dsl_pack_dgrad(L.ptr(w.cuda()), L.ptr(sc.cuda()), L.ptr(out), 80, 128, 9, 256, L.stream_ptr()))
+    sync()
+    ref = torch.zeros(256, 3, 3, 128)
+    ref[..., :80] = (w * sc[:, None, None, None]).permute(3, 1, 2, 0)
+    assert torch.equal(out.cpu(), ref.bfloat16())
