@@ -113,7 +113,8 @@ def test_conv_stem_small_c(K):
     ref = F.relu(F.conv2d(x, w, None, 2, 3))
     Ho, Wo = ref.shape[2:]
     x8 = torch.empty(N, H, W, 8, dtype=torch.bfloat16, device='cuda')
-    L.check(L.lib.dsl_pack_image(L.ptr(x.cuda()), L.ptr(x8), N, H, W, L.stream_ptr()))
+    x_d = x.cuda()
+    L.check(L.lib.dsl_pack_image(L.ptr(x_d), L.ptr(x8), N, H, W, L.stream_ptr()))
     sync()
     assert torch.equal(x8.float().cpu()[..., :3], x.permute(0, 2, 3, 1)) and float(x8[..., 3:].abs().max()) == 0
     wp = torch.zeros(64, 7 * 64)      # K = 49 taps * 8 channels = 392, padded to 448
@@ -334,8 +335,9 @@ def test_sgd_ema_cast_packdgrad(K):
     for step in range(3):
         gr = torch.randn(n, generator=g) * 30
         gn = torch.zeros(1, device='cuda')
-        L.check(L.lib.dsl_sumsq(L.ptr(gr.cuda()), n, L.ptr(gn), L.stream_ptr()))
-        L.check(L.lib.dsl_sgd_step(L.ptr(p), L.ptr(gr.cuda()), L.ptr(m), L.ptr(p16), L.ptr(grp.cuda()), n, 0.01, 0.9, 1e-4,
+        gr_d, grp_d = gr.cuda(), grp.cuda()      # keep the device tensors alive across the launches
+        L.check(L.lib.dsl_sumsq(L.ptr(gr_d), n, L.ptr(gn), L.stream_ptr()))
+        L.check(L.lib.dsl_sgd_step(L.ptr(p), L.ptr(gr_d), L.ptr(m), L.ptr(p16), L.ptr(grp_d), n, 0.01, 0.9, 1e-4,
                                    2.0, 0.0, L.ptr(gn), 35.0, int(step == 0), L.stream_ptr()))
         coef = min(35.0 / (float(gr.double().norm()) + 1e-6), 1.0)
         lr = torch.where(grp.bool(), torch.tensor(0.02), torch.tensor(0.01))
@@ -347,14 +349,15 @@ def test_sgd_ema_cast_packdgrad(K):
     assert torch.allclose(p.cpu(), pr, rtol=1e-5, atol=1e-6)
     assert torch.equal(p16.cpu(), p.cpu().bfloat16())
     t, s = torch.randn(n, generator=g), torch.randn(n, generator=g)
-    td = t.clone().cuda()
-    L.check(L.lib.dsl_ema_lerp(L.ptr(td), L.ptr(s.cuda()), n, 0.99, L.stream_ptr()))
+    td, sd_ = t.clone().cuda(), s.cuda()
+    L.check(L.lib.dsl_ema_lerp(L.ptr(td), L.ptr(sd_), n, 0.99, L.stream_ptr()))
     sync()
     assert torch.allclose(td.cpu(), O.ema_update({'w': t}, {'w': s}, 0.99)['w'], rtol=1e-6, atol=1e-7)
     w = torch.randn(80, 3, 3, 256, generator=g)
     sc = torch.rand(80, generator=g) + 0.5
     out = torch.full((256, 3, 3, 128), 5.0).bfloat16().cuda()
-    L.check(L.lib.dsl_pack_dgrad(L.ptr(w.cuda()), L.ptr(sc.cuda()), L.ptr(out), 80, 128, 9, 256, L.stream_ptr()))
+    w_d, sc_d = w.cuda(), sc.cuda()
+    L.check(L.lib.dsl_pack_dgrad(L.ptr(w_d), L.ptr(sc_d), L.ptr(out), 80, 128, 9, 256, L.stream_ptr()))
     sync()
     ref = torch.zeros(256, 3, 3, 128)
     ref[..., :80] = (w * sc[:, None, None, None]).permute(3, 1, 2, 0)
