@@ -131,4 +131,8 @@ def stream_ptr():
 
 
 def ptr(t):
-    return C.c_void_p(0 if t is None else t.data_ptr())
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())

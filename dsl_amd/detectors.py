@@ -1,0 +1,317 @@
+"""Registered detector classes with the reference's names and constructor arguments, so that
+configs/fcos_semi/*.py build unmodified:
+
+  FCOS / SingleStageDetector   mmdet/models/detectors/{fcos,single_stage,base}.py
+  ResNet                        mmdet/models/backbones/resnet.py:304-656   (depth 50, caffe, frozen BN)
+  FPN                           mmdet/models/necks/fpn.py:9-202
+  FCOSHead                      mmdet/models/dense_heads/fcos_head.py:14-726
+  FocalLoss / GIoULoss / CrossEntropyLoss   mmdet/models/losses/*.py
+
+Unlike the reference these classes do not compute with torch ops: they validate the configuration
+the HIP path implements, own the parameter store, and drive the prebuilt kernel lists of
+dsl_amd.engine.  There is no CPU / PyTorch fallback: calling the hot path without the HIP library or
+off-GPU raises.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .params import ParamStore
+from .registry import BACKBONES, DETECTORS, HEADS, LOSSES, NECKS, build_backbone, build_head, build_loss, build_neck
+
+
+def _expect(cond, msg):
+    if not cond:
+        raise NotImplementedError('dsl_amd hot path: ' + msg)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch', init_cfg=None,
+                 pretrained=None, **kw):
+        super().__init__()
+        _expect(depth == 50 and num_stages == 4 and tuple(out_indices) == (0, 1, 2, 3), 'ResNet-50, 4 stages, all outputs')
+        _expect(style == 'caffe', "style='caffe' (stride on the first 1x1)")
+        _expect(frozen_stages == 1 and norm_eval and not norm_cfg.get('requires_grad', True),
+                'frozen_stages=1, norm_eval=True, BN requires_grad=False (configs/fcos_semi/r50_caffe_*.py:4-15)')
+        _expect(not kw.get('dcn') and not kw.get('plugins') and not kw.get('with_cp', False), 'no DCN/plugins/checkpointing')
+        self.init_cfg = init_cfg
+
+
+@BACKBONES.register_module()
+class RLA_ResNet(nn.Module):
+    def __init__(self, *a, **kw):
+        super().__init__()
+        raise NotImplementedError(
+            'RLA_ResNet (mmdet/models/backbones/resnet_rla.py) is a SURVEY.md §8(f) "next" row; build the DSL config '
+            "with --cfg-options model.backbone.type=ResNet model.backbone.depth=50 model.backbone.style=caffe "
+            'model.backbone.norm_cfg="dict(type=\'BN\', requires_grad=False)"')
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None, norm_cfg=None, act_cfg=None,
+                 upsample_cfg=dict(mode='nearest'), init_cfg=None, **kw):
+        super().__init__()
+        _expect(list(in_channels) == [256, 512, 1024, 2048] and out_channels == 256 and num_outs == 5 and start_level == 1,
+                'FPN 256ch, start_level=1, 5 outputs')
+        _expect(add_extra_convs == 'on_output' and relu_before_extra_convs and norm_cfg is None and act_cfg is None,
+                "add_extra_convs='on_output', relu_before_extra_convs=True, no norm/act")
+        _expect(upsample_cfg.get('mode', 'nearest') == 'nearest' and 'scale_factor' not in upsample_cfg, 'nearest upsample')
+
+
+class _LossCfg(nn.Module):
+    def __init__(self, loss_weight=1.0, **kw):
+        super().__init__()
+        _expect(loss_weight == 1.0 and kw.get('reduction', 'mean') == 'mean', 'loss_weight=1.0, reduction=mean')
+        self.loss_weight = loss_weight
+
+
+@LOSSES.register_module()
+class FocalLoss(_LossCfg):
+    def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, **kw):
+        super().__init__(**kw)
+        _expect(use_sigmoid and gamma == 2.0 and alpha == 0.25, 'sigmoid focal loss, gamma 2, alpha 0.25')
+
+
+@LOSSES.register_module()
+class GIoULoss(_LossCfg):
+    def __init__(self, eps=1e-6, **kw):
+        super().__init__(**kw)
+        _expect(eps == 1e-6, 'GIoU eps 1e-6')
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(_LossCfg):
+    def __init__(self, use_sigmoid=False, use_mask=False, class_weight=None, **kw):
+        super().__init__(**kw)
+        _expect(use_sigmoid and not use_mask and class_weight is None, 'sigmoid BCE centerness loss')
+
+
+@HEADS.register_module()
+class FCOSHead(nn.Module):
+    def __init__(self, num_classes, in_channels, regress_ranges=((-1, 64), (64, 128), (128, 256), (256, 512), (512, 1e8)),
+                 center_sampling=False, center_sample_radius=1.5, norm_on_bbox=False, centerness_on_reg=False,
+                 loss_weight=1.0, soft_weight=0.0, soft_warm_up=0, feat_channels=256, stacked_convs=4,
+                 strides=(4, 8, 16, 32, 64), dcn_on_last_conv=False, conv_bias='auto',
+                 loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_bbox=dict(type='IoULoss', loss_weight=1.0),
+                 loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 norm_cfg=dict(type='GN', num_groups=32, requires_grad=True), train_cfg=None, test_cfg=None,
+                 init_cfg=None, **kw):
+        super().__init__()
+        _expect(num_classes == 80 and in_channels == 256 and feat_channels == 256 and stacked_convs == 4, '80 classes, 256ch, 4 convs')
+        _expect(list(strides) == [8, 16, 32, 64, 128], 'strides 8..128')
+        _expect(center_sampling and norm_on_bbox and centerness_on_reg and not dcn_on_last_conv and conv_bias is True,
+                'the fcos_semi "tricks" head: center_sampling, norm_on_bbox, centerness_on_reg, conv_bias=True')
+        _expect(norm_cfg.get('type') == 'GN' and norm_cfg.get('num_groups') == 32, 'GN-32 towers')
+        self.num_classes, self.strides = num_classes, tuple(strides)
+        self.regress_ranges = tuple(tuple(r) for r in regress_ranges)
+        self.center_sample_radius = center_sample_radius
+        self.loss_weight, self.soft_weight, self.soft_warm_up = loss_weight, soft_weight, soft_warm_up
+        self.cur_iter = 0                               # fcos_head.py:103
+        self.loss_cls, self.loss_bbox = build_loss(loss_cls), build_loss(loss_bbox)
+        self.loss_centerness = build_loss(loss_centerness)
+        _expect(isinstance(self.loss_cls, FocalLoss) and isinstance(self.loss_bbox, GIoULoss)
+                and isinstance(self.loss_centerness, CrossEntropyLoss), 'FocalLoss + GIoULoss + CrossEntropyLoss')
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    def effective_soft_weight(self, batch_size):
+        """fcos_head.py:312-327: the sisoft term exists for odd batches with soft_weight != 0; while
+        cur_iter <= soft_warm_up it is scaled by 1/1000 and the counter advances."""
+        if batch_size % 2 == 0 or self.soft_weight == 0.0:
+            return 0.0
+        w = self.soft_weight * 1.0
+        if self.soft_warm_up >= self.cur_iter:
+            self.cur_iter += 1
+            w = self.soft_weight / 1000.0
+        return w
+
+
+class _TrainStepFn(torch.autograd.Function):
+    """Bridges `loss.backward()` (mmcv OptimizerHook) to the hand-written backward kernel lists."""
+
+    @staticmethod
+    def forward(ctx, anchor, det, plan):
+        ctx.det, ctx.plan = det, plan
+        return plan.lossplan.losses.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.det._run_backward(ctx.plan)
+        return None, None, None
+
+
+@DETECTORS.register_module()
+class FCOS(nn.Module):
+    """SingleStageDetector (detectors/single_stage.py:10-165) specialised by detectors/fcos.py:5-18."""
+
+    def __init__(self, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None,
+                 init_cfg=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.store = ParamStore(self.bbox_head.num_classes, 'cpu')
+        self.store.init_reference_style(0)
+        self._params = None
+        self._engine = None
+        self._anchor = None
+        self.dist_group = None        # set by the DDP wrapper
+        self.world_size = 1
+        self.CLASSES = None
+        self.lazy_log = False         # True: log_vars stay device tensors (no per-iteration host sync)
+        self._pending = []
+
+    # ---- nn.Module surface redirected to the flat store ------------------------------------------
+    def init_weights(self):
+        self.store.init_reference_style(0)
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, device=self.store.device))
+        if probe.device != self.store.device:
+            self.store.to(probe.device)
+            self._params = None
+            self._engine = None
+            self._anchor = None
+        return self
+
+    def state_dict(self, destination=None, prefix='', keep_vars=False):
+        out = OrderedDict() if destination is None else destination
+        for k, v in self.store.named_views().items():
+            out[prefix + k] = v
+        return out
+
+    def load_state_dict(self, state_dict, strict=True):
+        return self.store.load_named(state_dict, strict)
+
+    def named_parameters(self, prefix='', recurse=True, remove_duplicate=True):
+        if self._params is None:
+            tv = self.store.named_views()
+            gv = self.store.named_views(self.store.grad)
+            self._params = OrderedDict()
+            for k, v in tv.items():
+                if not v.is_floating_point() or k.rsplit('.', 1)[-1] in ('running_mean', 'running_var'):
+                    continue
+                p = nn.Parameter(v, requires_grad=k in gv)
+                if k in gv:
+                    p.grad = gv[k]
+                self._params[k] = p
+        for k, p in self._params.items():
+            yield prefix + ('.' if prefix else '') + k, p
+
+    def parameters(self, recurse=True):
+        for _, p in self.named_parameters():
+            yield p
+
+    def _rebind_grads(self):
+        if self._params is not None:
+            gv = self.store.named_views(self.store.grad)
+            for k, p in self._params.items():
+                if k in gv and p.grad is None:
+                    p.grad = gv[k]
+
+    # ---- hot path ----------------------------------------------------------------------------------
+    def _get_engine(self):
+        if self.store.device.type != 'cuda':
+            raise RuntimeError('dsl_amd.FCOS runs only on an MI355X: move the model to cuda (no CPU fallback)')
+        if self._engine is None:
+            from .engine import Engine
+            self._engine = Engine()
+            self._anchor = torch.zeros(1, device=self.store.device, requires_grad=True)
+        return self._engine
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
+        """single_stage.py:56-84 + base_dense_head.py:22-59.  Returns dict of scalar loss tensors."""
+        eng = self._get_engine()
+        N, _, H, W = img.shape
+        assert len(img_metas) == N == len(gt_bboxes) == len(gt_labels)
+        plan = eng.plan(self.store, N, H, W, training=True)
+        head = self.bbox_head
+        if head.loss_weight != 1.0 and gt_bboxes_ignore is None:
+            raise TypeError('loss_weight != 1.0 needs gt_bboxes_ignore (fcos_head.py:223 iterates ig_labels)')
+        lp = plan.lossplan
+        lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
+        sw = head.effective_soft_weight(N)
+        ws = self.world_size
+        lp.configure(loss_weight=head.loss_weight, soft_weight=sw, grad_scale=1.0 / ws, inv_world=1.0 / ws)
+        plan.img.copy_(img, non_blocking=True)
+        plan.assign_ops.run()
+        work = None
+        if ws > 1:      # reduce_mean of (num_pos, sum centerness targets): one 2-float all-reduce (fcos_head.py:264-274)
+            work = dist.all_reduce(lp.stats[:2], group=self.dist_group, async_op=True)
+        plan.fwd.run()
+        if work is not None:
+            work.wait()
+        plan.loss_ops.run()
+        out = _TrainStepFn.apply(self._anchor, self, plan)
+        losses = OrderedDict(loss_cls=out[0], loss_bbox=out[1], loss_centerness=out[2])
+        if sw != 0.0:
+            losses['loss_sisoft'] = out[3]
+        return losses
+
+    def _run_backward(self, plan):
+        """Hand-written backward; gradient buckets are all-reduced as each segment's kernels are queued
+        (bulk RCCL traffic overlaps the remaining backward, as torch DDP does at mmdet/apis/train.py:92-96)."""
+        self._pending = []
+        for ol, (lo, hi) in plan.bwd_segments:
+            ol.run()
+            if self.world_size > 1:
+                self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
+        self._rebind_grads()
+
+    def wait_grads(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        """detectors/base.py:155-173."""
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        if isinstance(imgs, (list, tuple)):
+            assert len(imgs) == 1, 'test-time augmentation is out of scope'
+            imgs, img_metas = imgs[0], img_metas[0]
+        return self.simple_test(imgs, img_metas, **kwargs)
+
+    def simple_test(self, img, img_metas, rescale=False):
+        from .sweep import simple_test
+        return simple_test(self, img, img_metas, rescale)
+
+    def _parse_losses(self, losses):
+        """detectors/base.py:175-208: total = sum of keys containing 'loss'; log vars averaged over ranks."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            log_vars[name] = value.mean() if isinstance(value, torch.Tensor) else sum(v.mean() for v in value)
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        keys = list(log_vars.keys())
+        vec = torch.stack([log_vars[k].detach() for k in keys])
+        if self.world_size > 1:      # ONE all-reduce for all log vars instead of one per key
+            dist.all_reduce(vec, group=self.dist_group)
+            vec = vec / self.world_size
+        if self.lazy_log:
+            log_vars = OrderedDict((k, vec[i]) for i, k in enumerate(keys))
+        else:
+            host = vec.tolist()
+            log_vars = OrderedDict((k, host[i]) for i, k in enumerate(keys))
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        """detectors/base.py:210-243."""
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+    def val_step(self, data, optimizer=None):
+        return self.train_step(data, optimizer)

@@ -1,0 +1,395 @@
+"""Execution plans for the FCOS R50-FPN step: for one input shape (N, H, W) the engine allocates every
+activation / gradient buffer once and pre-builds flat lists of kernel descriptors (dsl_op[]) that
+libdsl_hip.so replays with ONE C call per segment (dsl_run_ops) — no per-launch Python.
+
+What the lists compute is the reference's
+  SingleStageDetector.forward_train (mmdet/models/detectors/single_stage.py:56-84)
+    = ResNet.forward (backbones/resnet.py:630-645) -> FPN.forward (necks/fpn.py:150-202)
+      -> FCOSHead.forward (dense_heads/fcos_head.py:118-168) -> FCOSHead.loss (:170-338)
+and its autograd backward, written out by hand (no autograd graph exists here).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .head_loss import FcosLossPlan
+from .params import STAGE_BLOCKS, STAGE_PLANES
+
+BF = torch.bfloat16
+
+
+class OpList:
+    def __init__(self):
+        self.items, self.keep, self.arr = [], [], None
+
+    def _add(self, kind, desc=None, i=(), p=(), l=()):
+        o = L.Op()
+        o.kind = kind
+        for k, v in enumerate(i):
+            o.i[k] = int(v)
+        for k, v in enumerate(p):
+            o.p[k] = v if isinstance(v, int) else (0 if v is None else v.data_ptr())
+        for k, v in enumerate(l):
+            o.l[k] = int(v)
+        if desc is not None:
+            o.desc = C.addressof(desc)
+            self.keep.append(desc)
+        self.items.append(o)
+        self.arr = None
+
+    def conv(self, d):
+        self._add(L.OP_CONV, d)
+
+    def wgrad(self, d):
+        self._add(L.OP_WGRAD, d)
+
+    def gn_fwd(self, d):
+        self._add(L.OP_GN_FWD, d)
+
+    def gn_bwd(self, d):
+        self._add(L.OP_GN_BWD, d)
+
+    def assign(self, d):
+        self._add(L.OP_ASSIGN, d)
+
+    def loss(self, d):
+        self._add(L.OP_LOSS, d)
+
+    def maxpool(self, x, y, n, h, w, c):
+        self._add(L.OP_MAXPOOL, i=(n, h, w, c), p=(x, y))
+
+    def sum2x2(self, g, out, n, h, w, ch, cw, c):
+        self._add(L.OP_SUM2X2, i=(n, h, w, ch, cw, c), p=(g, out))
+
+    def pack_image(self, img, out, n, h, w):
+        self._add(L.OP_PACK_IMAGE, i=(n, h, w), p=(img, out))
+
+    def run(self):
+        if not self.items:
+            return
+        if self.arr is None:
+            self.arr = (L.Op * len(self.items))(*self.items)
+        L.check(L.lib.dsl_run_ops(self.arr, len(self.items), L.stream_ptr()), 'dsl_run_ops')
+
+
+def conv_out(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+class Plan:
+    """All buffers + op lists for one (N, H, W) and one ParamStore."""
+
+    def __init__(self, store, N, H, W, training=True, max_gt=1024):
+        assert store.device.type == 'cuda'
+        if store.dirty:
+            store.refresh()
+        self.store, self.N, self.H, self.W, self.training = store, N, H, W, training
+        dev = store.device
+        self.dev = dev
+        self.bufs = {}
+        self.fwd = OpList()
+        self.loss_ops = OpList()
+        self.assign_ops = OpList()
+        self.bwd_segments = []          # [(OpList, (grad_lo, grad_hi))] in execution order
+        self.img = torch.zeros(N, 3, H, W, dtype=torch.float32, device=dev)
+        self._build_forward()
+        if training:
+            self.lossplan = FcosLossPlan(N, self.level_sizes, dev, max_gt=max_gt)
+            self.lossplan.bind_outputs(self.bufs['cls_logits'], self.bufs['regctr'], store.t32_ptr('head.scales'))
+            # scale gradients go straight into the flat gradient buffer
+            self.lossplan.desc.g_scales = store.t32_ptr('head.scales', store.grad)
+            self.assign_ops.assign(self.lossplan.desc)
+            self.loss_ops.loss(self.lossplan.desc)
+            self._build_backward()
+
+    # ---------------------------------------------------------------------------------------------
+    def buf(self, name, *shape, dtype=BF, zero=False):
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
+        self.bufs[name] = t
+        return t
+
+    def _conv(self, spec, src, dst, n, in_hw, out_hw, *, relu=False, addend=None, add_hw=None, flags=0, dst_ld=None,
+              small_c=False):
+        st = self.store
+        scale = bias = None
+        if spec.bn:
+            scale, bias = st.bn_ptrs(spec.bn)
+        elif spec.bias:
+            bias = st.t32_ptr(spec.name + '.bias')
+        f = flags | (L.CONV_RELU_OUT if relu else 0) | (L.CONV_SMALL_C if small_c else 0)
+        if add_hw is not None:
+            f |= L.CONV_ADD_UPSAMPLE
+        return ops.conv_desc(src, st.w16_ptr(spec), dst, n=n, grid=out_hw, src_hw=in_hw, dst_hw=out_hw,
+                             cs=8 if small_c else spec.cin, cd=spec.cout, cd_pad=spec.cout_pad,
+                             ldd=dst_ld or spec.cout, kh=spec.k, kw=spec.k, stride=spec.stride, pad=spec.pad,
+                             flags=f, scale=scale, bias=bias, addend=addend, lda=spec.cout, add_hw=add_hw)
+
+    def _build_forward(self):
+        st, N, H, W, f = self.store, self.N, self.H, self.W, self.fwd
+        cv = st.convs
+        x8 = self.buf('x8', N, H, W, 8)
+        f.pack_image(self.img, x8, N, H, W)
+        h1, w1 = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
+        s1 = self.buf('stem', N, h1, w1, 64)
+        f.conv(self._conv(cv['backbone.conv1'], x8, s1, N, [(H, W)], [(h1, w1)], relu=True, small_c=True))
+        h, w = conv_out(h1, 3, 2, 1), conv_out(w1, 3, 2, 1)
+        x = self.buf('pool', N, h, w, 64)
+        f.maxpool(s1, x, N, h1, w1, 64)
+        self.blocks = []        # per block: dict(xin, a1, a2, out, idt, in_hw, out_hw, prefix, stride)
+        self.stage_out = []
+        for li, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
+            for b in range(nb):
+                p = f'backbone.layer{li + 1}.{b}'
+                c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
+                s = c1.stride
+                oh, ow = conv_out(h, 1, s, 0), conv_out(w, 1, s, 0)
+                a1 = self.buf(p + '.a1', N, oh, ow, planes)
+                a2 = self.buf(p + '.a2', N, oh, ow, planes)
+                out = self.buf(p + '.out', N, oh, ow, planes * 4)
+                f.conv(self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True))
+                f.conv(self._conv(c2, a1, a2, N, [(oh, ow)], [(oh, ow)], relu=True))
+                idt = x
+                if b == 0:
+                    idt = self.buf(p + '.idt', N, oh, ow, planes * 4)
+                    f.conv(self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)]))
+                f.conv(self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt))
+                self.blocks.append(dict(prefix=p, xin=x, a1=a1, a2=a2, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
+                                        stage=li, b=b, planes=planes))
+                x, h, w = out, oh, ow
+            self.stage_out.append((x, (h, w)))
+        # ---- FPN (start_level=1) ----
+        (c3, hw3), (c4, hw4), (c5, hw5) = self.stage_out[1], self.stage_out[2], self.stage_out[3]
+        hw6 = (conv_out(hw5[0], 3, 2, 1), conv_out(hw5[1], 3, 2, 1))
+        hw7 = (conv_out(hw6[0], 3, 2, 1), conv_out(hw6[1], 3, 2, 1))
+        self.level_sizes = [hw3, hw4, hw5, hw6, hw7]
+        self.P = sum(a * b for a, b in self.level_sizes)
+        self.M = N * self.P
+        self.seg_off = [0]
+        for a, b in self.level_sizes:
+            self.seg_off.append(self.seg_off[-1] + N * a * b)
+        lat = [self.buf(f'lat{i}', N, hw[0], hw[1], 256) for i, hw in enumerate((hw3, hw4, hw5))]
+        lc = [cv[f'neck.lateral_convs.{i}.conv'] for i in range(3)]
+        f.conv(self._conv(lc[2], c5, lat[2], N, [hw5], [hw5]))
+        f.conv(self._conv(lc[1], c4, lat[1], N, [hw4], [hw4], addend=lat[2], add_hw=[hw5]))
+        f.conv(self._conv(lc[0], c3, lat[0], N, [hw3], [hw3], addend=lat[1], add_hw=[hw4]))
+        feats = self.buf('feats', self.M, 256)
+        self.feat_seg = [feats.data_ptr() + self.seg_off[i] * 256 * 2 for i in range(5)]
+        fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
+        for i, hw in enumerate((hw3, hw4, hw5)):
+            f.conv(self._conv(fc[i], lat[i], self.feat_seg[i], N, [hw], [hw]))
+        f.conv(self._conv(fc[3], self.feat_seg[2], self.feat_seg[3], N, [hw5], [hw6]))          # P6 (no relu)
+        p6r = self.buf('p6r', N, hw6[0], hw6[1], 256)
+        f.conv(self._conv(fc[3], self.feat_seg[2], p6r, N, [hw5], [hw6], relu=True))            # relu(P6)
+        f.conv(self._conv(fc[4], p6r, self.feat_seg[4], N, [hw6], [hw7]))                       # P7
+        # ---- head: shared weights, all 5 levels per launch ----
+        ls = self.level_sizes
+        self.tower = {}
+        for tower in ('cls_convs', 'reg_convs'):
+            xin = feats
+            lays = []
+            for i in range(4):
+                spec = cv[f'bbox_head.{tower}.{i}.conv']
+                pre = self.buf(f'{tower}.{i}.pre', self.M, 256)
+                act = self.buf(f'{tower}.{i}.act', self.M, 256)
+                stats = self.buf(f'{tower}.{i}.stats', 5 * N * 32, 2, dtype=torch.float32)
+                f.conv(self._conv(spec, xin, pre, N, ls, ls))
+                base = f'bbox_head.{tower}.{i}.gn'
+                gd = ops.gn_desc(pre, act, st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'), stats,
+                                 self._gn_red(), n=N, hw=ls)
+                f.gn_fwd(gd)
+                lays.append(dict(spec=spec, xin=xin, pre=pre, act=act, stats=stats, gn=base))
+                xin = act
+            self.tower[tower] = lays
+        cls_logits = self.buf('cls_logits', self.M, 80, dtype=torch.float32)
+        regctr = self.buf('regctr', self.M, 8, dtype=torch.float32, zero=True)
+        f.conv(ops.conv_desc(self.tower['cls_convs'][3]['act'], st.t16_ptr('head.cls_w'), cls_logits, n=N, grid=ls,
+                             src_hw=ls, dst_hw=ls, cs=256, cd=80, cd_pad=128, ldd=80, kh=3, kw=3, stride=1, pad=1,
+                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.cls_b')))
+        f.conv(ops.conv_desc(self.tower['reg_convs'][3]['act'], st.t16_ptr('head.regctr_w'), regctr, n=N, grid=ls,
+                             src_hw=ls, dst_hw=ls, cs=256, cd=5, cd_pad=64, ldd=8, kh=3, kw=3, stride=1, pad=1,
+                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.regctr_b')))
+
+    def _gn_red(self):
+        if 'gn_red' not in self.bufs:
+            self.buf('gn_red', 5 * self.N * 32, 2, dtype=torch.float32)
+        return self.bufs['gn_red']
+
+    # ---------------------------------------------------------------------------------------------
+    def _wgrad(self, ol, spec, dy, x, n, out_hw, in_hw, cy=None, cd=None, wregion=None, bregion=None):
+        st = self.store
+        scale = st.bn_ptrs(spec.bn)[0] if (spec is not None and spec.bn) else None
+        name = wregion or (spec.name + '.weight')
+        db = None
+        if bregion is not None:
+            db = st.t32_ptr(bregion, st.grad)
+        elif spec is not None and spec.bias:
+            db = st.t32_ptr(spec.name + '.bias', st.grad)
+        k = 3 if spec is None else spec.k
+        d = ops.wgrad_desc(dy, x, st.t32_ptr(name, st.grad), n=n, grid=out_hw, src_hw=in_hw,
+                           cs=256 if spec is None else spec.cin, cy=cy or spec.cout_pad, cd=cd or spec.cout,
+                           kh=k, kw=k, stride=1 if spec is None else spec.stride, pad=1 if spec is None else spec.pad,
+                           scale=scale, db=db, workspace=self._wg_ws(n, out_hw, in_hw, spec, cy))
+        ol.wgrad(d)
+
+    def _wg_ws(self, n, out_hw, in_hw, spec, cy):
+        need = ops.wgrad_workspace_bytes(n=n, grid=out_hw, src_hw=in_hw, cs=256 if spec is None else spec.cin,
+                                         cy=cy or spec.cout_pad, cd=1, kh=3 if spec is None else spec.k,
+                                         kw=3 if spec is None else spec.k, stride=1 if spec is None else spec.stride,
+                                         pad=1 if spec is None else spec.pad)
+        ws = self.bufs.get('wg_ws')
+        if ws is None or ws.numel() < need:
+            # grow: descriptors built earlier keep pointing at the old (smaller, still alive) buffer
+            ws = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=self.dev)
+            self.bufs.setdefault('wg_ws_old', []).append(self.bufs.get('wg_ws'))
+            self.bufs['wg_ws'] = ws
+        return ws
+
+    def _dgrad(self, name, dy, dst, n, dy_hw, dst_hw, *, cs, cd, k, stride, pad, os=1, addend=None, mask=None,
+               mask_first=False, mask_last=False):
+        st = self.store
+        f = (L.CONV_MASK_FIRST if mask_first else 0) | (L.CONV_MASK_LAST if mask_last else 0)
+        grid = dy_hw if os > 1 else dst_hw
+        return ops.conv_desc(dy, st.wT_ptr(name), dst, n=n, grid=grid, src_hw=dy_hw, dst_hw=dst_hw, cs=cs, cd=cd,
+                             cd_pad=cd, ldd=cd, kh=k, kw=k, stride=stride, pad=pad, mode=1, os=os, flags=f,
+                             addend=addend, lda=cd, mask=mask, ldm=cd)
+
+    def _build_backward(self):
+        st, N, ls = self.store, self.N, self.level_sizes
+        lp = self.lossplan
+        reg = st.train_regions
+        M = self.M
+        gA = self.buf('gA', M, 256)
+        gB = self.buf('gB', M, 256)
+        g_feats = self.buf('g_feats', M, 256)
+        # ================= segment 0: head + FPN =================
+        ol = OpList()
+        for ti, tower in enumerate(('cls_convs', 'reg_convs')):
+            lays = self.tower[tower]
+            if tower == 'cls_convs':
+                self._wgrad(ol, None, lp.g_cls, lays[3]['act'], N, ls, ls, cy=128, cd=80, wregion='head.cls_w',
+                            bregion='head.cls_b')
+                ol.conv(self._dgrad('head.cls', lp.g_cls, gA, N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1))
+            else:
+                self._wgrad(ol, None, lp.g_rc, lays[3]['act'], N, ls, ls, cy=64, cd=5, wregion='head.regctr_w',
+                            bregion='head.regctr_b')
+                ol.conv(self._dgrad('head.regctr', lp.g_rc, gA, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1))
+            for i in (3, 2, 1, 0):
+                lay = lays[i]
+                base = lay['gn']
+                gd = ops.gn_desc(lay['pre'], lay['act'], st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'),
+                                 lay['stats'], self._gn_red(), n=N, hw=ls, dy=gA, dx=gB,
+                                 dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad))
+                ol.gn_bwd(gd)
+                self._wgrad(ol, lay['spec'], gB, lay['xin'], N, ls, ls)
+                if i > 0:
+                    ol.conv(self._dgrad(lay['spec'].name, gB, gA, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
+                else:
+                    ol.conv(self._dgrad(lay['spec'].name, gB, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1,
+                                        addend=g_feats if ti == 1 else None))
+        # ---- FPN backward ----
+        cv = st.convs
+        fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
+        lc = [cv[f'neck.lateral_convs.{i}.conv'] for i in range(3)]
+        hw3, hw4, hw5, hw6, hw7 = ls
+        gseg = [g_feats.data_ptr() + self.seg_off[i] * 256 * 2 for i in range(5)]
+        lat = [self.bufs[f'lat{i}'] for i in range(3)]
+        p6r = self.bufs['p6r']
+        g_p6 = self.buf('g_p6', N, hw6[0], hw6[1], 256)
+        g_p5 = self.buf('g_p5', N, hw5[0], hw5[1], 256)
+        g_lat = [self.buf(f'g_lat{i}', N, hw[0], hw[1], 256) for i, hw in enumerate((hw3, hw4, hw5))]
+        s0 = self.buf('s0', N, hw4[0], hw4[1], 256)
+        s1 = self.buf('s1', N, hw5[0], hw5[1], 256)
+        # P7 = fpn4(relu(P6))
+        self._wgrad(ol, fc[4], gseg[4], p6r, N, [hw7], [hw6])
+        ol.conv(self._dgrad(fc[4].name, gseg[4], g_p6, N, [hw7], [hw6], cs=256, cd=256, k=3, stride=2, pad=1,
+                            addend=gseg[3], mask=p6r, mask_first=True))
+        # P6 = fpn3(P5)
+        self._wgrad(ol, fc[3], g_p6, self.feat_seg[2], N, [hw6], [hw5])
+        ol.conv(self._dgrad(fc[3].name, g_p6, g_p5, N, [hw6], [hw5], cs=256, cd=256, k=3, stride=2, pad=1,
+                            addend=gseg[2]))
+        # P3..P5 = fpn_i(lat_i)
+        self._wgrad(ol, fc[2], g_p5, lat[2], N, [hw5], [hw5])
+        self._wgrad(ol, fc[1], gseg[1], lat[1], N, [hw4], [hw4])
+        self._wgrad(ol, fc[0], gseg[0], lat[0], N, [hw3], [hw3])
+        ol.conv(self._dgrad(fc[0].name, gseg[0], g_lat[0], N, [hw3], [hw3], cs=256, cd=256, k=3, stride=1, pad=1))
+        ol.sum2x2(g_lat[0], s0, N, hw4[0], hw4[1], hw3[0], hw3[1], 256)
+        ol.conv(self._dgrad(fc[1].name, gseg[1], g_lat[1], N, [hw4], [hw4], cs=256, cd=256, k=3, stride=1, pad=1,
+                            addend=s0))
+        ol.sum2x2(g_lat[1], s1, N, hw5[0], hw5[1], hw4[0], hw4[1], 256)
+        ol.conv(self._dgrad(fc[2].name, g_p5, g_lat[2], N, [hw5], [hw5], cs=256, cd=256, k=3, stride=1, pad=1,
+                            addend=s1))
+        # laterals -> gradients w.r.t. C3, C4, C5 (masked by the ReLU that produced them)
+        self.g_stage = {}
+        for i, (li, hw) in enumerate(((1, hw3), (2, hw4), (3, hw5))):
+            cfeat = self.stage_out[li][0]
+            cch = STAGE_PLANES[li] * 4
+            self._wgrad(ol, lc[i], g_lat[i], cfeat, N, [hw], [hw])
+            g0 = self.buf(f'g_stage{li}_0', N, hw[0], hw[1], cch)
+            g1 = self.buf(f'g_stage{li}_1', N, hw[0], hw[1], cch)
+            self.g_stage[li] = [g0, g1]
+            ol.conv(self._dgrad(lc[i].name, g_lat[i], g0, N, [hw], [hw], cs=256, cd=cch, k=1, stride=1, pad=0,
+                                mask=cfeat, mask_first=True))
+        self.bwd_segments.append((ol, (reg['neck.lateral_convs.0.conv.weight'][0], st.n_train)))
+        # ================= backbone: layer4, layer3, layer2 =================
+        blocks_by_stage = {li: [b for b in self.blocks if b['stage'] == li] for li in (1, 2, 3)}
+        for li in (3, 2, 1):
+            ol = OpList()
+            blks = blocks_by_stage[li]
+            hw = blks[0]['out_hw']
+            planes = blks[0]['planes']
+            gA1 = self.buf(f'g_l{li}_a1', N, hw[0], hw[1], planes)
+            gA2 = self.buf(f'g_l{li}_a2', N, hw[0], hw[1], planes)
+            gout = self.g_stage[li]
+            cur = 0
+            for blk in reversed(blks):
+                p = blk['prefix']
+                c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
+                g_pre = gout[cur]
+                self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw])
+                ol.conv(self._dgrad(c3.name, g_pre, gA2, N, [hw], [hw], cs=c3.cout, cd=c3.cin, k=1, stride=1, pad=0,
+                                    mask=blk['a2'], mask_last=True))
+                self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw])
+                ol.conv(self._dgrad(c2.name, gA2, gA1, N, [hw], [hw], cs=c2.cout, cd=c2.cin, k=3, stride=1, pad=1,
+                                    mask=blk['a1'], mask_last=True))
+                self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']])
+                if blk['b'] > 0:
+                    ol.conv(self._dgrad(c1.name, gA1, gout[cur ^ 1], N, [hw], [hw], cs=c1.cout, cd=c1.cin, k=1, stride=1,
+                                        pad=0, addend=g_pre, mask=blk['xin'], mask_last=True))
+                    cur ^= 1
+                else:
+                    ds = cv[p + '.downsample.0']
+                    self._wgrad(ol, ds, g_pre, blk['xin'], N, [hw], [blk['in_hw']])
+                    if li > 1:      # data gradient into the previous stage's output (stride-2 scatter)
+                        tgt = self.g_stage[li - 1][0]
+                        ihw = blk['in_hw']
+                        for spec, dy in ((ds, g_pre), (c1, gA1)):
+                            ol.conv(self._dgrad(spec.name, dy, tgt, N, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
+                                                stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
+            lo = reg[f'backbone.layer{li + 1}.0.conv1.weight'][0]
+            hi = reg[f'backbone.layer{li + 2}.0.conv1.weight'][0] if li < 3 else reg['neck.lateral_convs.0.conv.weight'][0]
+            self.bwd_segments.append((ol, (lo, hi)))
+
+    # ---------------------------------------------------------------------------------------------
+    def forward(self, img=None):
+        if img is not None:
+            self.img.copy_(img, non_blocking=True)
+        self.fwd.run()
+
+
+class Engine:
+    """Caches plans per (store, N, H, W, training) and runs the student step / the teacher forward."""
+
+    def __init__(self):
+        self.plans = {}
+
+    def plan(self, store, N, H, W, training=True):
+        key = (id(store), N, H, W, training)
+        p = self.plans.get(key)
+        if p is None:
+            p = Plan(store, N, H, W, training)
+            self.plans[key] = p
+        if store.dirty:
+            store.refresh()
+        return p

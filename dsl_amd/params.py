@@ -1,0 +1,339 @@
+"""Parameter storage for the FCOS R50-caffe + FPN + FCOSHead detector, laid out for the HIP kernels.
+
+The reference keeps 377 separate OIHW fp32 tensors.  Here every trainable
+parameter lives in ONE flat fp32 buffer (`train`), with conv weights stored KRSC =
+[Cout][kh][kw][Cin] so that
+  * the weight-gradient kernel writes straight into the matching flat `grad` buffer,
+  * SGD / EMA / gradient all-reduce are single passes over flat memory,
+  * the bf16 forward pack is an element-wise cast of the same buffer (`train16`).
+`state_dict()` keys, shapes and dtypes are exactly the reference's: each entry is a (permuted) view
+into the flat buffers, so checkpoints and the EMA hook interoperate.
+
+Frozen tensors (stem, layer1, every BatchNorm) live in a second flat buffer (`frozen`).
+"""
+import math
+
+import torch
+
+from . import _lib as L
+
+STAGE_BLOCKS = (3, 4, 6, 3)
+STAGE_PLANES = (64, 128, 256, 512)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class ConvSpec:
+    def __init__(self, name, cin, cout, k, stride, pad, bn=None, bias=False, trainable=True):
+        self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
+        self.bn, self.bias, self.trainable = bn, bias, trainable
+        self.cout_pad = _round_up(cout, 64)
+
+
+def backbone_specs():
+    """ResNet-50, caffe style, frozen_stages=1, BN frozen (mmdet/models/backbones/resnet.py:304-656)."""
+    specs = [ConvSpec('backbone.conv1', 3, 64, 7, 2, 3, bn='backbone.bn1', trainable=False)]
+    inpl = 64
+    for li, (planes, blocks) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
+        tr = li >= 1
+        for b in range(blocks):
+            p = f'backbone.layer{li + 1}.{b}'
+            s = 2 if (b == 0 and li > 0) else 1      # caffe: stride on the first 1x1 (resnet.py:153-158)
+            specs.append(ConvSpec(p + '.conv1', inpl, planes, 1, s, 0, bn=p + '.bn1', trainable=tr))
+            specs.append(ConvSpec(p + '.conv2', planes, planes, 3, 1, 1, bn=p + '.bn2', trainable=tr))
+            specs.append(ConvSpec(p + '.conv3', planes, planes * 4, 1, 1, 0, bn=p + '.bn3', trainable=tr))
+            if b == 0:
+                specs.append(ConvSpec(p + '.downsample.0', inpl, planes * 4, 1, s, 0, bn=p + '.downsample.1',
+                                      trainable=tr))
+            inpl = planes * 4
+    return specs
+
+
+def neck_specs():
+    specs = [ConvSpec(f'neck.lateral_convs.{i}.conv', c, 256, 1, 1, 0, bias=True)
+             for i, c in enumerate((512, 1024, 2048))]
+    specs += [ConvSpec(f'neck.fpn_convs.{i}.conv', 256, 256, 3, 1 if i < 3 else 2, 1, bias=True) for i in range(5)]
+    return specs
+
+
+def head_specs():
+    specs = []
+    for tower in ('cls_convs', 'reg_convs'):
+        specs += [ConvSpec(f'bbox_head.{tower}.{i}.conv', 256, 256, 3, 1, 1, bias=True) for i in range(4)]
+    return specs
+
+
+class ParamStore:
+    """Flat buffers + named views.  One instance for the student, one for the EMA teacher."""
+
+    def __init__(self, num_classes=80, device='cpu'):
+        assert num_classes == 80
+        self.num_classes = num_classes
+        self.convs = {s.name: s for s in backbone_specs() + neck_specs() + head_specs()}
+        self.train_regions = {}     # name -> (offset, numel, shape)   (shape = storage shape)
+        self.frozen_regions = {}
+        toff = foff = 0
+
+        def add(regions, off, name, shape):
+            n = _round_up(int(math.prod(shape)) if len(shape) else 1, 8)
+            regions[name] = (off, n, tuple(shape))
+            return off + n
+
+        for s in self.convs.values():
+            shape = (s.cout, s.k, s.k, s.cin)
+            if s.trainable:
+                toff = add(self.train_regions, toff, s.name + '.weight', shape)
+                if s.bias:
+                    toff = add(self.train_regions, toff, s.name + '.bias', (s.cout,))
+            else:
+                foff = add(self.frozen_regions, foff, s.name + '.weight', shape)
+            if s.bn:
+                for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
+                    foff = add(self.frozen_regions, foff, f'{s.bn}.{leaf}', (s.cout,))
+        for tower in ('cls_convs', 'reg_convs'):
+            for i in range(4):
+                toff = add(self.train_regions, toff, f'bbox_head.{tower}.{i}.gn.weight', (256,))
+                toff = add(self.train_regions, toff, f'bbox_head.{tower}.{i}.gn.bias', (256,))
+        # predictors: rows padded to the kernel tile; conv_reg (4) + conv_centerness (1) share one region
+        toff = add(self.train_regions, toff, 'head.cls_w', (128, 3, 3, 256))
+        toff = add(self.train_regions, toff, 'head.cls_b', (128,))
+        toff = add(self.train_regions, toff, 'head.regctr_w', (64, 3, 3, 256))
+        toff = add(self.train_regions, toff, 'head.regctr_b', (64,))
+        toff = add(self.train_regions, toff, 'head.scales', (8,))
+        self.n_train, self.n_frozen = toff, foff
+        self.device = torch.device(device)
+        self.train = torch.zeros(toff, dtype=torch.float32, device=device)
+        self.frozen = torch.zeros(foff, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(toff, dtype=torch.float32, device=device)
+        self.nbt = {s.bn: torch.zeros((), dtype=torch.long, device=device) for s in self.convs.values() if s.bn}
+        # bias group mask for the optimizer's paramwise rules (bias_lr_mult / bias_decay_mult apply to
+        # conv biases, not to norm layers: mmcv DefaultOptimizerConstructor, SURVEY.md §8a note)
+        grp = torch.zeros(toff, dtype=torch.uint8)
+        for name, (off, n, shape) in self.train_regions.items():
+            if (name.endswith('.conv.bias') or name in ('head.cls_b', 'head.regctr_b')):
+                grp[off:off + n] = 1
+        self.group = grp.to(device)
+        # derived device-side packs (built by refresh())
+        self.train16 = None
+        self.frozen16 = None
+        self.wT16 = None
+        self.bn_scale = None
+        self.bn_bias = None
+        self.stem16 = None
+        self._views = None
+        self.dirty = True
+
+    # -- flat <-> named ---------------------------------------------------------------------------
+    def tview(self, name, buf=None):
+        off, n, shape = self.train_regions[name]
+        buf = self.train if buf is None else buf
+        return buf[off:off + int(math.prod(shape))].view(shape)
+
+    def fview(self, name):
+        off, n, shape = self.frozen_regions[name]
+        return self.frozen[off:off + int(math.prod(shape))].view(shape)
+
+    def toff(self, name):
+        return self.train_regions[name][0]
+
+    def named_views(self, buf=None):
+        """OrderedDict key -> tensor view with the reference's names/shapes (OIHW for conv weights).
+        `buf` selects which flat buffer the trainable views come from (train / grad)."""
+        out = {}
+        tb = self.train if buf is None else buf
+
+        def conv_w(s):
+            v = self.tview(s.name + '.weight', tb) if s.trainable else (self.fview(s.name + '.weight') if buf is None else None)
+            return None if v is None else v.permute(0, 3, 1, 2)
+
+        def bn(name):
+            if buf is not None:
+                return
+            for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
+                out[f'{name}.{leaf}'] = self.fview(f'{name}.{leaf}')
+            out[f'{name}.num_batches_tracked'] = self.nbt[name]
+
+        for s in self.convs.values():
+            w = conv_w(s)
+            if w is not None:
+                out[s.name + '.weight'] = w
+            if s.bias:
+                out[s.name + '.bias'] = self.tview(s.name + '.bias', tb)
+            if s.bn:
+                bn(s.bn)
+            if s.name.startswith('bbox_head.') and s.name.endswith('.conv'):
+                base = s.name[:-5]
+                out[base + '.gn.weight'] = self.tview(base + '.gn.weight', tb)
+                out[base + '.gn.bias'] = self.tview(base + '.gn.bias', tb)
+        cw, cb = self.tview('head.cls_w', tb), self.tview('head.cls_b', tb)
+        rw, rb = self.tview('head.regctr_w', tb), self.tview('head.regctr_b', tb)
+        out['bbox_head.conv_cls.weight'] = cw[:80].permute(0, 3, 1, 2)
+        out['bbox_head.conv_cls.bias'] = cb[:80]
+        out['bbox_head.conv_reg.weight'] = rw[:4].permute(0, 3, 1, 2)
+        out['bbox_head.conv_reg.bias'] = rb[:4]
+        out['bbox_head.conv_centerness.weight'] = rw[4:5].permute(0, 3, 1, 2)
+        out['bbox_head.conv_centerness.bias'] = rb[4:5]
+        sc = self.tview('head.scales', tb)
+        for i in range(5):
+            out[f'bbox_head.scales.{i}.scale'] = sc[i]
+        return out
+
+    def load_named(self, sd, strict=True):
+        views = self.named_views()
+        missing = [k for k in views if k not in sd]
+        unexpected = [k for k in sd if k not in views]
+        if strict and (missing or unexpected):
+            raise KeyError(f'state_dict mismatch: missing {missing[:5]}, unexpected {unexpected[:5]}')
+        with torch.no_grad():
+            for k, v in views.items():
+                if k in sd:
+                    v.copy_(sd[k].to(v.device))
+        self.dirty = True
+        return missing, unexpected
+
+    def to(self, device):
+        device = torch.device(device)
+        for a in ('train', 'frozen', 'grad', 'group'):
+            setattr(self, a, getattr(self, a).to(device))
+        self.nbt = {k: v.to(device) for k, v in self.nbt.items()}
+        self.device = device
+        self.dirty = True
+        return self
+
+    # -- device-side derived packs ------------------------------------------------------------------
+    def wT_layout(self):
+        """Offsets (bf16 elements) of the dgrad packs [Cin][kh][kw][CoutPad] of every conv that needs a
+        data gradient."""
+        if getattr(self, '_wT', None) is None:
+            off, lay = 0, {}
+            for s in self.convs.values():
+                if not s.trainable:
+                    continue
+                if s.name in ('backbone.layer2.0.conv1', 'backbone.layer2.0.downsample.0'):
+                    continue      # fed by frozen layer1: no data gradient needed
+                lay[s.name] = (off, s.cin * s.k * s.k * s.cout_pad)
+                off += _round_up(lay[s.name][1], 8)
+            lay['head.cls'] = (off, 256 * 9 * 128)
+            off += 256 * 9 * 128
+            lay['head.regctr'] = (off, 256 * 9 * 64)
+            off += 256 * 9 * 64
+            self._wT, self._wT_total = lay, off
+        return self._wT, self._wT_total
+
+    def refresh_frozen(self):
+        """Fold the frozen BatchNorms into per-channel (scale, bias) and build the bf16 packs of the frozen
+        convs.  y = gamma*(x-mean)/sqrt(var+eps)+beta = x*scale + bias  (BN eval mode, resnet.py:647-656)."""
+        dev = self.device
+        scs, bis, self.bn_off = [], [], {}
+        off = 0
+        for s in self.convs.values():
+            if not s.bn:
+                continue
+            g, b = self.fview(s.bn + '.weight'), self.fview(s.bn + '.bias')
+            m, v = self.fview(s.bn + '.running_mean'), self.fview(s.bn + '.running_var')
+            sc = g / torch.sqrt(v + 1e-5)
+            scs.append(sc)
+            bis.append(b - m * sc)
+            self.bn_off[s.bn] = off
+            off += s.cout
+        self.bn_scale = torch.cat(scs).contiguous()
+        self.bn_bias = torch.cat(bis).contiguous()
+        self.frozen16 = self.frozen.bfloat16()
+        w = self.fview('backbone.conv1.weight')           # [64][7][7][3] -> [64][448], k = tap*8 + c
+        wp = torch.zeros(64, 7 * 64, device=dev)
+        wp[:, :392] = torch.cat([w, torch.zeros(64, 7, 7, 5, device=dev)], -1).reshape(64, 392)
+        self.stem16 = wp.bfloat16()
+
+    def refresh_train_packs(self, stream_ptr=None):
+        """bf16 forward pack (= cast of the flat buffer) and dgrad packs.  Called after load_state_dict;
+        the fused SGD kernel keeps train16 current afterwards, the dgrad packs are re-made per step."""
+        if self.train16 is None or self.train16.device != self.device:
+            self.train16 = torch.empty(self.n_train, dtype=torch.bfloat16, device=self.device)
+        sp = stream_ptr or L.stream_ptr()
+        L.check(L.lib.dsl_cast_bf16(L.ptr(self.train), L.ptr(self.train16), self.n_train, sp), 'dsl_cast_bf16')
+        self.repack_dgrad(sp)
+
+    def repack_dgrad(self, sp=None):
+        lay, total = self.wT_layout()
+        if self.wT16 is None or self.wT16.device != self.device:
+            self.wT16 = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
+        sp = sp or L.stream_ptr()
+        esz = 2
+        for name, (off, n) in lay.items():
+            if name == 'head.cls':
+                w, co, cop, taps, cin, sc = self.tview('head.cls_w'), 80, 128, 9, 256, None
+            elif name == 'head.regctr':
+                w, co, cop, taps, cin, sc = self.tview('head.regctr_w'), 5, 64, 9, 256, None
+            else:
+                s = self.convs[name]
+                w, co, cop, taps, cin = self.tview(name + '.weight'), s.cout, s.cout_pad, s.k * s.k, s.cin
+                sc = self.bn_scale[self.bn_off[s.bn]:] if s.bn else None
+            L.check(L.lib.dsl_pack_dgrad(L.ptr(w), L.ptr(sc), self.wT16.data_ptr() + off * esz, co, cop, taps, cin, sp),
+                    'dsl_pack_dgrad')
+
+    def refresh(self):
+        assert self.device.type == 'cuda', 'the HIP packs live on the GPU'
+        self.refresh_frozen()
+        self.refresh_train_packs()
+        self.dirty = False
+
+    # -- pointers used by the plans -----------------------------------------------------------------
+    def w16_ptr(self, s):
+        if s.trainable:
+            return self.train16.data_ptr() + self.toff(s.name + '.weight') * 2
+        if s.name == 'backbone.conv1':
+            return self.stem16.data_ptr()
+        return self.frozen16.data_ptr() + self.frozen_regions[s.name + '.weight'][0] * 2
+
+    def t16_ptr(self, region):
+        return self.train16.data_ptr() + self.toff(region) * 2
+
+    def t32_ptr(self, region, buf=None):
+        return (self.train if buf is None else buf).data_ptr() + self.toff(region) * 4
+
+    def wT_ptr(self, name):
+        lay, _ = self.wT_layout()
+        return self.wT16.data_ptr() + lay[name][0] * 2
+
+    def bn_ptrs(self, bn):
+        o = self.bn_off[bn] * 4
+        return self.bn_scale.data_ptr() + o, self.bn_bias.data_ptr() + o
+
+    # -- reference-style initialisation (random-init weights for the benchmark) ---------------------
+    def init_reference_style(self, seed=0):
+        """Kaiming-normal backbone convs, Xavier-uniform FPN, Normal(0, 0.01) head with the focal prior
+        bias on conv_cls (fcos_head.py:83-91), BN gamma 1 / beta 0 / running stats (0, 1), scales 1."""
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+        for k, v in self.named_views().items():
+            leaf = k.rsplit('.', 1)[-1]
+            shape = tuple(v.shape)
+            if leaf == 'num_batches_tracked':
+                t = torch.zeros((), dtype=torch.long)
+            elif leaf == 'scale':
+                t = torch.tensor(1.0)
+            elif leaf == 'running_mean':
+                t = torch.zeros(shape)
+            elif leaf == 'running_var':
+                t = torch.ones(shape)
+            elif len(shape) == 4:
+                fan_in = shape[1] * shape[2] * shape[3]
+                fan_out = shape[0] * shape[2] * shape[3]
+                if k.startswith('backbone.'):
+                    t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_out)
+                elif k.startswith('neck.'):
+                    a = math.sqrt(6.0 / (fan_in + fan_out))
+                    t = (torch.rand(shape, generator=g) * 2 - 1) * a
+                else:
+                    t = torch.randn(shape, generator=g) * 0.01
+            elif leaf == 'weight':
+                t = torch.ones(shape)
+            else:
+                t = torch.zeros(shape)
+                if k == 'bbox_head.conv_cls.bias':
+                    t = torch.full(shape, -math.log((1 - 0.01) / 0.01))
+            sd[k] = t
+        self.load_named(sd)
+        return self

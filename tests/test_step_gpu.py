@@ -1,0 +1,106 @@
+"""Whole training step on the GPU (forward + loss + hand-written backward through the C ABI) against
+(1) golden vectors produced by the reference itself and (2) the CPU oracle, fp32 and bf16-emulating."""
+import numpy as np
+import pytest
+import torch
+
+from util import fcos_model_cfg, levels_to_flat, rel_l2
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def build(**head):
+    from dsl_amd import detectors  # noqa: F401  (registers the classes)
+    from dsl_amd.registry import build_detector
+    from oracle import fcos_oracle as O
+    cfg = fcos_model_cfg(**head)
+    model = build_detector(cfg)
+    model.load_state_dict(O.synth_state_dict(0))
+    return model.cuda()
+
+
+@pytest.mark.parametrize('name', ['net_tiny', 'net_small_dsl'])
+def test_train_step_vs_reference_and_oracle(golden, name):
+    from oracle import fcos_oracle as O
+    d = golden(name + '.npz')
+    B, dsl = int(d['B']), bool(int(d['dsl']))
+    head = dict(loss_weight=3.0, soft_weight=1.0, soft_warm_up=0) if dsl else {}
+    model = build(**head)
+    if dsl:
+        model.bbox_head.cur_iter = 1          # as in the fixture: past the warm-up window
+    img = T(d['img'])
+    gtb = [T(d[f'gt{i}']) for i in range(B)]
+    gtl = [T(d[f'gl{i}']) for i in range(B)]
+    ig = [T(d[f'ig{i}']) for i in range(B)] if dsl else None
+    metas = [dict(img_shape=tuple(img.shape[2:]) + (3,), pad_shape=tuple(img.shape[2:]) + (3,), scale_factor=1.0)] * B
+    losses = model.forward_train(img.cuda(), metas, gtb, gtl, ig)
+    total = sum(losses.values())
+    total.backward()
+    torch.cuda.synchronize()
+    got = {k: float(v) for k, v in losses.items()}
+    # (a) the reference itself (fp32): documented bf16 tolerance
+    for k in got:
+        assert got[k] == pytest.approx(float(d[k]), rel=3e-2), (k, got[k], float(d[k]))
+    # (b) oracle with bf16 storage emulation at the same points: the 1e-3 bar of north_star
+    sd = O.synth_state_dict(0)
+    kw = dict(loss_weight=3.0, soft_weight=1.0, soft_scale=1.0) if dsl else {}
+    ol, og, aux = O.train_step(sd, img, gtb, gtl, ig, emulate_bf16=True, **kw)
+    print(name, 'losses hip', got, 'oracle-bf16', ol, 'ref-fp32', {k: float(d[k]) for k in got})
+    for k in got:
+        assert got[k] == pytest.approx(ol[k], rel=2e-3), (k, got[k], ol[k])
+    plan = next(iter(model._engine.plans.values()))
+    cls = plan.bufs['cls_logits'].cpu()
+    ref_cls = levels_to_flat([c.detach() for c in aux['cls']])
+    assert rel_l2(cls, ref_cls) < 5e-3
+    rc = plan.bufs['regctr'].cpu()
+    # assignment indices are identical to the fp32 reference (exact arithmetic, independent of bf16)
+    _, raux = O.fcos_loss(aux['cls'], aux['reg'], aux['ctr'], gtb, gtl, ig, return_aux=True, **kw)
+    assert torch.equal(plan.lossplan.labels.cpu(), raux['labels'])
+    assert torch.equal(plan.lossplan.assign_idx.cpu().long(), raux['assign_idx'])
+    # gradients
+    named = dict(model.named_parameters())
+    keys = [str(k) for k in d['grad_keys']]
+    errs = {}
+    for k in keys:
+        errs[k] = rel_l2(named[k].grad.cpu(), og[k])
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    print('worst grad rel-l2 vs bf16 oracle:', worst)
+    assert max(errs.values()) < 6e-2, worst
+    assert float(np.median(list(errs.values()))) < 2e-2
+    ref_norms = dict(zip(keys, d['grad_norms']))
+    nerr = {k: abs(float(named[k].grad.norm()) - ref_norms[k]) / (ref_norms[k] + 1e-12) for k in keys}
+    print('worst grad-norm err vs fp32 reference:', sorted(nerr.items(), key=lambda kv: -kv[1])[:5])
+    assert max(nerr.values()) < 0.15
+
+
+def test_sgd_step_and_ema_on_flat_store():
+    from dsl_amd.optim import FlatSGD
+    from oracle import fcos_oracle as O
+    model = build()
+    rng = np.random.RandomState(0)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(2, 3, 64, 96, generator=g) * 40
+    gtb = [T(O.synth_boxes(rng, 2, H=64, W=96, lo=8, hi=60)) for _ in range(2)]
+    gtl = [T(rng.randint(0, 80, len(b)).astype('int64')) for b in gtb]
+    metas = [dict(img_shape=(64, 96, 3))] * 2
+    opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
+                  grad_clip=dict(max_norm=35, norm_type=2))
+    before = {k: v.clone().cpu() for k, v in model.state_dict().items()}
+    losses = model.forward_train(img.cuda(), metas, gtb, gtl)
+    sum(losses.values()).backward()
+    grads = {k: p.grad.clone().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    opt.step()
+    torch.cuda.synchronize()
+    after = {k: v.cpu() for k, v in model.state_dict().items()}
+    tk = O.trainable_keys(before)
+    params, bufs = O.sgd_step({k: before[k] for k in tk}, {k: grads[k] for k in tk}, {}, base_lr=0.01, max_norm=35,
+                              first_step=True)
+    for k in tk:
+        assert torch.allclose(after[k], params[k], rtol=1e-5, atol=1e-7), k
+    for k in before:
+        if k not in tk:
+            assert torch.equal(after[k], before[k]), k      # frozen tensors untouched
+    # bf16 pack follows the master weights
+    st = model.store
+    assert torch.equal(st.train16.float().cpu(), st.train.cpu().bfloat16().float())
