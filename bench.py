@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Benchmark of the FCOS R50-FPN training step (BASELINE.json metric: imgs/sec per training step,
+1333x800, at 1/2/4/8 MI355X).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" = one full pass of the hot path over one synthetic batch: image pack -> ResNet-50 -> FPN ->
+FCOS head -> target assignment -> focal/GIoU/centerness loss -> hand-written backward -> (N>1: RCCL
+gradient all-reduce overlapped with backward) -> fused SGD step + bf16 re-pack.  Inputs are resident
+in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+GFLOP_PER_IMAGE_STEP = 1185.8      # SURVEY.md §8d / BASELINE.md: fwd 419.55 + bwd 766.23 GFLOP per 800x1344 image
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+
+
+def model_cfg(dsl=False):
+    head = dict(type='FCOSHead', num_classes=80, in_channels=256, stacked_convs=4, feat_channels=256,
+                strides=[8, 16, 32, 64, 128], norm_on_bbox=True, centerness_on_reg=True, dcn_on_last_conv=False,
+                center_sampling=True, conv_bias=True,
+                loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                loss_bbox=dict(type='GIoULoss', loss_weight=1.0),
+                loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0))
+    if dsl:
+        head.update(loss_weight=3.0, soft_weight=1.0, soft_warm_up=5000)
+    return dict(type='FCOS',
+                backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                              norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='caffe'),
+                neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
+                          add_extra_convs='on_output', num_outs=5, relu_before_extra_convs=True),
+                bbox_head=head,
+                test_cfg=dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5),
+                              max_per_img=100))
+
+
+def synth_boxes(rng, n, H=800, W=1333, lo=16.0, hi=600.0):
+    cx, cy = rng.uniform(0, W, n), rng.uniform(0, H, n)
+    w = np.exp(rng.uniform(np.log(lo), np.log(min(hi, W)), n))
+    h = np.exp(rng.uniform(np.log(lo), np.log(min(hi, H)), n))
+    b = np.stack([np.clip(cx - w / 2, 0, W), np.clip(cy - h / 2, 0, H), np.clip(cx + w / 2, 0, W),
+                  np.clip(cy + h / 2, 0, H)], 1).astype('float32')
+    return b[((b[:, 2] - b[:, 0]) >= 1) & ((b[:, 3] - b[:, 1]) >= 1)]
+
+
+def synth_batch(rank, n_img=2, H=800, W=1344, device='cuda'):
+    """N(0,1) image values (bf16-representable), G ~ clip(Poisson(7), 1, 40) boxes,
+    log-uniform sizes 16..600 px inside the 1333x800 area, labels U{0..79}."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn(n_img, 3, H, W, generator=g).bfloat16().float()
+    rng = np.random.RandomState(2024 + rank)
+    gtb, gtl = [], []
+    for _ in range(n_img):
+        b = synth_boxes(rng, int(np.clip(rng.poisson(7), 1, 40)))
+        gtb.append(torch.from_numpy(b))
+        gtl.append(torch.from_numpy(rng.randint(0, 80, len(b)).astype('int64')))
+    metas = [dict(img_shape=(800, 1333, 3), pad_shape=(H, W, 3), scale_factor=1.0) for _ in range(n_img)]
+    return dict(img=img.to(device), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
+
+
+def cpu_baseline(batch, seed=0):
+    """The CPU restatement of the SAME step (oracle/fcos_oracle.py, fp32 torch on the host cores), timed on a
+    bounded sample: one full N=2 step at 800x1344 (forward + loss + autograd backward + SGD)."""
+    from oracle import fcos_oracle as O
+    from dsl_amd.params import ParamStore
+    torch.manual_seed(seed)
+    store = ParamStore(80, 'cpu').init_reference_style(0)
+    sd = {k: v.clone() for k, v in store.named_views().items()}
+    img = batch['img'].cpu()
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    losses, grads, _ = O.train_step(sd, img, batch['gt_bboxes'], batch['gt_labels'], None)
+    tk = O.trainable_keys(sd)
+    O.sgd_step({k: sd[k] for k in tk}, grads, {}, first_step=True)
+    dt = time.perf_counter() - t0
+    n = img.shape[0]
+    return dict(value=n / dt, unit='imgs/s', cores=cores, kind='port',
+                sample=f'1 training step, {n} x (3,800,1344) fp32, torch CPU {cores} threads, {dt:.1f} s'), losses
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--imgs-per-gpu', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='do not bracket the conv kernels with HIP events')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+
+    from dsl_amd import _lib as L
+    from dsl_amd import detectors  # noqa: F401
+    from dsl_amd.optim import FlatSGD
+    from dsl_amd.parallel import HipDistributedDataParallel
+    from dsl_amd.registry import build_detector
+
+    model = build_detector(model_cfg()).cuda()      # random init, reference style, same seed on every rank
+    model.lazy_log = True
+    if world > 1:
+        model = HipDistributedDataParallel(model)
+    det = model.module if world > 1 else model
+    opt = FlatSGD(det, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+    batch = synth_batch(rank, args.imgs_per_gpu)
+
+    def step():
+        out = model.train_step(batch, opt)
+        out['loss'].backward()
+        opt.step()
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.no_prof:
+        L.lib.dsl_prof_reset()
+        L.lib.dsl_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step()
+        if (i + 1) % 10 == 0:            # TextLoggerHook interval=10: one host read of the log vars
+            _ = {k: float(v) for k, v in out['log_vars'].items()}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L.lib.dsl_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    log = {k: float(v) for k, v in out['log_vars'].items()}
+
+    n_total = args.imgs_per_gpu * world * args.steps
+    value = n_total / dt
+    roof = None
+    if not args.no_prof:
+        launches = (C.c_int64 * 3)()
+        ms = (C.c_double * 3)()
+        fl = (C.c_double * 3)()
+        L.lib.dsl_prof_read(launches, ms, fl)
+        if launches[0]:
+            ach = fl[0] / (ms[0] * 1e-3) / 1e12
+            roof = dict(bound='mfma', kernel='conv_gemm_kernel<128,false> (forward + data-gradient implicit GEMM)',
+                        achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                        traffic=None, launches_per_step=launches[0] // args.steps,
+                        avg_launch_us=round(ms[0] * 1e3 / launches[0], 2),
+                        algorithmic_gflop_per_launch=round(fl[0] / launches[0] / 1e9, 3),
+                        wgrad_kernel=dict(achieved=round(fl[2] / (ms[2] * 1e-3) / 1e12, 1) if launches[2] else None,
+                                          avg_launch_us=round(ms[2] * 1e3 / max(launches[2], 1), 2),
+                                          launches_per_step=launches[2] // args.steps),
+                        whole_step_frac=round(value / world * GFLOP_PER_IMAGE_STEP / 1e3 / PEAK_BF16_TFLOPS, 4))
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, _ = cpu_baseline(batch)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'imgs/sec training step, FCOS R50-FPN 1333x800', 'value': round(value, 2), 'unit': 'imgs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'FCOS R50-caffe-FPN supervised training step (BASELINE.json configs[1]), '
+                                   f'{args.imgs_per_gpu} x (3,800,1344) per GPU, synthetic COCO-shaped boxes, '
+                                   'random-init weights', 'global_batch': args.imgs_per_gpu * world,
+                       'parallelism': f'dp{world}', 'optimizer': 'SGD momentum 0.9 wd 1e-4'},
+            'roofline': roof, 'cpu_baseline': cpu, 'final_losses': log}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

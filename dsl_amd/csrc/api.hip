@@ -47,6 +47,55 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
   return 0;
 }
 
+// ---- live kernel timing ----------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+constexpr int kMaxRec = 1 << 15;
+bool g_prof_on = false;
+ProfRec* g_rec = nullptr;
+int g_nrec = 0, g_nevents = 0;
+}  // namespace
+
+bool dsl_prof_active() { return g_prof_on; }
+
+int dsl_prof_begin(int cls, double flops, hipStream_t st) {
+  if (!g_prof_on || g_nrec >= kMaxRec) return -1;
+  if (!g_rec) g_rec = (ProfRec*)calloc(kMaxRec, sizeof(ProfRec));
+  if (g_nrec >= g_nevents) {
+    hipEventCreate(&g_rec[g_nrec].a);
+    hipEventCreate(&g_rec[g_nrec].b);
+    g_nevents = g_nrec + 1;
+  }
+  g_rec[g_nrec].cls = cls;
+  g_rec[g_nrec].flops = flops;
+  hipEventRecord(g_rec[g_nrec].a, st);
+  return g_nrec++;
+}
+
+void dsl_prof_end(int id, hipStream_t st) {
+  if (id >= 0) hipEventRecord(g_rec[id].b, st);
+}
+
+extern "C" int dsl_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+extern "C" int dsl_prof_reset(void) {
+  g_nrec = 0;
+  return 0;
+}
+extern "C" int dsl_prof_read(int64_t* launches, double* ms, double* flops) {
+  for (int c = 0; c < DSL_PROF_CLASSES; ++c) { launches[c] = 0; ms[c] = 0; flops[c] = 0; }
+  for (int i = 0; i < g_nrec; ++i) {
+    hipEventSynchronize(g_rec[i].b);
+    float t = 0.f;
+    hipEventElapsedTime(&t, g_rec[i].a, g_rec[i].b);
+    const int c = g_rec[i].cls;
+    if (c >= 0 && c < DSL_PROF_CLASSES) { launches[c]++; ms[c] += t; flops[c] += g_rec[i].flops; }
+  }
+  return 0;
+}
+
 // ---- probe: semantics of ds_read_b64_tr_b16 (used by tests/test_probe_gpu.py) -------------------
 __global__ void probe_tr16_kernel(const uint16_t* img, const int* lane_off, uint16_t* out) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[4096];

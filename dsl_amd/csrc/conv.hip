@@ -578,11 +578,17 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     }                                                                                             \
     hipLaunchKernelGGL((conv_gemm_kernel<BCO_, SC_>), grid, dim3(256), lds, st, k);               \
   } while (0)
+  int prof = -1;
+  if (dsl_prof_active()) {
+    const double cin_real = smallc ? 3.0 : (double)d->cs;
+    prof = dsl_prof_begin((bco == 128 && !smallc) ? 0 : 1, 2.0 * px * (double)d->cd * d->kh * d->kw * cin_real, st);
+  }
   if (bco == 128) {
     if (smallc) LAUNCH(128, true); else LAUNCH(128, false);
   } else {
     if (smallc) LAUNCH(64, true); else LAUNCH(64, false);
   }
+  dsl_prof_end(prof, st);
 #undef LAUNCH
   DSL_LAUNCH_CHECK("conv_gemm_kernel");
   return 0;
@@ -651,6 +657,7 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(d->cy / bco, d->kh * d->kw * d->cs / 128, splits);
   const size_t lds = 2 * (size_t)(64 * bco * 2 + 64 * 256);
+  const int prof = dsl_prof_active() ? dsl_prof_begin(2, 2.0 * px * (double)d->cd * d->kh * d->kw * d->cs, st) : -1;
   if (bco == 128) {
     static bool a = false;
     if (!a) { hipFuncSetAttribute((const void*)wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
@@ -660,6 +667,7 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
     if (!a) { hipFuncSetAttribute((const void*)wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
     hipLaunchKernelGGL((wgrad_kernel<64>), grid, dim3(256), lds, st, k);
   }
+  dsl_prof_end(prof, st);
   DSL_LAUNCH_CHECK("wgrad_kernel");
   const long long total4 = (long long)d->cd * k.krow / 4;
   int rb = (int)((total4 + 255) / 256);

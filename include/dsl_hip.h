@@ -236,6 +236,17 @@ typedef struct dsl_op {
 } dsl_op;
 int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Live kernel timing with HIP events (bench.py roofline): when enabled, each launch of the MFMA
+ * conv kernels is bracketed by a hipEvent pair on the launch stream.  Classes: 0 = conv_gemm_kernel
+ * <128,false> (forward + data gradient), 1 = conv_gemm_kernel<64,*>/<128,true>, 2 = wgrad_kernel.
+ * dsl_prof_read synchronises the events and returns per class: launches, total ms, algorithmic FLOPs.
+ * ---------------------------------------------------------------------------------------- */
+#define DSL_PROF_CLASSES 3
+int dsl_prof_enable(int on);
+int dsl_prof_reset(void);
+int dsl_prof_read(int64_t* launches, double* ms, double* flops);
+
 /* hardware probes used by the tests */
 int dsl_probe_tr16(const uint16_t* lds_image /* 4096 u16 */, const int32_t* lane_off /* 64 u16-offsets */,
                    uint16_t* out /* [64][4] */, void* stream);

@@ -261,10 +261,22 @@ def head_forward(sd, feats, q, training=True):
     return cls_scores, bbox_preds, ctrs
 
 
-def extract_and_head(sd, img, q, training=True):
-    """single_stage.py:40-45 + base_dense_head.py:49."""
+def extract_and_head(sd, img, q, training=True, debug=None):
+    """single_stage.py:40-45 + base_dense_head.py:49.  `debug` (dict) receives the backbone / FPN
+    feature maps with retain_grad() so tests can compare intermediate gradients."""
     x = q.act(img) if q.on else img
-    return head_forward(sd, fpn_forward(sd, resnet50_forward(sd, x, q), q), q, training)
+    c = resnet50_forward(sd, x, q)
+    f = fpn_forward(sd, c, q)
+    if debug is not None:
+        for i, t in enumerate(c):
+            if t.requires_grad:
+                t.retain_grad()
+            debug[f'c{i + 2}'] = t
+        for i, t in enumerate(f):
+            if t.requires_grad:
+                t.retain_grad()
+            debug[f'p{i + 3}'] = t
+    return head_forward(sd, f, q, training)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -488,12 +500,12 @@ def append_half_scale(img, gt_bboxes, gt_labels, gt_bboxes_ignore):
 # whole step: forward + loss + backward   (detectors/single_stage.py:56-84, base.py:175-243)
 # ----------------------------------------------------------------------------------------------
 def train_step(sd, img, gt_bboxes, gt_labels, gt_bboxes_ignore=None, emulate_bf16=False,
-               want_grads=True, **loss_kw):
+               want_grads=True, debug=None, **loss_kw):
     q = Quant(emulate_bf16)
     tk = trainable_keys(sd)
     p = {k: (v.detach().clone().requires_grad_(k in tk) if v.is_floating_point() else v)
          for k, v in sd.items()}
-    cls, reg, ctr = extract_and_head(p, img, q, training=True)
+    cls, reg, ctr = extract_and_head(p, img, q, training=True, debug=debug)
     for t in cls + reg + ctr:
         t.retain_grad()
     losses = fcos_loss(cls, reg, ctr, gt_bboxes, gt_labels, gt_bboxes_ignore, **loss_kw)
