@@ -1,0 +1,302 @@
+// Teacher-sweep post-processing on the GPU: per-level top-k by max_c(score*centerness), box decode +
+// clip + rescale, score threshold, class-aware greedy NMS, top max_per_img.
+//
+// Restates FCOSHead._get_bboxes (mmdet/models/dense_heads/fcos_head.py:406-548), multiclass_nms
+// (mmdet/core/post_processing/bbox_nms.py:7-94) and mmcv.ops.batched_nms / nms (mmcv-full 1.3.10,
+// un-vendored: class-offset trick boxes + label*(max+1), suppress IoU > thr, offset 0, scores sorted
+// descending) of the reference, replacing the GPU->CPU numpy->JSON round trip of
+// mmdet/runner/hooks/unlabel_pred_hook.py:194-293.
+#include "common.hpp"
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int CAND_CAP = 16384;
+constexpr int NMS_THREADS = 1024;
+
+struct DetK {
+  int nlvl, n, num_classes, nms_pre, max_per_img;
+  int h[DSL_MAX_SEG], w[DSL_MAX_SEG], stride[DSL_MAX_SEG];
+  int mstart[DSL_MAX_SEG + 1];
+  float score_thr, iou_thr;
+  const float* cls; int ld_cls;
+  const float* rc; int ld_rc;
+  const float* scales; const float* img_shapes; const float* scale_factors;
+  float* dets; long long* det_labels; int* det_count;
+  // workspace
+  float* keys; int* sel; int* selcnt; float* cbox; float* cscore; int* clabel; int* ccount;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// key[m] = max_c sigmoid(cls) * sigmoid(ctr)     (fcos_head.py:472-473)
+__global__ void det_key_kernel(const DetK p) {
+  const int M = p.mstart[p.nlvl];
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float* c = p.cls + (long long)m * p.ld_cls;
+  const float ctr = sigmoidf_(p.rc[(long long)m * p.ld_rc + 4]);
+  float best = -1.f;
+  for (int k = 0; k < p.num_classes; k += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(c + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) best = fmaxf(best, sigmoidf_(v[e]) * ctr);
+  }
+  p.keys[m] = best;
+}
+
+// one block per (image, level): indices of the top nms_pre keys (all of them when the level is smaller)
+__global__ __launch_bounds__(1024) void det_select_kernel(const DetK p) {
+  __shared__ unsigned hist[2048];
+  __shared__ unsigned s_prefix, s_need, s_cnt, s_tie;
+  const int lvl = blockIdx.x, img = blockIdx.y;
+  const int P = p.h[lvl] * p.w[lvl];
+  const int base = p.mstart[lvl] + img * P;
+  int* sel = p.sel + ((long long)img * p.nlvl + lvl) * p.nms_pre;
+  int* cnt = p.selcnt + img * p.nlvl + lvl;
+  const int k = p.nms_pre;
+  if (!(k > 0 && k < P)) {        // get_k_for_topk: take everything
+    for (int i = threadIdx.x; i < P; i += blockDim.x) sel[i] = i;
+    if (threadIdx.x == 0) *cnt = P;
+    return;
+  }
+  // radix select (keys are non-negative floats: bit pattern is monotonic), 11 + 11 + 10 bits
+  unsigned prefix = 0, mask = 0;
+  unsigned need = k;
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << bits[pass];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+      const unsigned u = __float_as_uint(p.keys[base + i]);
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned acc = 0;
+      int b = nb - 1;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= need) break;
+        acc += hist[b];
+      }
+      s_prefix = prefix | ((unsigned)b << shifts[pass]);
+      s_need = need - acc;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    need = s_need;
+    mask |= ((unsigned)(nb - 1)) << shifts[pass];
+    __syncthreads();
+  }
+  // prefix = bit pattern of the k-th largest key; `need` = how many ties at that value to take
+  if (threadIdx.x == 0) {
+    s_cnt = 0;
+    s_tie = 0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    const unsigned u = __float_as_uint(p.keys[base + i]);
+    if (u > prefix) {
+      sel[atomicAdd(&s_cnt, 1u)] = i;
+    } else if (u == prefix) {
+      const unsigned t = atomicAdd(&s_tie, 1u);
+      if (t < need) sel[atomicAdd(&s_cnt, 1u)] = i;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *cnt = (int)s_cnt;
+}
+
+// one thread per (image, level, selected slot, class): emit candidates with score > score_thr
+__global__ void det_candidates_kernel(const DetK p) {
+  const int img = blockIdx.z, lvl = blockIdx.y;
+  const int nsel = p.selcnt[img * p.nlvl + lvl];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = t / p.num_classes, c = t - slot * p.num_classes;
+  if (slot >= nsel) return;
+  const int P = p.h[lvl] * p.w[lvl];
+  const int loc = p.sel[((long long)img * p.nlvl + lvl) * p.nms_pre + slot];
+  const int m = p.mstart[lvl] + img * P + loc;
+  const float score = sigmoidf_(p.cls[(long long)m * p.ld_cls + c]);
+  if (!(score > p.score_thr)) return;                    // bbox_nms.py:54: valid BEFORE the centerness factor
+  const float* rc = p.rc + (long long)m * p.ld_rc;
+  const float ctr = sigmoidf_(rc[4]);
+  const int s = p.stride[lvl];
+  const int y = loc / p.w[lvl], x = loc - y * p.w[lvl];
+  const float px = (float)x * (float)s + (float)(s / 2), py = (float)y * (float)s + (float)(s / 2);
+  const float sc = p.scales[lvl];
+  float d[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] = fmaxf(rc[e] * sc, 0.f) * (float)s;      // fcos_head.py:159-165 (eval)
+  const float H = p.img_shapes[2 * img], W = p.img_shapes[2 * img + 1];
+  float b[4] = {px - d[0], py - d[1], px + d[2], py + d[3]};
+  b[0] = fminf(fmaxf(b[0], 0.f), W);                    // distance2bbox clip (transforms.py:150-160)
+  b[1] = fminf(fmaxf(b[1], 0.f), H);
+  b[2] = fminf(fmaxf(b[2], 0.f), W);
+  b[3] = fminf(fmaxf(b[3], 0.f), H);
+  if (p.scale_factors) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = b[e] / p.scale_factors[4 * img + e];
+  }
+  const int slot_out = atomicAdd(p.ccount + img, 1);
+  if (slot_out >= CAND_CAP) return;
+  float* cb = p.cbox + ((long long)img * CAND_CAP + slot_out) * 4;
+  cb[0] = b[0]; cb[1] = b[1]; cb[2] = b[2]; cb[3] = b[3];
+  p.cscore[(long long)img * CAND_CAP + slot_out] = score * ctr;
+  p.clabel[(long long)img * CAND_CAP + slot_out] = c;
+}
+
+__device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr) {
+  // mmcv nms_cuda_kernel.cuh IoU with offset 0
+  const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+  const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+  const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+  const float inter = width * height;
+  const float sa = (a[2] - a[0]) * (a[3] - a[1]), sb = (b[2] - b[0]) * (b[3] - b[1]);
+  return inter / (sa + sb - inter) > thr;
+}
+
+// one block per image: sort candidates by score (bitonic, LDS), greedy class-aware NMS, keep max_per_img
+__global__ __launch_bounds__(NMS_THREADS) void det_nms_kernel(const DetK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* keyidx = reinterpret_cast<unsigned long long*>(smem);          // CAND_CAP * 8
+  float* kept = reinterpret_cast<float*>(smem + (size_t)CAND_CAP * 8);                // max_per_img * 4 (offset boxes)
+  __shared__ float s_red[NMS_THREADS / 64];
+  __shared__ int s_nkept, s_flag;
+  const int img = blockIdx.x;
+  int n = p.ccount[img];
+  if (n > CAND_CAP) n = CAND_CAP;
+  const float* cbox = p.cbox + (long long)img * CAND_CAP * 4;
+  const float* cscore = p.cscore + (long long)img * CAND_CAP;
+  const int* clabel = p.clabel + (long long)img * CAND_CAP;
+  // max coordinate over the valid boxes (batched_nms: offsets = idxs * (boxes.max() + 1))
+  float mx = -3.0e38f;
+  for (int i = threadIdx.x; i < n * 4; i += blockDim.x) mx = fmaxf(mx, cbox[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = s_red[0];
+  for (int i = 1; i < NMS_THREADS / 64; ++i) mx = fmaxf(mx, s_red[i]);
+  const float offs = mx + 1.0f;
+  // sort descending by score; ties by ascending candidate slot (deterministic given the slot order)
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+    unsigned long long k = 0ull;
+    if (i < n) k = ((unsigned long long)__float_as_uint(cscore[i]) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+    keyidx[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keyidx[i], b = keyidx[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (a < b) : (a > b)) {
+            keyidx[i] = b;
+            keyidx[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  if (threadIdx.x == 0) s_nkept = 0;
+  __syncthreads();
+  // greedy scan: candidate i survives iff no kept box (same label via the offset trick) has IoU > thr
+  const int maxk = p.max_per_img;
+  for (int i = 0; i < n; ++i) {
+    const int nk = s_nkept;
+    if (nk >= maxk) break;
+    const int ci = (int)(0xffffffffu - (unsigned)(keyidx[i] & 0xffffffffu));
+    const float off = (float)clabel[ci] * offs;
+    const float bi[4] = {cbox[4 * ci] + off, cbox[4 * ci + 1] + off, cbox[4 * ci + 2] + off, cbox[4 * ci + 3] + off};
+    if (threadIdx.x == 0) s_flag = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < nk && iou_gt(kept + 4 * threadIdx.x, bi, p.iou_thr)) s_flag = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && !s_flag) {
+      kept[4 * nk] = bi[0]; kept[4 * nk + 1] = bi[1]; kept[4 * nk + 2] = bi[2]; kept[4 * nk + 3] = bi[3];
+      float* o = p.dets + ((long long)img * maxk + nk) * 5;
+      o[0] = cbox[4 * ci]; o[1] = cbox[4 * ci + 1]; o[2] = cbox[4 * ci + 2]; o[3] = cbox[4 * ci + 3];
+      o[4] = cscore[ci];
+      p.det_labels[(long long)img * maxk + nk] = clabel[ci];
+      s_nkept = nk + 1;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.det_count[img] = s_nkept;
+}
+
+size_t ws_layout(const dsl_det_desc* d, size_t off[8]) {
+  long long M = 0;
+  for (int l = 0; l < d->nlvl; ++l) M += (long long)d->n * d->h[l] * d->w[l];
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+  off[0] = take(M * 4);                                           // keys
+  off[1] = take((size_t)d->n * d->nlvl * d->nms_pre * 4);         // sel
+  off[2] = take((size_t)d->n * d->nlvl * 4);                      // selcnt
+  off[3] = take((size_t)d->n * CAND_CAP * 16);                    // cbox
+  off[4] = take((size_t)d->n * CAND_CAP * 4);                     // cscore
+  off[5] = take((size_t)d->n * CAND_CAP * 4);                     // clabel
+  off[6] = take((size_t)d->n * 4);                                // ccount
+  return o;
+}
+
+}  // namespace
+
+extern "C" size_t dsl_detect_workspace_bytes(const dsl_det_desc* d) {
+  size_t off[8];
+  return ws_layout(d, off);
+}
+
+extern "C" int dsl_fcos_detect(const dsl_det_desc* d, void* stream) {
+  DSL_CHECK(d && d->nlvl >= 1 && d->nlvl <= DSL_MAX_SEG && d->n >= 1, "dsl_fcos_detect: bad descriptor");
+  DSL_CHECK(d->cls_logits && d->regctr && d->scales && d->img_shapes && d->dets && d->det_labels && d->det_count &&
+                d->workspace,
+            "dsl_fcos_detect: null pointer");
+  DSL_CHECK(d->num_classes % 4 == 0 && d->ld_cls % 4 == 0 && d->ld_rc >= 5, "dsl_fcos_detect: unsupported layout");
+  DSL_CHECK(d->max_per_img > 0 && d->max_per_img <= NMS_THREADS && d->nms_pre > 0, "dsl_fcos_detect: max_per_img must be in 1..%d", NMS_THREADS);
+  size_t off[8];
+  const size_t need = ws_layout(d, off);
+  DSL_CHECK(d->workspace_bytes >= need, "dsl_fcos_detect: workspace too small (%zu < %zu)", d->workspace_bytes, need);
+  DetK k;
+  memset(&k, 0, sizeof(k));
+  k.nlvl = d->nlvl; k.n = d->n; k.num_classes = d->num_classes; k.nms_pre = d->nms_pre; k.max_per_img = d->max_per_img;
+  int m = 0, maxP = 0;
+  for (int l = 0; l < d->nlvl; ++l) {
+    k.h[l] = d->h[l]; k.w[l] = d->w[l]; k.stride[l] = d->stride[l];
+    k.mstart[l] = m;
+    m += d->n * d->h[l] * d->w[l];
+    maxP = max(maxP, d->h[l] * d->w[l]);
+  }
+  k.mstart[d->nlvl] = m;
+  k.score_thr = d->score_thr; k.iou_thr = d->iou_thr;
+  k.cls = d->cls_logits; k.ld_cls = d->ld_cls; k.rc = d->regctr; k.ld_rc = d->ld_rc;
+  k.scales = d->scales; k.img_shapes = d->img_shapes; k.scale_factors = d->scale_factors;
+  k.dets = d->dets; k.det_labels = (long long*)d->det_labels; k.det_count = d->det_count;
+  unsigned char* ws = (unsigned char*)d->workspace;
+  k.keys = (float*)(ws + off[0]); k.sel = (int*)(ws + off[1]); k.selcnt = (int*)(ws + off[2]);
+  k.cbox = (float*)(ws + off[3]); k.cscore = (float*)(ws + off[4]); k.clabel = (int*)(ws + off[5]);
+  k.ccount = (int*)(ws + off[6]);
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(k.ccount, 0, sizeof(int) * d->n, st);
+  hipMemsetAsync(d->dets, 0, sizeof(float) * 5 * d->n * d->max_per_img, st);
+  hipLaunchKernelGGL(det_key_kernel, dim3((m + 255) / 256), dim3(256), 0, st, k);
+  hipLaunchKernelGGL(det_select_kernel, dim3(d->nlvl, d->n), dim3(1024), 0, st, k);
+  const int per_lvl = min(maxP, d->nms_pre) * d->num_classes;
+  hipLaunchKernelGGL(det_candidates_kernel, dim3((per_lvl + 255) / 256, d->nlvl, d->n), dim3(256), 0, st, k);
+  const size_t lds = (size_t)CAND_CAP * 8 + (size_t)d->max_per_img * 16;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)det_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)CAND_CAP * 8 + NMS_THREADS * 16));
+    attr = true;
+  }
+  hipLaunchKernelGGL(det_nms_kernel, dim3(d->n), dim3(NMS_THREADS), lds, st, k);
+  DSL_LAUNCH_CHECK("dsl_fcos_detect");
+  return 0;
+}

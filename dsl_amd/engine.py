@@ -331,7 +331,8 @@ class Plan:
             self.g_stage[li] = [g0, g1]
             ol.conv(self._dgrad(lc[i].name, g_lat[i], g0, N, [hw], [hw], cs=256, cd=cch, k=1, stride=1, pad=0,
                                 mask=cfeat, mask_first=True))
-        self.bwd_segments.append((ol, (reg['neck.lateral_convs.0.conv.weight'][0], st.n_train)))
+        buckets = st.grad_buckets()
+        self.bwd_segments.append((ol, buckets[0]))
         # ================= backbone: layer4, layer3, layer2 =================
         blocks_by_stage = {li: [b for b in self.blocks if b['stage'] == li] for li in (1, 2, 3)}
         for li in (3, 2, 1):
@@ -367,9 +368,7 @@ class Plan:
                         for spec, dy in ((ds, g_pre), (c1, gA1)):
                             ol.conv(self._dgrad(spec.name, dy, tgt, N, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
-            lo = reg[f'backbone.layer{li + 1}.0.conv1.weight'][0]
-            hi = reg[f'backbone.layer{li + 2}.0.conv1.weight'][0] if li < 3 else reg['neck.lateral_convs.0.conv.weight'][0]
-            self.bwd_segments.append((ol, (lo, hi)))
+            self.bwd_segments.append((ol, buckets[4 - li]))
 
     # ---------------------------------------------------------------------------------------------
     def forward(self, img=None):

@@ -279,6 +279,14 @@ class ParamStore:
         self.refresh_train_packs()
         self.dirty = False
 
+    def grad_buckets(self):
+        """Contiguous gradient ranges in the order the backward completes them: head+FPN, layer4, layer3,
+        layer2.  Together they cover the whole flat gradient buffer exactly once."""
+        r = self.train_regions
+        b = [r[f'backbone.layer{i}.0.conv1.weight'][0] for i in (2, 3, 4)] + [r['neck.lateral_convs.0.conv.weight'][0],
+                                                                             self.n_train]
+        return [(b[3], b[4]), (b[2], b[3]), (b[1], b[2]), (b[0], b[1])]
+
     # -- pointers used by the plans -----------------------------------------------------------------
     def w16_ptr(self, s):
         if s.trainable:

@@ -1,0 +1,115 @@
+"""Host-side logic on CPU: registry / config surface, parameter store layout, runner helpers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import fcos_model_cfg
+
+REF_CFG = '/root/reference/configs/fcos_semi/r50_caffe_mslonger_tricks_0.Xdata.py'
+
+
+def build():
+    from dsl_amd import detectors  # noqa: F401
+    from dsl_amd.registry import build_detector
+    return build_detector(fcos_model_cfg())
+
+
+def test_state_dict_matches_reference_layout():
+    from oracle import fcos_oracle as O
+    m = build()
+    sd = O.synth_state_dict(0)
+    m.load_state_dict(sd)
+    out = m.state_dict()
+    assert len(out) == 377 and set(out) == set(sd)
+    for k, v in sd.items():
+        assert tuple(out[k].shape) == tuple(v.shape) and out[k].dtype == v.dtype, k
+        assert torch.equal(out[k], v), k
+    train = [k for k, p in m.named_parameters() if p.requires_grad]
+    assert sorted(train) == sorted(O.trainable_keys(sd))
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 32021850
+    # views alias the flat buffer: an in-place edit through state_dict is seen by the store
+    out['bbox_head.conv_cls.bias'].fill_(-1.25)
+    assert float(m.store.tview('head.cls_b')[:80].mean()) == -1.25
+    lo_hi = m.store.grad_buckets()
+    assert lo_hi[-1][0] == 0 and lo_hi[0][1] == m.store.n_train
+    assert all(a[0] == b[1] for a, b in zip(lo_hi[:-1], lo_hi[1:]))
+
+
+def test_hot_path_refuses_to_run_without_gpu():
+    m = build()
+    with pytest.raises(RuntimeError):
+        m.forward_train(torch.zeros(1, 3, 64, 64), [dict()], [torch.zeros(0, 4)], [torch.zeros(0, dtype=torch.long)])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason='reference tree not present')
+def test_reference_config_builds_unmodified():
+    from dsl_amd import detectors, runner  # noqa: F401
+    from dsl_amd.optim import build_optimizer
+    from dsl_amd.registry import Config, build_detector
+    cfg = Config.fromfile(REF_CFG)
+    m = build_detector(cfg.model)
+    opt = build_optimizer(m, cfg.optimizer, grad_clip=cfg.optimizer_config.get('grad_clip'))
+    assert type(m).__name__ == 'FCOS' and opt.bias_lr_mult == 2.0 and opt.bias_decay_mult == 0.0
+    cfg.merge_from_dict(Config.parse_cfg_options(['model.bbox_head.loss_weight=3.0', 'data.samples_per_gpu=4']))
+    assert cfg.model.bbox_head.loss_weight == 3.0 and cfg.data.samples_per_gpu == 4
+    dsl = Config.fromfile(os.path.join(os.path.dirname(REF_CFG), [f for f in os.listdir(os.path.dirname(REF_CFG)) if f.startswith('RLA')][0]))
+    with pytest.raises(NotImplementedError):
+        build_detector(dsl.model)          # RLA_ResNet is a "next" row; the error says how to override
+    dsl.merge_from_dict({'model.backbone': dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                                                frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=False),
+                                                norm_eval=True, style='caffe')})
+    m2 = build_detector(dsl.model)
+    assert m2.bbox_head.loss_weight == 3.0 and m2.bbox_head.soft_warm_up == 5000
+
+
+def test_scale_invariant_batch_matches_oracle():
+    from dsl_amd.runner import append_half_scale
+    from oracle import fcos_oracle as O
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(2, 3, 64, 96, generator=g)
+    gb = [torch.rand(3, 4) * 50, torch.rand(2, 4) * 50]
+    gl = [torch.tensor([1, 2, 3]), torch.tensor([4, 5])]
+    ig = [torch.zeros(0, 4), torch.rand(1, 4) * 50]
+    metas = [dict(img_shape=(64, 90, 3), pad_shape=(64, 96, 3), scale_factor=1.0)] * 2
+    a = append_half_scale(img, gb, gl, ig, metas)
+    b = O.append_half_scale(img, gb, gl, ig)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1][2], b[1][2]) and torch.equal(a[3][2], b[3][2])
+    assert a[4][2]['img_shape'] == (32, 45, 3) and a[4][2]['pad_shape'] == (32, 48, 3)
+
+
+def test_soft_warmup_counter_and_lr_schedule():
+    from dsl_amd.runner import StepLrUpdaterHook
+    m = build()
+    h = m.bbox_head
+    h.soft_weight, h.soft_warm_up = 1.0, 2
+    assert [h.effective_soft_weight(3) for _ in range(5)] == [0.001, 0.001, 0.001, 1.0, 1.0]     # fcos_head.py:323-326
+    assert h.effective_soft_weight(2) == 0.0
+
+    class R:
+        epoch, iter = 0, 0
+        optimizer = type('O', (), {'param_groups': [dict(lr=0.01, initial_lr=0.01), dict(lr=0.02, initial_lr=0.02)]})()
+    hook = StepLrUpdaterHook(step=[20, 26], warmup='linear', warmup_iters=500, warmup_ratio=1.0 / 3)
+    r = R()
+    hook.before_train_iter(r)
+    assert r.optimizer.param_groups[0]['lr'] == pytest.approx(0.01 / 3)
+    r.iter = 250
+    hook.before_train_iter(r)
+    assert r.optimizer.param_groups[0]['lr'] == pytest.approx(0.01 * (1 - 0.5 * (2 / 3)))
+    r.iter, r.epoch = 10000, 21
+    hook.before_train_iter(r)
+    assert r.optimizer.param_groups[1]['lr'] == pytest.approx(0.002)
+
+
+def test_adaptive_thresholds_and_split():
+    from dsl_amd.runner import adaptive_thresholds, split_pseudo_labels
+    by_c = {0: [0.9, 0.8, 0.35, 0.2], 1: [0.31], 2: [0.1]}
+    thr, w = adaptive_thresholds(by_c)
+    assert set(thr) == {0, 1} and all(0.3 <= v <= 0.35 for v in thr.values())
+    avg = 4 / 2
+    assert thr[0] == pytest.approx(max(min((2.05 / avg) ** 0.05 * 0.3, 0.35), 0.3))
+    assert w[1] == pytest.approx((avg / 0.31) ** 0.6)
+    gt, gl, ig = split_pseudo_labels(np.array([[0, 0, 10, 10], [5, 5, 30, 30], [1, 1, 1.5, 9]]), [0, 0, 1], [0.5, 0.2, 0.9],
+                                     {0: 0.32})
+    assert gt.shape == (1, 4) and gl.tolist() == [0] and ig.shape == (1, 4)
