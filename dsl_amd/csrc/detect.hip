@@ -24,7 +24,7 @@ struct DetK {
   const float* scales; const float* img_shapes; const float* scale_factors;
   float* dets; long long* det_labels; int* det_count;
   // workspace
-  float* keys; int* sel; int* selcnt; float* cbox; float* cscore; int* clabel; int* ccount;
+  float* keys; int* sel; int* selcnt; float* cbox; float* cscore; int* clabel; int* ccount; float* pairscore;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -45,10 +45,47 @@ __global__ void det_key_kernel(const DetK p) {
   p.keys[m] = best;
 }
 
+// Block-wide radix select over non-negative floats (bit pattern is monotonic): returns the bit pattern
+// of the k-th largest value and how many elements equal to it belong to the top k.  11 + 11 + 10 bits.
+__device__ void radix_select_block(const float* keys, int P, int k, unsigned* hist /*2048*/, unsigned* s_tmp /*2*/,
+                                   unsigned& prefix_out, unsigned& need_out) {
+  unsigned prefix = 0, mask = 0, need = (unsigned)k;
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << bits[pass];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+      const float f = keys[i];
+      const unsigned u = f > 0.f ? __float_as_uint(f) : 0u;
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned acc = 0;
+      int b = nb - 1;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= need) break;
+        acc += hist[b];
+      }
+      s_tmp[0] = prefix | ((unsigned)b << shifts[pass]);
+      s_tmp[1] = need - acc;
+    }
+    __syncthreads();
+    prefix = s_tmp[0];
+    need = s_tmp[1];
+    mask |= ((unsigned)(nb - 1)) << shifts[pass];
+    __syncthreads();
+  }
+  prefix_out = prefix;
+  need_out = need;
+}
+
 // one block per (image, level): indices of the top nms_pre keys (all of them when the level is smaller)
 __global__ __launch_bounds__(1024) void det_select_kernel(const DetK p) {
   __shared__ unsigned hist[2048];
-  __shared__ unsigned s_prefix, s_need, s_cnt, s_tie;
+  __shared__ unsigned s_tmp[2], s_cnt, s_tie;
   const int lvl = blockIdx.x, img = blockIdx.y;
   const int P = p.h[lvl] * p.w[lvl];
   const int base = p.mstart[lvl] + img * P;
@@ -60,44 +97,16 @@ __global__ __launch_bounds__(1024) void det_select_kernel(const DetK p) {
     if (threadIdx.x == 0) *cnt = P;
     return;
   }
-  // radix select (keys are non-negative floats: bit pattern is monotonic), 11 + 11 + 10 bits
-  unsigned prefix = 0, mask = 0;
-  unsigned need = k;
-  const int shifts[3] = {21, 10, 0};
-  const int bits[3] = {11, 11, 10};
-  for (int pass = 0; pass < 3; ++pass) {
-    const int nb = 1 << bits[pass];
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-      const unsigned u = __float_as_uint(p.keys[base + i]);
-      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & (nb - 1)], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned acc = 0;
-      int b = nb - 1;
-      for (; b > 0; --b) {
-        if (acc + hist[b] >= need) break;
-        acc += hist[b];
-      }
-      s_prefix = prefix | ((unsigned)b << shifts[pass]);
-      s_need = need - acc;
-    }
-    __syncthreads();
-    prefix = s_prefix;
-    need = s_need;
-    mask |= ((unsigned)(nb - 1)) << shifts[pass];
-    __syncthreads();
-  }
-  // prefix = bit pattern of the k-th largest key; `need` = how many ties at that value to take
+  unsigned prefix, need;
+  radix_select_block(p.keys + base, P, k, hist, s_tmp, prefix, need);
   if (threadIdx.x == 0) {
     s_cnt = 0;
     s_tie = 0;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    const unsigned u = __float_as_uint(p.keys[base + i]);
+    const float f = p.keys[base + i];
+    const unsigned u = f > 0.f ? __float_as_uint(f) : 0u;
     if (u > prefix) {
       sel[atomicAdd(&s_cnt, 1u)] = i;
     } else if (u == prefix) {
@@ -109,43 +118,86 @@ __global__ __launch_bounds__(1024) void det_select_kernel(const DetK p) {
   if (threadIdx.x == 0) *cnt = (int)s_cnt;
 }
 
-// one thread per (image, level, selected slot, class): emit candidates with score > score_thr
-__global__ void det_candidates_kernel(const DetK p) {
+// dense final scores of every (selected location, class) pair: score*centerness if score > score_thr
+// (bbox_nms.py:54: validity is tested BEFORE the centerness factor), else -1
+__global__ void det_pairscore_kernel(const DetK p) {
   const int img = blockIdx.z, lvl = blockIdx.y;
   const int nsel = p.selcnt[img * p.nlvl + lvl];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.nms_pre * p.num_classes) return;
   const int slot = t / p.num_classes, c = t - slot * p.num_classes;
-  if (slot >= nsel) return;
-  const int P = p.h[lvl] * p.w[lvl];
-  const int loc = p.sel[((long long)img * p.nlvl + lvl) * p.nms_pre + slot];
-  const int m = p.mstart[lvl] + img * P + loc;
-  const float score = sigmoidf_(p.cls[(long long)m * p.ld_cls + c]);
-  if (!(score > p.score_thr)) return;                    // bbox_nms.py:54: valid BEFORE the centerness factor
-  const float* rc = p.rc + (long long)m * p.ld_rc;
-  const float ctr = sigmoidf_(rc[4]);
-  const int s = p.stride[lvl];
-  const int y = loc / p.w[lvl], x = loc - y * p.w[lvl];
-  const float px = (float)x * (float)s + (float)(s / 2), py = (float)y * (float)s + (float)(s / 2);
-  const float sc = p.scales[lvl];
-  float d[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) d[e] = fmaxf(rc[e] * sc, 0.f) * (float)s;      // fcos_head.py:159-165 (eval)
-  const float H = p.img_shapes[2 * img], W = p.img_shapes[2 * img + 1];
-  float b[4] = {px - d[0], py - d[1], px + d[2], py + d[3]};
-  b[0] = fminf(fmaxf(b[0], 0.f), W);                    // distance2bbox clip (transforms.py:150-160)
-  b[1] = fminf(fmaxf(b[1], 0.f), H);
-  b[2] = fminf(fmaxf(b[2], 0.f), W);
-  b[3] = fminf(fmaxf(b[3], 0.f), H);
-  if (p.scale_factors) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b[e] = b[e] / p.scale_factors[4 * img + e];
+  float out = -1.f;
+  if (slot < nsel) {
+    const int P = p.h[lvl] * p.w[lvl];
+    const int loc = p.sel[((long long)img * p.nlvl + lvl) * p.nms_pre + slot];
+    const int m = p.mstart[lvl] + img * P + loc;
+    const float score = sigmoidf_(p.cls[(long long)m * p.ld_cls + c]);
+    if (score > p.score_thr) out = score * sigmoidf_(p.rc[(long long)m * p.ld_rc + 4]);
   }
-  const int slot_out = atomicAdd(p.ccount + img, 1);
-  if (slot_out >= CAND_CAP) return;
-  float* cb = p.cbox + ((long long)img * CAND_CAP + slot_out) * 4;
-  cb[0] = b[0]; cb[1] = b[1]; cb[2] = b[2]; cb[3] = b[3];
-  p.cscore[(long long)img * CAND_CAP + slot_out] = score * ctr;
-  p.clabel[(long long)img * CAND_CAP + slot_out] = c;
+  p.pairscore[((long long)img * p.nlvl + lvl) * p.nms_pre * p.num_classes + t] = out;
+}
+
+// one block per image: keep the CAND_CAP best pairs (all of them when fewer are valid), decode their boxes
+__global__ __launch_bounds__(1024) void det_compact_kernel(const DetK p) {
+  __shared__ unsigned hist[2048];
+  __shared__ unsigned s_tmp[2], s_cnt, s_tie, s_valid;
+  const int img = blockIdx.x;
+  const int per_img = p.nlvl * p.nms_pre * p.num_classes;
+  const float* ps = p.pairscore + (long long)img * per_img;
+  if (threadIdx.x == 0) {
+    s_valid = 0;
+    s_cnt = 0;
+    s_tie = 0;
+  }
+  __syncthreads();
+  unsigned local = 0;
+  for (int i = threadIdx.x; i < per_img; i += blockDim.x) local += ps[i] > 0.f ? 1u : 0u;
+  atomicAdd(&s_valid, local);
+  __syncthreads();
+  const unsigned nvalid = s_valid;
+  unsigned prefix = 0, need = 0;
+  const bool all = nvalid <= (unsigned)CAND_CAP;
+  if (!all) radix_select_block(ps, per_img, CAND_CAP, hist, s_tmp, prefix, need);
+  for (int i = threadIdx.x; i < per_img; i += blockDim.x) {
+    const float f = ps[i];
+    if (!(f > 0.f)) continue;
+    const unsigned u = __float_as_uint(f);
+    bool take = all || u > prefix;
+    if (!take && u == prefix) take = atomicAdd(&s_tie, 1u) < need;
+    if (!take) continue;
+    const int out = (int)atomicAdd(&s_cnt, 1u);
+    if (out >= CAND_CAP) continue;
+    const int c = i % p.num_classes;
+    const int slot = (i / p.num_classes) % p.nms_pre;
+    const int lvl = i / (p.num_classes * p.nms_pre);
+    const int P = p.h[lvl] * p.w[lvl];
+    const int loc = p.sel[((long long)img * p.nlvl + lvl) * p.nms_pre + slot];
+    const int m = p.mstart[lvl] + img * P + loc;
+    const float* rc = p.rc + (long long)m * p.ld_rc;
+    const int s = p.stride[lvl];
+    const int y = loc / p.w[lvl], x = loc - y * p.w[lvl];
+    const float px = (float)x * (float)s + (float)(s / 2), py = (float)y * (float)s + (float)(s / 2);
+    const float sc = p.scales[lvl];
+    float d[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = fmaxf(rc[e] * sc, 0.f) * (float)s;      // fcos_head.py:159-165 (eval)
+    const float H = p.img_shapes[2 * img], W = p.img_shapes[2 * img + 1];
+    float b[4] = {px - d[0], py - d[1], px + d[2], py + d[3]};
+    b[0] = fminf(fmaxf(b[0], 0.f), W);                    // distance2bbox clip (transforms.py:150-160)
+    b[1] = fminf(fmaxf(b[1], 0.f), H);
+    b[2] = fminf(fmaxf(b[2], 0.f), W);
+    b[3] = fminf(fmaxf(b[3], 0.f), H);
+    if (p.scale_factors) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[e] = b[e] / p.scale_factors[4 * img + e];
+    }
+    float* cb = p.cbox + ((long long)img * CAND_CAP + out) * 4;
+    cb[0] = b[0]; cb[1] = b[1]; cb[2] = b[2]; cb[3] = b[3];
+    p.cscore[(long long)img * CAND_CAP + out] = f;
+    p.clabel[(long long)img * CAND_CAP + out] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) p.ccount[img] = min((int)s_cnt, CAND_CAP);
 }
 
 __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr) {
@@ -244,6 +296,7 @@ size_t ws_layout(const dsl_det_desc* d, size_t off[8]) {
   off[4] = take((size_t)d->n * CAND_CAP * 4);                     // cscore
   off[5] = take((size_t)d->n * CAND_CAP * 4);                     // clabel
   off[6] = take((size_t)d->n * 4);                                // ccount
+  off[7] = take((size_t)d->n * d->nlvl * d->nms_pre * d->num_classes * 4);   // pairscore
   return o;
 }
 
@@ -283,13 +336,15 @@ extern "C" int dsl_fcos_detect(const dsl_det_desc* d, void* stream) {
   k.keys = (float*)(ws + off[0]); k.sel = (int*)(ws + off[1]); k.selcnt = (int*)(ws + off[2]);
   k.cbox = (float*)(ws + off[3]); k.cscore = (float*)(ws + off[4]); k.clabel = (int*)(ws + off[5]);
   k.ccount = (int*)(ws + off[6]);
+  k.pairscore = (float*)(ws + off[7]);
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(k.ccount, 0, sizeof(int) * d->n, st);
   hipMemsetAsync(d->dets, 0, sizeof(float) * 5 * d->n * d->max_per_img, st);
   hipLaunchKernelGGL(det_key_kernel, dim3((m + 255) / 256), dim3(256), 0, st, k);
   hipLaunchKernelGGL(det_select_kernel, dim3(d->nlvl, d->n), dim3(1024), 0, st, k);
-  const int per_lvl = min(maxP, d->nms_pre) * d->num_classes;
-  hipLaunchKernelGGL(det_candidates_kernel, dim3((per_lvl + 255) / 256, d->nlvl, d->n), dim3(256), 0, st, k);
+  const int per_lvl = d->nms_pre * d->num_classes;
+  hipLaunchKernelGGL(det_pairscore_kernel, dim3((per_lvl + 255) / 256, d->nlvl, d->n), dim3(256), 0, st, k);
+  hipLaunchKernelGGL(det_compact_kernel, dim3(d->n), dim3(1024), 0, st, k);
   const size_t lds = (size_t)CAND_CAP * 8 + (size_t)d->max_per_img * 16;
   static bool attr = false;
   if (!attr) {
