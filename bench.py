@@ -161,14 +161,17 @@ def main():
         L.lib.dsl_prof_read(launches, ms, fl)
         if launches[0]:
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel='conv_gemm_kernel<128,false> (forward + data-gradient implicit GEMM)',
+            roof = dict(bound='mfma', kernel='conv_glds_kernel<256,192,4,2,2> (forward + data-gradient implicit GEMM, 256x192 tile)',
                         achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         traffic=None, launches_per_step=launches[0] // args.steps,
                         avg_launch_us=round(ms[0] * 1e3 / launches[0], 2),
                         algorithmic_gflop_per_launch=round(fl[0] / launches[0] / 1e9, 3),
-                        wgrad_kernel=dict(achieved=round(fl[2] / (ms[2] * 1e-3) / 1e12, 1) if launches[2] else None,
-                                          avg_launch_us=round(ms[2] * 1e3 / max(launches[2], 1), 2),
-                                          launches_per_step=launches[2] // args.steps),
+                        other_conv_kernels=dict(achieved=round(fl[1] / (ms[1] * 1e-3) / 1e12, 1) if launches[1] else None,
+                                                avg_launch_us=round(ms[1] * 1e3 / max(launches[1], 1), 2),
+                                                launches_per_step=launches[1] // args.steps),
+                        wgrad_kernels=dict(achieved=round(fl[2] / (ms[2] * 1e-3) / 1e12, 1) if launches[2] else None,
+                                           avg_launch_us=round(ms[2] * 1e3 / max(launches[2], 1), 2),
+                                           launches_per_step=launches[2] // args.steps),
                         whole_step_frac=round(value / world * GFLOP_PER_IMAGE_STEP / 1e3 / PEAK_BF16_TFLOPS, 4))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

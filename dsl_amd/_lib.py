@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
                 ('mode', C.c_int32), ('os', C.c_int32), ('flags', C.c_int32),
                 ('src', C.c_void_p), ('wgt', C.c_void_p), ('dst', C.c_void_p),
-                ('scale', C.c_void_p), ('bias', C.c_void_p), ('addend', C.c_void_p), ('mask', C.c_void_p)]
+                ('scale', C.c_void_p), ('bias', C.c_void_p), ('addend', C.c_void_p), ('mask', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
 class WgradDesc(C.Structure):
@@ -88,11 +89,12 @@ class Op(C.Structure):
 
 lib.dsl_last_error.restype = C.c_char_p
 lib.dsl_wgrad_workspace_bytes.restype = C.c_size_t
+lib.dsl_conv2d_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_detect_workspace_bytes'):
     lib.dsl_detect_workspace_bytes.restype = C.c_size_t
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
-    'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
+    'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_workspace_bytes': [_vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
     'dsl_wgrad_workspace_bytes': [_vp],
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
     'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp],

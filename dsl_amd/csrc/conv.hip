@@ -10,6 +10,8 @@
 // the v_mfma_f32_32x32x16_bf16 result each lane owns ONE pixel and 4-channel runs of couts
 // -> the epilogue does per-pixel index math once per lane and 8/16-byte channel-contiguous
 // stores into NHWC.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -25,6 +27,8 @@ struct ConvK {
   long long soff[DSL_MAX_SEG], doff[DSL_MAX_SEG], aoff[DSL_MAX_SEG];   // segment starts, in pixels
   int cs, cd, ldd, lda, ldm, kh, kw, stride, pad, mode, os, flags;
   int ktiles, kc;
+  int splits, kt_per_split, cd_pad;   // split-K over K tiles (v2 kernel): fp32 partials -> ws, then conv_splitk_epilogue_kernel
+  float* ws;
   long long wrow;
   const uint16_t* src;
   const uint16_t* wgt;
@@ -62,6 +66,109 @@ __device__ __forceinline__ void decode_pixel(const ConvK& p, int gp, int& seg, i
   const int rem = q - img * hw;
   y = rem / p.gw[seg];
   x = rem - y * p.gw[seg];
+}
+
+
+// Epilogue for 4 consecutive output channels of one pixel (shared by every conv kernel).
+__device__ __forceinline__ void conv_epilogue4(const ConvK& p, long long dpix, long long apix, int co, float v[4]) {
+  const bool out_f32 = (p.flags & DSL_CONV_OUT_F32) != 0;
+  const bool relu_out = (p.flags & DSL_CONV_RELU_OUT) != 0;
+  const bool mask_first = (p.flags & DSL_CONV_MASK_FIRST) != 0 && p.mask != nullptr;
+  const bool mask_last = (p.flags & DSL_CONV_MASK_LAST) != 0 && p.mask != nullptr;
+  const bool has_mask = mask_first || mask_last;
+  if (co + 3 < p.cd) {
+    if (p.scale) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.scale + co);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= s4[e];
+    }
+    if (p.bias) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += b4[e];
+    }
+    float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (has_mask) {
+      const u32x2 mm = *reinterpret_cast<const u32x2*>(p.mask + dpix * p.ldm + co);
+      m[0] = bflo(mm[0]) > 0.f ? 1.f : 0.f;
+      m[1] = bfhi(mm[0]) > 0.f ? 1.f : 0.f;
+      m[2] = bflo(mm[1]) > 0.f ? 1.f : 0.f;
+      m[3] = bfhi(mm[1]) > 0.f ? 1.f : 0.f;
+    }
+    if (mask_first) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= m[e];
+    }
+    if (p.addend) {
+      const u32x2 aa = *reinterpret_cast<const u32x2*>(p.addend + apix * p.lda + co);
+      v[0] += bflo(aa[0]);
+      v[1] += bfhi(aa[0]);
+      v[2] += bflo(aa[1]);
+      v[3] += bfhi(aa[1]);
+    }
+    if (mask_last) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= m[e];
+    }
+    if (relu_out) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (out_f32) {
+      f32x4 o = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dst) + dpix * p.ldd + co) = o;
+    } else {
+      u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.dst) + dpix * p.ldd + co) = o;
+    }
+  } else {   // ragged channel tail (e.g. conv_reg+centerness = 5 channels): element-wise
+    for (int e = 0; e < 4 && co + e < p.cd; ++e) {
+      float t = v[e];
+      if (p.scale) t *= p.scale[co + e];
+      if (p.bias) t += p.bias[co + e];
+      float mk = 1.f;
+      if (has_mask) mk = bf2f(p.mask[dpix * p.ldm + co + e]) > 0.f ? 1.f : 0.f;
+      if (mask_first) t *= mk;
+      if (p.addend) t += bf2f(p.addend[apix * p.lda + co + e]);
+      if (mask_last) t *= mk;
+      if (relu_out) t = fmaxf(t, 0.f);
+      if (out_f32)
+        reinterpret_cast<float*>(p.dst)[dpix * p.ldd + co + e] = t;
+      else
+        reinterpret_cast<uint16_t*>(p.dst)[dpix * p.ldd + co + e] = f2bf(t);
+    }
+  }
+}
+
+__device__ __forceinline__ void conv_out_index(const ConvK& p, int gp, long long& dpix, long long& apix) {
+  int seg, img, y, x;
+  decode_pixel(p, gp, seg, img, y, x);
+  const int oy = y * p.os, ox = x * p.os;
+  dpix = p.doff[seg] + ((long long)img * p.dh[seg] + oy) * p.dw[seg] + ox;
+  apix = dpix;
+  if (p.flags & DSL_CONV_ADD_UPSAMPLE) {
+    const int ay = (oy * p.ah[seg]) / p.dh[seg], ax = (ox * p.aw[seg]) / p.dw[seg];
+    apix = p.aoff[seg] + ((long long)img * p.ah[seg] + ay) * p.aw[seg] + ax;
+  }
+}
+
+// split-K second pass: sum the fp32 partial tiles and run the epilogue
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvK p) {
+  const int totpx = p.pxstart[p.nseg];
+  const int c4 = p.cd_pad / 4;
+  const long long total = (long long)totpx * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int gp = (int)(i / c4);
+    const int co = (int)(i - (long long)gp * c4) * 4;
+    if (co >= p.cd) continue;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < p.splits; ++sp)
+      s += *reinterpret_cast<const f32x4*>(p.ws + ((long long)sp * totpx + gp) * p.cd_pad + co);
+    long long dpix, apix;
+    conv_out_index(p, gp, dpix, apix);
+    float v[4] = {s[0], s[1], s[2], s[3]};
+    conv_epilogue4(p, dpix, apix, co, v);
+  }
 }
 
 template <int BCO, bool SMALLC>
@@ -212,24 +319,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
   }
 
   // ---- epilogue ----
-  const bool out_f32 = (p.flags & DSL_CONV_OUT_F32) != 0;
-  const bool relu_out = (p.flags & DSL_CONV_RELU_OUT) != 0;
-  const bool mask_first = (p.flags & DSL_CONV_MASK_FIRST) != 0 && p.mask != nullptr;
-  const bool mask_last = (p.flags & DSL_CONV_MASK_LAST) != 0 && p.mask != nullptr;
-  const bool has_mask = mask_first || mask_last;
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt) {
     const int gp = px0 + wave_px * 64 + pt * 32 + frow;
     if (gp >= totpx) continue;
-    int seg, img, y, x;
-    decode_pixel(p, gp, seg, img, y, x);
-    const int oy = y * p.os, ox = x * p.os;
-    const long long dpix = p.doff[seg] + ((long long)img * p.dh[seg] + oy) * p.dw[seg] + ox;
-    long long apix = dpix;
-    if (p.flags & DSL_CONV_ADD_UPSAMPLE) {
-      const int ay = (oy * p.ah[seg]) / p.dh[seg], ax = (ox * p.aw[seg]) / p.dw[seg];
-      apix = p.aoff[seg] + ((long long)img * p.ah[seg] + ay) * p.aw[seg] + ax;
-    }
+    long long dpix, apix;
+    conv_out_index(p, gp, dpix, apix);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -239,69 +334,192 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[ct][pt][4 * g + e];
-        const bool full = co + 3 < p.cd;
-        if (full) {
-          if (p.scale) {
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.scale + co);
+        conv_epilogue4(p, dpix, apix, co, v);
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// v2 forward / data-gradient kernel: bigger tiles, 8 waves, operands DMA'd straight into LDS
+// (global_load_lds_dwordx4, 1 KB per wave-instruction = 8 rows x 128 B), the XOR swizzle applied through
+// the per-lane SOURCE address (the LDS image of a DMA is lane-linear), out-of-image taps read a zero line.
+// One barrier per K tile; the next tile's DMA is in flight while the current one feeds the MFMAs.
+// ================================================================================================
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __attribute__((aligned(16))) unsigned int g_zero_line[4] = {0u, 0u, 0u, 0u};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BCO, int BPX, int WCO, int WPX, int NST>
+__global__ __launch_bounds__(64 * WCO * WPX) void conv_glds_kernel(const ConvK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int T = 64 * WCO * WPX;
+  constexpr int RPP = T / 8;                 // tile rows filled per pass (8 lanes per 128-byte row)
+  constexpr int WPASS = BCO / RPP, XPASS = BPX / RPP;
+  constexpr int TILE_W = BCO * 128;
+  constexpr int STAGE = (BCO + BPX) * 128;
+  constexpr int PT = BPX / WPX / 32;         // 32-pixel MFMA tiles per wave
+  static_assert(BCO / WCO == 64, "each wave owns 64 couts");
+  static_assert(BCO % RPP == 0 && BPX % RPP == 0 && (BPX / WPX) % 32 == 0, "tile/thread mismatch");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_co = wave / WPX, wave_px = wave % WPX;
+  const int co0 = blockIdx.x * BCO;
+  const int px0 = blockIdx.y * BPX;
+  const int totpx = p.pxstart[p.nseg];
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ ((tid >> 4) & 7);     // source chunk that belongs in LDS slot (tid & 7) of this row
+
+  int r_base[XPASS], r_yx[XPASS], r_hw[XPASS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= s4[e];
-          }
-          if (p.bias) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+  for (int i = 0; i < XPASS; ++i) {
+    const int gp = px0 + lrow + RPP * i;
+    int seg = 0, img = 0, y = 0, x = 0;
+    const bool ok = gp < totpx;
+    if (ok) decode_pixel(p, gp, seg, img, y, x);
+    r_hw[i] = (p.sh[seg] << 16) | p.sw[seg];
+    r_base[i] = (int)(p.soff[seg] + (long long)img * p.sh[seg] * p.sw[seg]);
+    r_yx[i] = ok ? ((y << 16) | x) : -1;
+  }
+  const uint16_t* wbase = p.wgt + (long long)(co0 + lrow) * p.wrow + chunk * 8;
+  const gptr_t zero = (gptr_t)g_zero_line;
+
+  const int kt0 = blockIdx.z * p.kt_per_split;
+  const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+  int cidx = kt0 % p.kc;
+  int tap_r = (kt0 / p.kc) / p.kw, tap_s = (kt0 / p.kc) % p.kw;
+  auto gload = [&](int kt, int buf) {
+    unsigned char* stage = smem + buf * STAGE;
+    const int coff = cidx * 64 + chunk * 8;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += b4[e];
-          }
-          float m[4] = {1.f, 1.f, 1.f, 1.f};
-          if (has_mask) {
-            const u32x2 mm = *reinterpret_cast<const u32x2*>(p.mask + dpix * p.ldm + co);
-            m[0] = bflo(mm[0]) > 0.f ? 1.f : 0.f;
-            m[1] = bfhi(mm[0]) > 0.f ? 1.f : 0.f;
-            m[2] = bflo(mm[1]) > 0.f ? 1.f : 0.f;
-            m[3] = bfhi(mm[1]) > 0.f ? 1.f : 0.f;
-          }
-          if (mask_first) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= m[e];
-          }
-          if (p.addend) {
-            const u32x2 aa = *reinterpret_cast<const u32x2*>(p.addend + apix * p.lda + co);
-            v[0] += bflo(aa[0]);
-            v[1] += bfhi(aa[0]);
-            v[2] += bflo(aa[1]);
-            v[3] += bfhi(aa[1]);
-          }
-          if (mask_last) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= m[e];
-          }
-          if (relu_out) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (out_f32) {
-            f32x4 o = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dst) + dpix * p.ldd + co) = o;
-          } else {
-            u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.dst) + dpix * p.ldd + co) = o;
-          }
-        } else {   // ragged channel tail (e.g. conv_reg+centerness = 5 channels): element-wise
-          for (int e = 0; e < 4 && co + e < p.cd; ++e) {
-            float t = v[e];
-            if (p.scale) t *= p.scale[co + e];
-            if (p.bias) t += p.bias[co + e];
-            float mk = 1.f;
-            if (has_mask) mk = bf2f(p.mask[dpix * p.ldm + co + e]) > 0.f ? 1.f : 0.f;
-            if (mask_first) t *= mk;
-            if (p.addend) t += bf2f(p.addend[apix * p.lda + co + e]);
-            if (mask_last) t *= mk;
-            if (relu_out) t = fmaxf(t, 0.f);
-            if (out_f32)
-              reinterpret_cast<float*>(p.dst)[dpix * p.ldd + co + e] = t;
-            else
-              reinterpret_cast<uint16_t*>(p.dst)[dpix * p.ldd + co + e] = f2bf(t);
-          }
+    for (int i = 0; i < XPASS; ++i) {
+      const int y = r_yx[i] >> 16, x = r_yx[i] & 0xffff;
+      const int sh = r_hw[i] >> 16, sw = r_hw[i] & 0xffff;
+      int sy, sx;
+      bool ok = r_yx[i] >= 0;
+      if (p.mode == 0) {
+        sy = y * p.stride + tap_r - p.pad;
+        sx = x * p.stride + tap_s - p.pad;
+      } else {
+        const int ty = y + p.pad - tap_r, tx = x + p.pad - tap_s;
+        if (p.stride == 1) {
+          sy = ty;
+          sx = tx;
+        } else {
+          ok = ok && ty >= 0 && tx >= 0 && (ty % p.stride) == 0 && (tx % p.stride) == 0;
+          sy = ty / p.stride;
+          sx = tx / p.stride;
         }
+      }
+      ok = ok && (unsigned)sy < (unsigned)sh && (unsigned)sx < (unsigned)sw;
+      const long long off = ((long long)(r_base[i] + sy * sw + sx)) * p.cs + coff;
+      const gptr_t g = ok ? (gptr_t)(p.src + off) : zero;
+      __builtin_amdgcn_global_load_lds(g, (lptr_t)(stage + TILE_W + (i * RPP + wave * 8) * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WPASS; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (long long)(RPP * i) * p.wrow + (long long)kt * BK),
+                                       (lptr_t)(stage + (i * RPP + wave * 8) * 128), 16, 0, 0);
+    if (++cidx == p.kc) {
+      cidx = 0;
+      if (++tap_s == p.kw) {
+        tap_s = 0;
+        ++tap_r;
+      }
+    }
+  };
+
+  f32x16 acc[2][PT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int fswz = (frow >> 1) & 7;
+  auto compute = [&](int buf) {
+    const unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
+      bf16x8 a[2], b[PT];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        a[ct] = *reinterpret_cast<const bf16x8*>(base + (wave_co * 64 + ct * 32 + frow) * 128 + coff);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        b[pt] = *reinterpret_cast<const bf16x8*>(base + TILE_W + (wave_px * (32 * PT) + pt * 32 + frow) * 128 + coff);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b[pt], acc[ct][pt], 0, 0, 0);
+    }
+  };
+
+  // NST-stage ring: tiles kt+1 .. kt+NST-1 are in flight while tile kt feeds the MFMAs.  Each thread issues
+  // LPT DMA instructions per tile, so "tile kt has landed" == at most (tiles still allowed in flight) * LPT
+  // outstanding (counted s_waitcnt, raw s_barrier: __syncthreads() would drain the whole queue).
+  constexpr int LPT = WPASS + XPASS;
+  static_assert((NST - 2) * LPT <= 63, "vmcnt range");
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (kt0 + s < kt1) gload(kt0 + s, s);
+  int slot = 0;                      // ring slot of tile kt
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int ahead = min(kt1 - 1 - kt, NST - 2);     // tiles after kt that may stay in flight
+    if (NST >= 4 && ahead >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LPT>();
+    else if (NST >= 3 && ahead >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();          // everyone's DMA for tile kt landed; compute(kt-1) finished everywhere
+    if (kt + NST - 1 < kt1) gload(kt + NST - 1, slot == 0 ? NST - 1 : slot - 1);
+    compute(slot);
+    slot = (slot + 1 == NST) ? 0 : slot + 1;
+  }
+
+  if (p.splits > 1) {                      // split-K: raw fp32 partial tile -> workspace [split][pixel][cd_pad]
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int gp = px0 + wave_px * (32 * PT) + pt * 32 + (lane & 31);
+      if (gp >= totpx) continue;
+      float* row = p.ws + ((long long)blockIdx.z * totpx + gp) * p.cd_pad;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = co0 + wave_co * 64 + ct * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(row + co) = o;
+        }
+    }
+    return;
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int gp = px0 + wave_px * (32 * PT) + pt * 32 + frow;
+    if (gp >= totpx) continue;
+    long long dpix, apix;
+    conv_out_index(p, gp, dpix, apix);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + wave_co * 64 + ct * 32 + 8 * g + 4 * fhalf;
+        if (co >= p.cd) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[ct][pt][4 * g + e];
+        conv_epilogue4(p, dpix, apix, co, v);
       }
     }
   }
@@ -318,6 +536,8 @@ struct WgK {
   FastDiv dhw[DSL_MAX_SEG], dwd[DSL_MAX_SEG];
   int cs, cy, kh, kw, stride, pad;
   int ktiles, tiles_per_split, ctiles_per_tap;
+  int dbg;                  // ablation knobs (DSL_ABLATE env): 1 = skip DMA after the first tile, 2 = skip MFMA
+  int gx, gy, splits;       // v2: workgroup grid (cout tiles, column tiles) and split count for the XCD-aware 1-D launch
   long long krow;
   const uint16_t* dy;
   const uint16_t* x;
@@ -488,6 +708,260 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
     }
 }
 
+// inline-asm helpers must be explicit __device__ functions: a lambda inside a kernel is implicitly
+// __host__ __device__, and its AMDGPU asm constraints break the (silently dropped) host instantiation
+__device__ __forceinline__ u32x2 lds_tr_read_b64(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+struct Frag {
+  u32x2 lo, hi;
+};
+// Wait for the outstanding transpose reads AND tell the compiler the fragment registers change here
+// ("+v"): otherwise it may copy an asm-loaded register before the data has landed (the destination of an
+// inline-asm load counts as written when the statement ends, not when the LDS returns).
+template <int CT, int IT>
+__device__ __forceinline__ void wait_frags(Frag (&fa)[CT], Frag (&fb)[IT]) {
+  static_assert(IT == 2 && (CT == 2 || CT == 4), "fragment shapes used by the wgrad tiles");
+  if constexpr (CT == 4) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fa[0].lo), "+v"(fa[0].hi), "+v"(fa[1].lo), "+v"(fa[1].hi), "+v"(fa[2].lo), "+v"(fa[2].hi),
+                   "+v"(fa[3].lo), "+v"(fa[3].hi), "+v"(fb[0].lo), "+v"(fb[0].hi), "+v"(fb[1].lo), "+v"(fb[1].hi)
+                 :
+                 : "memory");
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fa[0].lo), "+v"(fa[0].hi), "+v"(fa[1].lo), "+v"(fa[1].hi), "+v"(fb[0].lo), "+v"(fb[0].hi),
+                   "+v"(fb[1].lo), "+v"(fb[1].hi)
+                 :
+                 : "memory");
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// v2 weight gradient: DMA-to-LDS operands, 256-wide tiles, 8 waves.  Same math/outputs as wgrad_kernel.
+template <int BCO, int BCI, int WCO, int WCI>
+__global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NW = WCO * WCI;
+  constexpr int YB = BCO * 2, XB = BCI * 2;          // bytes per pixel row of each tile
+  constexpr int TILE_Y = 64 * YB, TILE_X = 64 * XB, STAGE = TILE_Y + TILE_X;
+  constexpr int NY = TILE_Y / 1024, NX = TILE_X / 1024;      // 1 KB DMA instructions per tile
+  constexpr int LY = NY / NW, LX = NX / NW;                   // per wave
+  constexpr int CT = BCO / WCO / 32, IT = BCI / WCI / 32;
+  static_assert(NY % NW == 0 && NX % NW == 0, "tile / wave mismatch");
+  static_assert(YB >= 256 && XB >= 256, "64-byte-chunk swizzle needs >= 4 chunks per row");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_co = wave / WCI, wave_ci = wave % WCI;
+  // XCD-aware work mapping (block b runs on XCD b % 8): all (cout tile, tap, cin tile) workgroups of one
+  // pixel split share an XCD, so its dY / X pixel range is fetched into that XCD's L2 once instead of once
+  // per tap.  Placement only affects speed.
+  const int tiles_per_split_wg = p.gx * p.gy;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int sp = xcd + 8 * (jj / tiles_per_split_wg);
+  if (sp >= p.splits) return;
+  const int rem_wg = jj % tiles_per_split_wg;
+  const int co0 = (rem_wg % p.gx) * BCO;
+  const int colt = rem_wg / p.gx;
+  const int ctiles = p.cs / BCI;
+  const int tap = colt / ctiles;
+  const int ci0 = (colt - tap * ctiles) * BCI;
+  const int tr = tap / p.kw, ts = tap - tr * p.kw;
+  const int kt0 = sp * p.tiles_per_split;
+  const int kt1 = min(kt0 + p.tiles_per_split, p.ktiles);
+  const int totpx = p.pxstart[p.nseg];
+  const gptr_t zero = (gptr_t)g_zero_line;
+
+  // Per-segment decode constants live in LDS (carved after the stages): indexing the kernel-argument
+  // arrays with a runtime segment id makes hipcc emit vector loads + s_waitcnt vmcnt(0) inside the K loop,
+  // which drains the DMA queue every step.
+  int* segtab = reinterpret_cast<int*>(smem + 2 * STAGE);     // [nseg][12]
+  if (tid < p.nseg) {
+    int* t = segtab + tid * 12;
+    t[0] = p.pxstart[tid];
+    t[1] = (int)(p.dhw[tid].m & 0xffffffffu); t[2] = (int)(p.dhw[tid].m >> 32); t[3] = (int)p.dhw[tid].d;
+    t[4] = (int)(p.dwd[tid].m & 0xffffffffu); t[5] = (int)(p.dwd[tid].m >> 32); t[6] = (int)p.dwd[tid].d;
+    t[7] = p.sh[tid]; t[8] = p.sw[tid];
+    t[9] = (int)(p.xoff[tid] & 0xffffffff); t[10] = (int)(p.xoff[tid] >> 32);
+  }
+  const int px1 = p.nseg > 1 ? p.pxstart[1] : 0x7fffffff, px2 = p.nseg > 2 ? p.pxstart[2] : 0x7fffffff;
+  const int px3 = p.nseg > 3 ? p.pxstart[3] : 0x7fffffff, px4 = p.nseg > 4 ? p.pxstart[4] : 0x7fffffff;
+  __syncthreads();
+
+  // per DMA instruction this lane's (row, source channel) inside the tile
+  int yrow[LY], ych[LY], xrow[LX], xch[LX];
+#pragma unroll
+  for (int i = 0; i < LY; ++i) {
+    const int off = (wave + NW * i) * 1024 + lane * 16;
+    const int row = off / YB, inrow = off % YB;
+    yrow[i] = row;
+    ych[i] = (((inrow >> 6) ^ (row & 3)) << 5) + ((inrow & 63) >> 1);      // bf16 element offset in the row
+  }
+#pragma unroll
+  for (int i = 0; i < LX; ++i) {
+    const int off = (wave + NW * i) * 1024 + lane * 16;
+    const int row = off / XB, inrow = off % XB;
+    xrow[i] = row;
+    xch[i] = (((inrow >> 6) ^ (row & 3)) << 5) + ((inrow & 63) >> 1);
+  }
+
+  f32x16 acc[CT][IT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < IT; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+  // Transpose reads are issued through inline asm: given the builtin (an addrspace(3) access) hipcc orders
+  // every ds_read behind the in-flight LDS-DMA with s_waitcnt vmcnt(0), which would serialise DMA and MFMA.
+  // The hazards are handled by hand: DMA data is read one barrier after its vmcnt(0); fragment registers are
+  // consumed only after an explicit lgkmcnt(0) + sched_barrier (the MFMA builtins are register-only).
+  const int g16 = lane >> 4, l16 = lane & 15;
+  const int iblk = (g16 & 1) * 16, kblk = (g16 >> 1) * 8;
+  const int krow_l = kblk + (l16 >> 2);
+  const int ccol_l = iblk + 4 * (l16 & 3);
+  const unsigned lds_base = (unsigned)(size_t)smem;      // low 32 bits of a flat LDS address = the LDS offset
+  // per-lane byte offsets (within a tile) of the fragment rows for kk = 0, hh = 0; other (kk, hh) add
+  // (kk*16 + hh*4) * rowbytes, and (krow & 3) is unchanged by multiples of 4 rows
+  unsigned a_off[CT], b_off[IT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int col = wave_co * (32 * CT) + ct * 32 + ccol_l;
+    a_off[ct] = krow_l * YB + ((((col * 2) >> 6) ^ (krow_l & 3)) << 6) + ((col * 2) & 63);
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int col = wave_ci * (32 * IT) + it * 32 + ccol_l;
+    b_off[it] = TILE_Y + krow_l * XB + ((((col * 2) >> 6) ^ (krow_l & 3)) << 6) + ((col * 2) & 63);
+  }
+  auto issue = [&](unsigned stage_addr, int kk, Frag (&fa)[CT], Frag (&fb)[IT]) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const unsigned ad = stage_addr + a_off[ct] + kk * 16 * YB;
+      fa[ct].lo = lds_tr_read_b64(ad);
+      fa[ct].hi = lds_tr_read_b64(ad + 4 * YB);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const unsigned ad = stage_addr + b_off[it] + kk * 16 * XB;
+      fb[it].lo = lds_tr_read_b64(ad);
+      fb[it].hi = lds_tr_read_b64(ad + 4 * XB);
+    }
+  };
+  auto mma = [&](Frag (&fa)[CT], Frag (&fb)[IT]) {
+    bf16x8 a[CT], b[IT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      union { struct { u32x2 l, h; } s; bf16x8 v; } u;
+      u.s.l = fa[ct].lo;
+      u.s.h = fa[ct].hi;
+      a[ct] = u.v;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      union { struct { u32x2 l, h; } s; bf16x8 v; } u;
+      u.s.l = fb[it].lo;
+      u.s.h = fb[it].hi;
+      b[it] = u.v;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int it = 0; it < IT; ++it)
+        acc[ct][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b[it], acc[ct][it], 0, 0, 0);
+  };
+  auto compute = [&](int buf) {
+    const unsigned st = lds_base + buf * STAGE;
+    Frag fa0[CT], fb0[IT], fa1[CT], fb1[IT];
+    issue(st, 0, fa0, fb0);
+    wait_frags<CT, IT>(fa0, fb0);
+    issue(st, 1, fa1, fb1);           // next fragments fly while the MFMAs of this step run
+    mma(fa0, fb0);
+    wait_frags<CT, IT>(fa1, fb1);
+    issue(st, 2, fa0, fb0);
+    mma(fa1, fb1);
+    wait_frags<CT, IT>(fa0, fb0);
+    issue(st, 3, fa1, fb1);
+    mma(fa0, fb0);
+    wait_frags<CT, IT>(fa1, fb1);
+    mma(fa1, fb1);
+  };
+
+  // one loop, DMA for tile kc+1 written inline (a second call site would need a lambda, and hipcc drops the
+  // host stub of this kernel when the DMA address code lives in a lambda)
+  for (int kc = kt0 - 1; kc < kt1; ++kc) {
+    if (kc >= kt0) {
+      // the DMA of tile kc must have landed before anyone reads it: with the LDS reads hidden in inline asm
+      // hipcc no longer emits vmcnt(0) for the barrier's fence on its own
+      wait_vmcnt<0>();
+      __syncthreads();                       // ... and compute(kc-1) is done everywhere
+    }
+    if (kc + 1 < kt1 && !((p.dbg & 1) && kc >= kt0)) {
+        const int kt = kc + 1, buf = (kt - kt0) & 1;
+        unsigned char* stage = smem + buf * STAGE;
+      // all address math (incl. the LDS table reads) first, while no DMA is outstanding; then the DMA burst
+      long long gx[LX];        // element offset into p.x, -1 = zero line
+  #pragma unroll
+      for (int i = 0; i < LX; ++i) {
+        const int gp = kt * 64 + xrow[i];
+        long long g = -1;
+        if (gp < totpx) {
+          const int seg = (gp >= px1) + (gp >= px2) + (gp >= px3) + (gp >= px4);
+          const int* t = segtab + seg * 12;
+          const uint32_t q = gp - t[0];
+          const uint64_t m1 = ((uint64_t)(uint32_t)t[2] << 32) | (uint32_t)t[1];
+          const uint64_t m2 = ((uint64_t)(uint32_t)t[5] << 32) | (uint32_t)t[4];
+          const uint32_t img = (uint32_t)(((uint64_t)q * m1) >> 40);
+          const uint32_t rem = q - img * (uint32_t)t[3];
+          const uint32_t y = (uint32_t)(((uint64_t)rem * m2) >> 40);
+          const uint32_t x = rem - y * (uint32_t)t[6];
+          const int sh = t[7], sw = t[8];
+          const int sy = (int)y * p.stride + tr - p.pad, sx = (int)x * p.stride + ts - p.pad;
+          if ((unsigned)sy < (unsigned)sh && (unsigned)sx < (unsigned)sw) {
+            const long long xoff = ((long long)t[10] << 32) | (uint32_t)t[9];
+            const long long pix = xoff + ((long long)img * sh + sy) * sw + sx;
+            g = pix * p.cs + ci0 + xch[i];
+          }
+        }
+        gx[i] = g;
+      }
+  #pragma unroll
+      for (int i = 0; i < LY; ++i) {
+        const int gp = kt * 64 + yrow[i];
+        const gptr_t g = gp < totpx ? (gptr_t)(p.dy + (long long)gp * p.cy + co0 + ych[i]) : zero;
+        __builtin_amdgcn_global_load_lds(g, (lptr_t)(stage + (wave + NW * i) * 1024), 16, 0, 0);
+      }
+  #pragma unroll
+      for (int i = 0; i < LX; ++i)
+      {
+        // keep the select in a named variable: passing the ?: expression straight into the builtin makes
+        // hipcc silently drop this kernel's host stub
+        const gptr_t g = gx[i] >= 0 ? (gptr_t)(p.x + gx[i]) : zero;
+        __builtin_amdgcn_global_load_lds(g, (lptr_t)(stage + TILE_Y + (wave + NW * i) * 1024), 16, 0, 0);
+      }
+    }
+    if (kc >= kt0 && !(p.dbg & 2)) compute((kc - kt0) & 1);
+  }
+  if (p.dbg & 4) return;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const long long col = (long long)tap * p.cs + ci0 + wave_ci * (32 * IT) + it * 32 + frow;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int co = co0 + wave_co * (32 * CT) + ct * 32 + (j & 3) + 8 * (j >> 2) + 4 * fhalf;
+        p.ws[((long long)sp * p.cy + co) * p.krow + col] = acc[ct][it][j];
+      }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                     const float* __restrict__ scale, int splits, int cy, int cd,
                                     long long krow) {
@@ -510,6 +984,66 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // ================================================================================================
 // host side
 // ================================================================================================
+namespace {
+// v2 (DMA-to-LDS) tile configurations {BCO, BPX, workgroups per CU, relative per-CU rate}
+struct TileCfg { int bco, bpx, occ, nst; double rate; };
+constexpr int kNumCfg = 5;
+const TileCfg kCfgs[kNumCfg] = {{256, 192, 1, 2, 1.00}, {256, 128, 1, 3, 0.90}, {128, 256, 1, 3, 0.90},
+                                {128, 128, 2, 2, 0.75}, {64, 256, 2, 2, 0.60}};
+
+// picks the tile configuration (-1 = v1 kernel) and the split-K factor for a conv
+void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out, int* splits_out) {
+  const bool smallc = (d->flags & DSL_CONV_SMALL_C) != 0;
+  const int force = (d->flags >> 8) & 15;          // test hook: 1..5 = v2 config, 15 = v1 kernel
+  const int force_split = (d->flags >> 12) & 15;   // test hook: split-K factor
+  int pick = -1, splits = 1;
+  const bool v1_only = smallc || (d->flags & DSL_CONV_RELU_IN);
+  if (!v1_only && force != 15) {
+    double best = 1e300;
+    for (int c = 0; c < kNumCfg; ++c) {
+      if (d->cd_pad % kCfgs[c].bco) continue;
+      if (force >= 1 && force <= kNumCfg && force - 1 != c) continue;
+      const long long wgs = (long long)(d->cd_pad / kCfgs[c].bco) * ((px + kCfgs[c].bpx - 1) / kCfgs[c].bpx);
+      const long long slots = 256LL * kCfgs[c].occ;
+      int sp = 1;
+      if (d->workspace && wgs * 2 <= slots && ktiles >= 16) {
+        sp = (int)((slots + wgs - 1) / wgs);
+        if (sp > ktiles / 4) sp = ktiles / 4;
+        if (sp > 16) sp = 16;
+        while (sp > 1 && (size_t)sp * px * d->cd_pad * 4 > d->workspace_bytes) --sp;
+        if (sp < 1) sp = 1;
+      }
+      const long long rounds = (wgs * sp + slots - 1) / slots;
+      double t = (double)rounds * kCfgs[c].occ * kCfgs[c].bco * kCfgs[c].bpx / kCfgs[c].rate / sp;
+      if (sp > 1) t += 0.02 * kCfgs[c].bco * kCfgs[c].bpx;      // second pass + launch
+      if (t < best) { best = t; pick = c; splits = sp; }
+    }
+    if (pick >= 0 && force_split > 1 && d->workspace && (size_t)force_split * px * d->cd_pad * 4 <= d->workspace_bytes &&
+        force_split <= ktiles)
+      splits = force_split;
+  }
+  *pick_out = pick;
+  *splits_out = splits;
+}
+
+long long conv_pixels(const dsl_conv_desc* d) {
+  long long px = 0;
+  for (int s = 0; s < d->nseg; ++s) px += (long long)d->n * d->gh[s] * d->gw[s];
+  return px;
+}
+}  // namespace
+
+extern "C" size_t dsl_conv2d_workspace_bytes(const dsl_conv_desc* d) {
+  if (!d || d->nseg < 1 || d->nseg > DSL_MAX_SEG || (d->flags & DSL_CONV_SMALL_C) || d->cs % 64) return 0;
+  dsl_conv_desc t = *d;
+  t.workspace = (void*)1;
+  t.workspace_bytes = (size_t)1 << 40;
+  int pick, splits;
+  const long long px = conv_pixels(d);
+  conv_choose(&t, px, d->kh * d->kw * (d->cs / 64), &pick, &splits);
+  return splits > 1 ? (size_t)splits * px * d->cd_pad * 4 : 0;
+}
+
 extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   DSL_CHECK(d != nullptr, "dsl_conv2d: null descriptor");
   DSL_CHECK(d->nseg >= 1 && d->nseg <= DSL_MAX_SEG, "dsl_conv2d: nseg=%d out of range", d->nseg);
@@ -564,10 +1098,51 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   k.scale = d->scale; k.bias = d->bias;
   k.addend = (const uint16_t*)d->addend; k.mask = (const uint16_t*)d->mask;
 
+  hipStream_t st = (hipStream_t)stream;
+  // ---- kernel / tile selection -------------------------------------------------------------------
+  int pick, splits;
+  conv_choose(d, px, k.ktiles, &pick, &splits);
+  if (pick >= 0) {
+    const TileCfg& c = kCfgs[pick];
+    k.splits = splits;
+    k.kt_per_split = (k.ktiles + splits - 1) / splits;
+    k.cd_pad = d->cd_pad;
+    k.ws = (float*)d->workspace;
+    dim3 grid(d->cd_pad / c.bco, (px + c.bpx - 1) / c.bpx, splits);
+    const size_t lds = (size_t)c.nst * (c.bco + c.bpx) * 128;
+    int prof = -1;
+    if (dsl_prof_active()) prof = dsl_prof_begin(pick == 0 ? 0 : 1, 2.0 * px * (double)d->cd * d->kh * d->kw * d->cs, st);
+#define LAUNCH2(A, B, C_, D, S_)                                                                               \
+  do {                                                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      hipFuncSetAttribute((const void*)conv_glds_kernel<A, B, C_, D, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)lds);                                                                          \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_glds_kernel<A, B, C_, D, S_>), grid, dim3(64 * C_ * D), lds, st, k);              \
+  } while (0)
+    switch (pick) {
+      case 0: LAUNCH2(256, 192, 4, 2, 2); break;
+      case 1: LAUNCH2(256, 128, 4, 2, 3); break;
+      case 2: LAUNCH2(128, 256, 2, 4, 3); break;
+      case 3: LAUNCH2(128, 128, 2, 2, 2); break;
+      default: LAUNCH2(64, 256, 1, 4, 2); break;
+    }
+#undef LAUNCH2
+    dsl_prof_end(prof, st);
+    if (splits > 1) {
+      const long long total = (long long)px * (d->cd_pad / 4);
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, k);
+    }
+    DSL_LAUNCH_CHECK("conv_glds_kernel");
+    return 0;
+  }
   const int bco = (d->cd_pad % 128 == 0) ? 128 : 64;
   dim3 grid(d->cd_pad / bco, (px + BPX - 1) / BPX);
   const size_t lds = 2 * (size_t)(bco + BPX) * BK * 2;
-  hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(BCO_, SC_)                                                                         \
   do {                                                                                            \
     static bool attr_set = false;                                                                 \
@@ -581,7 +1156,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   int prof = -1;
   if (dsl_prof_active()) {
     const double cin_real = smallc ? 3.0 : (double)d->cs;
-    prof = dsl_prof_begin((bco == 128 && !smallc) ? 0 : 1, 2.0 * px * (double)d->cd * d->kh * d->kw * cin_real, st);
+    prof = dsl_prof_begin(1, 2.0 * px * (double)d->cd * d->kh * d->kw * cin_real, st);
   }
   if (bco == 128) {
     if (smallc) LAUNCH(128, true); else LAUNCH(128, false);
@@ -594,19 +1169,34 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   return 0;
 }
 
+// wgrad tile configurations: 0 = v1 (BCO 128|64 x 128, register staged), 1 = 256x256, 2 = 256co x 128ci,
+// 3 = 128co x 256ci, 4 = 128x128 (v2)
+static int wgrad_pick(const dsl_wgrad_desc* d) {
+  const int force = d->splits < 0 ? -d->splits : 0;       // test hook: splits = -(cfg+1) forces a config
+  if (force) return force - 1;
+  if (d->cy % 128) return 0;
+  if (d->cy % 256 == 0 && d->cs % 256 == 0) return 1;
+  if (d->cy % 256 == 0) return 2;
+  if (d->cs % 256 == 0) return 3;
+  return 4;
+}
 static int wgrad_geometry(const dsl_wgrad_desc* d, int* ktiles, int* tiles, int* bco) {
   long long px = 0;
   for (int s = 0; s < d->nseg; ++s) px += (long long)d->n * d->gh[s] * d->gw[s];
   *ktiles = (int)((px + 63) / 64);
-  *bco = (d->cy % 128 == 0) ? 128 : 64;
-  *tiles = (d->cy / *bco) * (d->kh * d->kw * d->cs / 128);
-  return 0;
+  const int cfg = wgrad_pick(d);
+  const int bcos[5] = {(d->cy % 128 == 0) ? 128 : 64, 256, 256, 128, 128};
+  const int bcis[5] = {128, 256, 128, 256, 128};
+  *bco = bcos[cfg];
+  *tiles = (d->cy / *bco) * (d->kh * d->kw * d->cs / bcis[cfg]);
+  return cfg;
 }
 
 extern "C" int dsl_wgrad_splits(const dsl_wgrad_desc* d) {
   int ktiles, tiles, bco;
-  wgrad_geometry(d, &ktiles, &tiles, &bco);
-  int splits = (768 + tiles - 1) / tiles;
+  const int cfg = wgrad_geometry(d, &ktiles, &tiles, &bco);
+  const int target = (cfg == 0 || cfg == 4) ? 768 : 300;     // 2 small workgroups per CU vs one 8-wave workgroup
+  int splits = (target + tiles - 1) / tiles;
   const int max_by_k = ktiles / 4 > 0 ? ktiles / 4 : 1;    // at least 4 K stages per split
   if (splits > max_by_k) splits = max_by_k;
   if (splits < 1) splits = 1;
@@ -628,7 +1218,7 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
   DSL_CHECK(d->cy % 64 == 0 && d->cd <= d->cy, "dsl_conv2d_wgrad: bad cy=%d cd=%d", d->cy, d->cd);
   DSL_CHECK(d->dy && d->x && d->dw && d->workspace, "dsl_conv2d_wgrad: null pointer");
   int ktiles, tiles, bco;
-  wgrad_geometry(d, &ktiles, &tiles, &bco);
+  const int cfg = wgrad_geometry(d, &ktiles, &tiles, &bco);
   const int splits = d->splits > 0 ? d->splits : dsl_wgrad_splits(d);
   DSL_CHECK(d->workspace_bytes >= dsl_wgrad_workspace_bytes(d), "dsl_conv2d_wgrad: workspace too small (%zu < %zu)",
             d->workspace_bytes, dsl_wgrad_workspace_bytes(d));
@@ -655,14 +1245,43 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
   k.krow = (long long)d->kh * d->kw * d->cs;
   k.dy = (const uint16_t*)d->dy; k.x = (const uint16_t*)d->x; k.ws = (float*)d->workspace;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(d->cy / bco, d->kh * d->kw * d->cs / 128, splits);
-  const size_t lds = 2 * (size_t)(64 * bco * 2 + 64 * 256);
   const int prof = dsl_prof_active() ? dsl_prof_begin(2, 2.0 * px * (double)d->cd * d->kh * d->kw * d->cs, st) : -1;
-  if (bco == 128) {
+  if (cfg >= 1) {
+    const int bcis[5] = {128, 256, 128, 256, 128};
+    const int bci = bcis[cfg];
+    DSL_CHECK(d->cy % bco == 0 && d->cs % bci == 0, "dsl_conv2d_wgrad: tile config %d does not divide cy=%d / cs=%d", cfg, d->cy, d->cs);
+    k.gx = d->cy / bco;
+    k.gy = d->kh * d->kw * d->cs / bci;
+    k.splits = splits;
+    { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
+    dim3 grid2(k.gx * k.gy * ((splits + 7) / 8) * 8);
+    const size_t lds2 = 2 * (size_t)128 * (bco + bci) + 256;
+#define LAUNCHW(A, B, C_, D)                                                                                          \
+  do {                                                                                                               \
+    static bool a_ = false;                                                                                          \
+    if (!a_) {                                                                                                       \
+      hipFuncSetAttribute((const void*)wgrad_glds_kernel<A, B, C_, D>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                          (int)lds2);                                                                                \
+      a_ = true;                                                                                                     \
+    }                                                                                                                \
+    hipLaunchKernelGGL((wgrad_glds_kernel<A, B, C_, D>), grid2, dim3(64 * C_ * D), lds2, st, k);                      \
+  } while (0)
+    switch (cfg) {
+      case 1: LAUNCHW(256, 256, 2, 4); break;
+      case 2: LAUNCHW(256, 128, 4, 2); break;
+      case 3: LAUNCHW(128, 256, 2, 4); break;
+      default: LAUNCHW(128, 128, 2, 2); break;
+    }
+#undef LAUNCHW
+  } else if (bco == 128) {
+    dim3 grid(d->cy / bco, d->kh * d->kw * d->cs / 128, splits);
+    const size_t lds = 2 * (size_t)(64 * bco * 2 + 64 * 256);
     static bool a = false;
     if (!a) { hipFuncSetAttribute((const void*)wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
     hipLaunchKernelGGL((wgrad_kernel<128>), grid, dim3(256), lds, st, k);
   } else {
+    dim3 grid(d->cy / bco, d->kh * d->kw * d->cs / 128, splits);
+    const size_t lds = 2 * (size_t)(64 * bco * 2 + 64 * 256);
     static bool a = false;
     if (!a) { hipFuncSetAttribute((const void*)wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
     hipLaunchKernelGGL((wgrad_kernel<64>), grid, dim3(256), lds, st, k);

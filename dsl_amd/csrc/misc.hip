@@ -69,7 +69,7 @@ struct GnK {
   float* red;
 };
 
-constexpr int GN_PPB = 512;   // pixels per block
+constexpr int GN_PPB = 128;   // pixels per block
 
 // pass 1 of forward: sum / sumsq per (seg, img, group) -> red (pre-zeroed)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnK p) {
   const uint16_t* base = p.x + (p.off[seg] + (long long)img * hw) * p.c;
   float s = 0.f, ss = 0.f;
   const int px1 = min(px0 + GN_PPB, hw);
+#pragma unroll 4
   for (int px = px0 + prow; px < px1; px += ppi) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long long)px * p.c + chunk * 8);
 #pragma unroll
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnK p) {
   }
   const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
   const int px1 = min(px0 + GN_PPB, hw);
+#pragma unroll 4
   for (int px = px0 + prow; px < px1; px += ppi) {
     const long long o = ibase + (long long)px * p.c + chunk * 8;
     const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + o);
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnK p) {
   float s1 = 0.f, s2 = 0.f;
   const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
   const int px1 = min(px0 + GN_PPB, hw);
+#pragma unroll 4
   for (int px = px0 + prow; px < px1; px += ppi) {
     const long long o = ibase + (long long)px * p.c + chunk * 8;
     const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + o);
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnK p) {
   }
   const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
   const int px1 = min(px0 + GN_PPB, hw);
+#pragma unroll 4
   for (int px = px0 + prow; px < px1; px += ppi) {
     const long long o = ibase + (long long)px * p.c + chunk * 8;
     const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + o);
@@ -296,7 +300,7 @@ __global__ void sum_children_kernel(const uint16_t* __restrict__ g, uint16_t* __
 }
 
 // ---- column sums of a bf16 [rows][ld] matrix ---------------------------------------------------
-constexpr int CS_RPB = 1024;
+constexpr int CS_RPB = 128;
 __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ x, float* __restrict__ out,
                                                       long long rows, int c, int ld) {
   __shared__ float sh[256 * 8];

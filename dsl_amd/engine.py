@@ -94,6 +94,9 @@ class Plan:
         self.assign_ops = OpList()
         self.bwd_segments = []          # [(OpList, (grad_lo, grad_hi))] in execution order
         self.img = torch.zeros(N, 3, H, W, dtype=torch.float32, device=dev)
+        # split-K scratch shared by all convs of the plan (they run back to back on one stream); the library
+        # lowers its split factor if a conv would need more than this
+        self.conv_ws = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
         self._build_forward()
         if training:
             self.lossplan = FcosLossPlan(N, self.level_sizes, dev, max_gt=max_gt)
@@ -124,7 +127,8 @@ class Plan:
         return ops.conv_desc(src, st.w16_ptr(spec), dst, n=n, grid=out_hw, src_hw=in_hw, dst_hw=out_hw,
                              cs=8 if small_c else spec.cin, cd=spec.cout, cd_pad=spec.cout_pad,
                              ldd=dst_ld or spec.cout, kh=spec.k, kw=spec.k, stride=spec.stride, pad=spec.pad,
-                             flags=f, scale=scale, bias=bias, addend=addend, lda=spec.cout, add_hw=add_hw)
+                             flags=f, scale=scale, bias=bias, addend=addend, lda=spec.cout, add_hw=add_hw,
+                             workspace=None if small_c else self.conv_ws)
 
     def _build_forward(self):
         st, N, H, W, f = self.store, self.N, self.H, self.W, self.fwd
@@ -206,10 +210,10 @@ class Plan:
         regctr = self.buf('regctr', self.M, 8, dtype=torch.float32, zero=True)
         f.conv(ops.conv_desc(self.tower['cls_convs'][3]['act'], st.t16_ptr('head.cls_w'), cls_logits, n=N, grid=ls,
                              src_hw=ls, dst_hw=ls, cs=256, cd=80, cd_pad=128, ldd=80, kh=3, kw=3, stride=1, pad=1,
-                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.cls_b')))
+                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.cls_b'), workspace=self.conv_ws))
         f.conv(ops.conv_desc(self.tower['reg_convs'][3]['act'], st.t16_ptr('head.regctr_w'), regctr, n=N, grid=ls,
                              src_hw=ls, dst_hw=ls, cs=256, cd=5, cd_pad=64, ldd=8, kh=3, kw=3, stride=1, pad=1,
-                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.regctr_b')))
+                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.regctr_b'), workspace=self.conv_ws))
 
     def _gn_red(self):
         if 'gn_red' not in self.bufs:
@@ -253,7 +257,7 @@ class Plan:
         grid = dy_hw if os > 1 else dst_hw
         return ops.conv_desc(dy, st.wT_ptr(name), dst, n=n, grid=grid, src_hw=dy_hw, dst_hw=dst_hw, cs=cs, cd=cd,
                              cd_pad=cd, ldd=cd, kh=k, kw=k, stride=stride, pad=pad, mode=1, os=os, flags=f,
-                             addend=addend, lda=cd, mask=mask, ldm=cd)
+                             addend=addend, lda=cd, mask=mask, ldm=cd, workspace=self.conv_ws)
 
     def _build_backward(self):
         st, N, ls = self.store, self.N, self.level_sizes

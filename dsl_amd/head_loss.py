@@ -41,6 +41,11 @@ class FcosLossPlan:
         self.gt_off = torch.zeros(n + 1, dtype=torch.int32, device=dev)
         self.ig_boxes = torch.zeros(max_gt, 4, dtype=torch.float32, device=dev)
         self.ig_off = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        # pinned staging: pageable H2D copies would block the host until the stream drains (one stall per step)
+        pin = torch.cuda.is_available()
+        self._h_boxes = torch.zeros(2, max_gt, 4, dtype=torch.float32, pin_memory=pin)
+        self._h_labels = torch.zeros(max_gt, dtype=torch.int64, pin_memory=pin)
+        self._h_off = torch.zeros(2, n + 1, dtype=torch.int32, pin_memory=pin)
         self.desc = ops.fcos_desc(n=n, sizes=self.sizes, strides=strides, ranges=ranges, radius=radius,
                                   num_classes=num_classes)
         ops.set_ptrs(self.desc, gt_boxes=self.gt_boxes, gt_labels=self.gt_labels, gt_off=self.gt_off,
@@ -54,26 +59,32 @@ class FcosLossPlan:
     # -- ground truth upload (host lists -> one pinned staging copy) --------------------------------
     def set_targets(self, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
         assert len(gt_bboxes) == self.n == len(gt_labels)
-        offs, tot = [0], 0
-        for b in gt_bboxes:
-            tot += int(b.shape[0])
-            offs.append(tot)
-        assert tot <= self.max_gt, f'{tot} gt boxes exceed the plan capacity {self.max_gt}'
+
+        def stage(boxes, slot, labels=None):
+            tot = 0
+            self._h_off[slot, 0] = 0
+            for i, b in enumerate(boxes):
+                k = int(b.shape[0])
+                assert tot + k <= self.max_gt, f'more than {self.max_gt} boxes in one batch'
+                if k:
+                    self._h_boxes[slot, tot:tot + k].copy_(b.reshape(-1, 4))
+                    if labels is not None:
+                        self._h_labels[tot:tot + k].copy_(labels[i].reshape(-1))
+                tot += k
+                self._h_off[slot, i + 1] = tot
+            return tot
+
+        tot = stage(gt_bboxes, 0, gt_labels)
         if tot:
-            self.gt_boxes[:tot].copy_(torch.cat([b.reshape(-1, 4).float() for b in gt_bboxes]), non_blocking=True)
-            self.gt_labels[:tot].copy_(torch.cat([l.reshape(-1).long() for l in gt_labels]), non_blocking=True)
-        self.gt_off.copy_(torch.tensor(offs, dtype=torch.int32), non_blocking=True)
+            self.gt_boxes[:tot].copy_(self._h_boxes[0, :tot], non_blocking=True)
+            self.gt_labels[:tot].copy_(self._h_labels[:tot], non_blocking=True)
+        self.gt_off.copy_(self._h_off[0], non_blocking=True)
         if gt_bboxes_ignore is not None:
             assert len(gt_bboxes_ignore) == self.n
-            offs, tot = [0], 0
-            for b in gt_bboxes_ignore:
-                tot += int(b.shape[0])
-                offs.append(tot)
-            assert tot <= self.max_gt
+            tot = stage(gt_bboxes_ignore, 1)
             if tot:
-                self.ig_boxes[:tot].copy_(torch.cat([b.reshape(-1, 4).float() for b in gt_bboxes_ignore]),
-                                          non_blocking=True)
-            self.ig_off.copy_(torch.tensor(offs, dtype=torch.int32), non_blocking=True)
+                self.ig_boxes[:tot].copy_(self._h_boxes[1, :tot], non_blocking=True)
+            self.ig_off.copy_(self._h_off[1], non_blocking=True)
             ops.set_ptrs(self.desc, ig_boxes=self.ig_boxes, ig_off=self.ig_off)
         else:
             ops.set_ptrs(self.desc, ig_boxes=None, ig_off=None)

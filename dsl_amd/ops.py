@@ -16,7 +16,7 @@ def _segs(shapes):
 
 def conv_desc(src, wgt, dst, *, n, grid, src_hw, dst_hw, cs, cd, cd_pad, ldd, kh, kw, stride=1, pad=0,
               mode=0, os=1, flags=0, scale=None, bias=None, addend=None, lda=0, add_hw=None, mask=None,
-              ldm=0):
+              ldm=0, workspace=None):
     """grid/src_hw/dst_hw/add_hw: list of (h, w) per level segment."""
     d = L.ConvDesc()
     d.nseg, d.n = len(grid), n
@@ -29,8 +29,14 @@ def conv_desc(src, wgt, dst, *, n, grid, src_hw, dst_hw, cs, cd, cd_pad, ldd, kh
     d.kh, d.kw, d.stride, d.pad, d.mode, d.os, d.flags = kh, kw, stride, pad, mode, os, flags
     d.src, d.wgt, d.dst = L.ptr(src), L.ptr(wgt), L.ptr(dst)
     d.scale, d.bias, d.addend, d.mask = L.ptr(scale), L.ptr(bias), L.ptr(addend), L.ptr(mask)
-    d._keep = (src, wgt, dst, scale, bias, addend, mask)
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = L.ptr(workspace), workspace.numel() * workspace.element_size()
+    d._keep = (src, wgt, dst, scale, bias, addend, mask, workspace)
     return d
+
+
+def conv_workspace_bytes(d):
+    return lib.dsl_conv2d_workspace_bytes(C.byref(d))
 
 
 def conv2d(*a, **k):
@@ -40,14 +46,15 @@ def conv2d(*a, **k):
 
 
 def wgrad_desc(dy, x, dw, *, n, grid, src_hw, cs, cy, cd, kh, kw, stride=1, pad=0, scale=None, db=None,
-               workspace=None):
+               workspace=None, force_cfg=None):
     d = L.WgradDesc()
     d.nseg, d.n = len(grid), n
     d.gh, d.gw = _segs(grid)
     d.sh, d.sw = _segs(src_hw)
     d.cs, d.cy, d.cd, d.kh, d.kw, d.stride, d.pad = cs, cy, cd, kh, kw, stride, pad
-    d.splits = 0
-    d.splits = lib.dsl_wgrad_splits(C.byref(d))
+    d.splits = 0 if force_cfg is None else -(force_cfg + 1)     # negative: test hook forcing a tile config
+    if force_cfg is None:
+        d.splits = lib.dsl_wgrad_splits(C.byref(d))
     d.dy, d.x, d.scale, d.dw, d.db = L.ptr(dy), L.ptr(x), L.ptr(scale), L.ptr(dw), L.ptr(db)
     need = lib.dsl_wgrad_workspace_bytes(C.byref(d))
     if workspace is None:

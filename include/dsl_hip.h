@@ -69,8 +69,12 @@ typedef struct dsl_conv_desc {
   const float* bias;                                 /* [cd] or NULL (=0) */
   const void* addend;                                /* bf16 or NULL */
   const void* mask;                                  /* bf16 or NULL */
+  void* workspace;                                   /* optional fp32 scratch for split-K (small-M, large-K convs) */
+  size_t workspace_bytes;                            /* NULL/0: never split */
 } dsl_conv_desc;
 
+/* bytes of split-K scratch this conv would like (0 if it will not split); any smaller buffer is legal */
+size_t dsl_conv2d_workspace_bytes(const dsl_conv_desc* d);
 int dsl_conv2d(const dsl_conv_desc* d, void* stream);
 
 /* Weight gradient: dW[co][r][s][ci] = scale[co] * sum_p dY[p][co] * X[p@(r,s)][ci]  (fp32, KRSC).
@@ -238,8 +242,9 @@ int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Live kernel timing with HIP events (bench.py roofline): when enabled, each launch of the MFMA
- * conv kernels is bracketed by a hipEvent pair on the launch stream.  Classes: 0 = conv_gemm_kernel
- * <128,false> (forward + data gradient), 1 = conv_gemm_kernel<64,*>/<128,true>, 2 = wgrad_kernel.
+ * conv kernels is bracketed by a hipEvent pair on the launch stream.  Classes: 0 = conv_glds_kernel
+ * <256,192,4,2,2> (forward + data gradient, the dominant kernel), 1 = every other forward/dgrad conv
+ * kernel instance, 2 = the weight-gradient kernels.
  * dsl_prof_read synchronises the events and returns per class: launches, total ms, algorithmic FLOPs.
  * ---------------------------------------------------------------------------------------- */
 #define DSL_PROF_CLASSES 3

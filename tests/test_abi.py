@@ -26,7 +26,7 @@ def test_header_symbols_exported():
 def test_descriptor_sizes_match_header_layout():
     """ctypes mirrors must have the C struct sizes (natural alignment, LP64)."""
     from dsl_amd import _lib as L
-    assert ctypes.sizeof(L.ConvDesc) == 2 * 4 + 8 * 5 * 4 + 13 * 4 + 4 + 7 * 8     # 4 bytes padding before the pointers
+    assert ctypes.sizeof(L.ConvDesc) == 2 * 4 + 8 * 5 * 4 + 13 * 4 + 4 + 9 * 8     # 4 bytes padding before the pointers
     assert ctypes.sizeof(L.Op) == 4 + 7 * 4 + 8 + 4 * 8 + 2 * 8
     assert ctypes.sizeof(L.GnDesc) % 8 == 0 and ctypes.sizeof(L.FcosDesc) % 8 == 0
 

@@ -84,10 +84,17 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 15, 4 + (3 << 4), 5 + (2 << 4), 6 + (5 << 4), 0 + (16 << 4)])
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_forward(K, case):
+def test_conv_forward(K, case, force):
+    """force: 0 = library's own tile choice, 1..5 = v2 (DMA-to-LDS) tile configs, 15 = v1 kernel."""
     L, ops = K
     _, N, Ci, Co, H, W, k, s, p = case
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device='cuda') if force >> 4 else None
+    force = (force & 15) | ((force >> 4) & 15) << 4         # bits 8-11 tile config, bits 12-15 forced split-K (16 -> auto)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128}.get(force & 15)
+    if bco and ((Co + 63) // 64 * 64) % bco:
+        pytest.skip('tile does not divide Cout')
     g = torch.Generator().manual_seed(hash(case[0]) % 1000)
     x, w = rnd(N, Ci, H, W, g=g), rnd(Co, Ci, k, k, g=g, scale=1 / math.sqrt(Ci * k * k))
     scale, bias = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
@@ -98,7 +105,8 @@ def test_conv_forward(K, case):
     y = torch.empty(N, Ho, Wo, Co, dtype=torch.bfloat16, device='cuda')
     ops.conv2d(nhwc(x), pack_w(w, cd_pad), y, n=N, grid=[(Ho, Wo)], src_hw=[(H, W)], dst_hw=[(Ho, Wo)],
                cs=Ci, cd=Co, cd_pad=cd_pad, ldd=Co, kh=k, kw=k, stride=s, pad=p,
-               flags=L.CONV_RELU_OUT, scale=scale.cuda(), bias=bias.cuda(), addend=nhwc(res), lda=Co)
+               flags=L.CONV_RELU_OUT | (force << 8), scale=scale.cuda(), bias=bias.cuda(), addend=nhwc(res), lda=Co,
+               workspace=ws)
     sync()
     got = from_nhwc(y)
     assert torch.allclose(got, ref, rtol=1e-2, atol=1e-2), (got - ref).abs().max()
@@ -172,11 +180,15 @@ DGRAD_CASES = [('3x3_s1', 2, 128, 64, 11, 13, 3, 1, 1), ('3x3_s2', 1, 128, 128, 
                ('1x1_s1', 2, 256, 128, 7, 9, 1, 1, 0), ('3x3_s1_pad80', 1, 256, 80, 9, 9, 3, 1, 1)]
 
 
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 15])
 @pytest.mark.parametrize('case', DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
-def test_conv_dgrad_transposed(K, case):
+def test_conv_dgrad_transposed(K, case, force):
     """mode 1 gather == autograd input-gradient; epilogue (acc + addend) * (mask > 0)."""
     L, ops = K
     _, N, Ci, Co, H, W, k, s, p = case
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128}.get(force)
+    if bco and Ci % bco:
+        pytest.skip('tile does not divide Cin')
     g = torch.Generator().manual_seed(len(case[0]))
     x = rnd(N, Ci, H, W, g=g).requires_grad_()
     w = rnd(Co, Ci, k, k, g=g, scale=1 / math.sqrt(Co * k * k))
@@ -192,7 +204,7 @@ def test_conv_dgrad_transposed(K, case):
     dx = torch.empty(N, H, W, Ci, dtype=torch.bfloat16, device='cuda')
     ops.conv2d(dyp.bfloat16().cuda(), pack_w_dgrad(w, cy), dx, n=N, grid=[(H, W)], src_hw=[(Ho, Wo)], dst_hw=[(H, W)],
                cs=cy, cd=Ci, cd_pad=Ci, ldd=Ci, kh=k, kw=k, stride=s, pad=p, mode=1, addend=nhwc(add), lda=Ci,
-               mask=nhwc(msk), ldm=Ci, flags=L.CONV_MASK_LAST)
+               mask=nhwc(msk), ldm=Ci, flags=L.CONV_MASK_LAST | (force << 8))
     sync()
     got = from_nhwc(dx)
     assert torch.allclose(got, ref, rtol=1e-2, atol=2e-2), (got - ref).abs().max()
@@ -219,14 +231,19 @@ def test_conv_dgrad_1x1_s2_scatter(K):
     assert torch.allclose(from_nhwc(dx), ref, rtol=1e-2, atol=1e-2)
 
 
-WG_CASES = [('3x3_s1', 2, 128, 128, 12, 17, 3, 1, 1), ('1x1_s2', 2, 256, 128, 14, 18, 1, 2, 0),
+WG_CASES = [('3x3_s1', 2, 128, 128, 12, 17, 3, 1, 1), ('1x1_s2', 2, 256, 128, 14, 18, 1, 2, 0), ('3x3_256', 2, 256, 256, 9, 13, 3, 1, 1),
             ('3x3_s2', 1, 128, 256, 13, 21, 3, 2, 1), ('1x1_s1_co64', 2, 128, 64, 9, 10, 1, 1, 0)]
 
 
+@pytest.mark.parametrize('cfg', [None, 0, 1, 2, 3, 4])
 @pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
-def test_wgrad(K, case):
+def test_wgrad(K, case, cfg):
+    """cfg: None = library's choice, 0 = v1 kernel, 1..4 = v2 (DMA-to-LDS) tiles 256x256, 256x128, 128x256, 128x128."""
     L, ops = K
     _, N, Ci, Co, H, W, k, s, p = case
+    need = {1: (256, 256), 2: (256, 128), 3: (128, 256), 4: (128, 128)}.get(cfg)
+    if need and (Co % need[0] or Ci % need[1]):
+        pytest.skip('tile does not divide the channels')
     g = torch.Generator().manual_seed(7 + len(case[0]))
     x = rnd(N, Ci, H, W, g=g)
     w = rnd(Co, Ci, k, k, g=g).requires_grad_()
@@ -239,7 +256,7 @@ def test_wgrad(K, case):
     dw = torch.empty(Co, k, k, Ci, dtype=torch.float32, device='cuda')
     db = torch.empty(Co, dtype=torch.float32, device='cuda')
     ops.conv2d_wgrad(nhwc(dy), nhwc(x), dw, n=N, grid=[(Ho, Wo)], src_hw=[(H, W)], cs=Ci, cy=Co, cd=Co, kh=k, kw=k,
-                     stride=s, pad=p, scale=scale.cuda(), db=db)
+                     stride=s, pad=p, scale=scale.cuda(), db=db, force_cfg=cfg)
     sync()
     got = dw.cpu()
     tol = 2e-2 * float(ref.abs().max())

@@ -1,0 +1,22 @@
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dsl_amd import _lib as L
+from dsl_amd import ops
+N = 2
+LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+P = sum(h * w for h, w in LEVELS) * N
+dev = 'cuda'
+x = torch.randn(P, 256, device=dev).bfloat16()
+dy = torch.randn(P, 256, device=dev).bfloat16()
+dw = torch.empty(256, 3, 3, 256, device=dev)
+d = ops.wgrad_desc(dy, x, dw, n=N, grid=LEVELS, src_hw=LEVELS, cs=256, cy=256, cd=256, kh=3, kw=3, stride=1, pad=1, force_cfg=1)
+for _ in range(3):
+    L.lib.dsl_conv2d_wgrad(C.byref(d), L.stream_ptr())
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    L.lib.dsl_conv2d_wgrad(C.byref(d), L.stream_ptr())
+e1.record(); torch.cuda.synchronize()
+print('DSL_ABLATE=%s  %.1f us per wgrad op (incl. reduce)' % (os.environ.get('DSL_ABLATE', '0'), e0.elapsed_time(e1) * 100))

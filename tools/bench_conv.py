@@ -11,8 +11,10 @@ from dsl_amd import _lib as L
 from dsl_amd import ops
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+FORCE = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]
 LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
 dev = 'cuda'
+WS = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
 
 
 def timeit(fn, iters=10):
@@ -42,19 +44,26 @@ def bench(name, ci, co, k, s, sizes_in):
     dw = torch.empty(co, k, k, ci, device=dev)
     flops = 2.0 * pout * co * ci * k * k
     import ctypes as C
-    dfw = ops.conv_desc(x, w, y, n=N, grid=sizes_out, src_hw=sizes_in, dst_hw=sizes_out, cs=ci, cd=co, cd_pad=co,
-                        ldd=co, kh=k, kw=k, stride=s, pad=p, flags=L.CONV_RELU_OUT)
-    t_f = timeit(lambda: L.lib.dsl_conv2d(C.byref(dfw), L.stream_ptr()))
-    res = [f'{name:28s} fwd {t_f*1e6:8.1f} us {flops/t_f/1e12:7.1f} TF']
+    res = [f'{name:28s}']
+    for force in FORCE:
+        bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128}.get(force & 15)
+        if bco and co % bco:
+            res.append(f'f{force}: n/a')
+            continue
+        dfw = ops.conv_desc(x, w, y, n=N, grid=sizes_out, src_hw=sizes_in, dst_hw=sizes_out, cs=ci, cd=co, cd_pad=co,
+                            ldd=co, kh=k, kw=k, stride=s, pad=p, flags=L.CONV_RELU_OUT | ((force & 15) << 8), workspace=WS if force < 16 else None)
+        t_f = timeit(lambda: L.lib.dsl_conv2d(C.byref(dfw), L.stream_ptr()))
+        res.append(f'f{force}: {t_f*1e6:6.1f}us {flops/t_f/1e12:5.0f}TF')
     if s == 1:
         ddg = ops.conv_desc(dy, wt, dx, n=N, grid=sizes_in, src_hw=sizes_out, dst_hw=sizes_in, cs=co, cd=ci, cd_pad=ci,
-                            ldd=ci, kh=k, kw=k, stride=s, pad=p, mode=1, mask=x, ldm=ci, flags=L.CONV_MASK_LAST)
+                            ldd=ci, kh=k, kw=k, stride=s, pad=p, mode=1, mask=x, ldm=ci, flags=L.CONV_MASK_LAST, workspace=WS)
         t_d = timeit(lambda: L.lib.dsl_conv2d(C.byref(ddg), L.stream_ptr()))
         res.append(f'dgrad {t_d*1e6:8.1f} us {flops/t_d/1e12:7.1f} TF')
     if ci % 128 == 0:
-        dwg = ops.wgrad_desc(dy, x, dw, n=N, grid=sizes_out, src_hw=sizes_in, cs=ci, cy=co, cd=co, kh=k, kw=k, stride=s, pad=p)
-        t_w = timeit(lambda: L.lib.dsl_conv2d_wgrad(C.byref(dwg), L.stream_ptr()))
-        res.append(f'wgrad {t_w*1e6:8.1f} us {flops/t_w/1e12:7.1f} TF (splits {dwg.splits})')
+        for cfg in (0, None):
+            dwg = ops.wgrad_desc(dy, x, dw, n=N, grid=sizes_out, src_hw=sizes_in, cs=ci, cy=co, cd=co, kh=k, kw=k, stride=s, pad=p, force_cfg=cfg)
+            t_w = timeit(lambda: L.lib.dsl_conv2d_wgrad(C.byref(dwg), L.stream_ptr()))
+            res.append(f'wgrad[{cfg}] {t_w*1e6:7.1f}us {flops/t_w/1e12:5.0f}TF')
     print('  '.join(res), flush=True)
 
 
