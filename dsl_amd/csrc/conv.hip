@@ -27,6 +27,8 @@ struct ConvK {
   long long soff[DSL_MAX_SEG], doff[DSL_MAX_SEG], aoff[DSL_MAX_SEG];   // segment starts, in pixels
   int cs, cd, ldd, lda, ldm, kh, kw, stride, pad, mode, os, flags;
   int ktiles, kc;
+  int ident;                          // 1: destination pixel index == compute-grid pixel index (os 1, same sizes)
+  int dbg;                            // ablation knobs (DSL_ABLATE env): 1 = DMA only for the first tiles, 2 = no MFMA, 4 = no epilogue
   int splits, kt_per_split, cd_pad;   // split-K over K tiles (v2 kernel): fp32 partials -> ws, then conv_splitk_epilogue_kernel
   float* ws;
   long long wrow;
@@ -140,7 +142,77 @@ __device__ __forceinline__ void conv_epilogue4(const ConvK& p, long long dpix, l
   }
 }
 
+// Epilogue for 8 consecutive channels of one pixel: 16-byte loads / stores (used by the LDS-staged epilogue
+// of the v2 kernel).  Falls back to two 4-channel epilogues on a ragged channel tail.
+__device__ __forceinline__ void conv_epilogue8(const ConvK& p, long long dpix, long long apix, int co, float v[8]) {
+  if (co + 7 >= p.cd) {
+    conv_epilogue4(p, dpix, apix, co, v);
+    if (co + 4 < p.cd) conv_epilogue4(p, dpix, apix, co + 4, v + 4);
+    return;
+  }
+  const bool mask_first = (p.flags & DSL_CONV_MASK_FIRST) != 0 && p.mask != nullptr;
+  const bool mask_last = (p.flags & DSL_CONV_MASK_LAST) != 0 && p.mask != nullptr;
+  if (p.scale) {
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale + co), s1 = *reinterpret_cast<const f32x4*>(p.scale + co + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] *= s0[e];
+      v[4 + e] *= s1[e];
+    }
+  }
+  if (p.bias) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + co), b1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] += b0[e];
+      v[4 + e] += b1[e];
+    }
+  }
+  float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  if (mask_first || mask_last) {
+    const u32x4 mm = *reinterpret_cast<const u32x4*>(p.mask + dpix * p.ldm + co);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      m[2 * e] = bflo(mm[e]) > 0.f ? 1.f : 0.f;
+      m[2 * e + 1] = bfhi(mm[e]) > 0.f ? 1.f : 0.f;
+    }
+  }
+  if (mask_first) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= m[e];
+  }
+  if (p.addend) {
+    const u32x4 aa = *reinterpret_cast<const u32x4*>(p.addend + apix * p.lda + co);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] += bflo(aa[e]);
+      v[2 * e + 1] += bfhi(aa[e]);
+    }
+  }
+  if (mask_last) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= m[e];
+  }
+  if (p.flags & DSL_CONV_RELU_OUT) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (p.flags & DSL_CONV_OUT_F32) {
+    float* o = reinterpret_cast<float*>(p.dst) + dpix * p.ldd + co;
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else {
+    u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.dst) + dpix * p.ldd + co) = o;
+  }
+}
+
 __device__ __forceinline__ void conv_out_index(const ConvK& p, int gp, long long& dpix, long long& apix) {
+  if (p.ident) {           // common case: no integer divisions in the epilogue
+    dpix = gp;
+    apix = gp;
+    return;
+  }
   int seg, img, y, x;
   decode_pixel(p, gp, seg, img, y, x);
   const int oy = y * p.os, ox = x * p.os;
@@ -480,11 +552,12 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_glds_kernel(const ConvK p
     else if (NST >= 3 && ahead >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * LPT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // everyone's DMA for tile kt landed; compute(kt-1) finished everywhere
-    if (kt + NST - 1 < kt1) gload(kt + NST - 1, slot == 0 ? NST - 1 : slot - 1);
-    compute(slot);
+    if (kt + NST - 1 < kt1 && !(p.dbg & 1)) gload(kt + NST - 1, slot == 0 ? NST - 1 : slot - 1);
+    if (!(p.dbg & 2)) compute(slot);
     slot = (slot + 1 == NST) ? 0 : slot + 1;
   }
 
+  if (p.dbg & 4) return;
   if (p.splits > 1) {                      // split-K: raw fp32 partial tile -> workspace [split][pixel][cd_pad]
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -503,24 +576,37 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_glds_kernel(const ConvK p
     return;
   }
 
-  // ---- epilogue ----
+  // ---- epilogue, staged through LDS: the MFMA result layout gives each lane one pixel and scattered 4-channel
+  // runs (8-byte stores 2 KB apart); transposing 32*WPX pixels at a time through the (now free) stage memory
+  // turns every global access of the epilogue - output, residual addend, ReLU mask - into 16-byte lanes that
+  // cover whole 512-byte pixel rows.
+  constexpr int ROWB = BCO * 4 + 16;            // fp32 row + 16 B pad: conflict-free ds_write_b128 down a column
+  constexpr int CPX = 32 * WPX;                 // pixels per chunk
+  constexpr int GPR = BCO / 8;                  // 8-channel groups per pixel row
+  static_assert(CPX * ROWB <= NST * STAGE, "epilogue staging must fit in the stage memory");
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    const int gp = px0 + wave_px * (32 * PT) + pt * 32 + frow;
-    if (gp >= totpx) continue;
-    long long dpix, apix;
-    conv_out_index(p, gp, dpix, apix);
+    __syncthreads();                            // previous chunk fully read (first pass: all MFMA operands consumed)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int co = co0 + wave_co * 64 + ct * 32 + 8 * g + 4 * fhalf;
-        if (co >= p.cd) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[ct][pt][4 * g + e];
-        conv_epilogue4(p, dpix, apix, co, v);
+        const int col = wave_co * 64 + ct * 32 + 8 * g + 4 * fhalf;
+        f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
       }
+    __syncthreads();
+    for (int id = tid; id < CPX * GPR; id += T) {
+      const int pl = id / GPR, cg = id - pl * GPR;
+      const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
+      const int co = co0 + cg * 8;
+      if (gp >= totpx || co >= p.cd) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32 + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      long long dpix, apix;
+      conv_out_index(p, gp, dpix, apix);
+      conv_epilogue8(p, dpix, apix, co, v);
     }
   }
 }
@@ -1083,6 +1169,9 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     ao += (long long)d->n * k.ah[s] * k.aw[s];
   }
   k.pxstart[d->nseg] = px;
+  k.ident = (d->os == 1 && !(d->flags & DSL_CONV_ADD_UPSAMPLE)) ? 1 : 0;
+  for (int s = 0; s < d->nseg; ++s)
+    if (d->gh[s] != d->dh[s] || d->gw[s] != d->dw[s]) k.ident = 0;
   k.cs = d->cs; k.cd = d->cd; k.ldd = d->ldd; k.lda = d->lda; k.ldm = d->ldm;
   k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.mode = d->mode; k.os = d->os;
   k.flags = d->flags;
@@ -1108,6 +1197,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     k.kt_per_split = (k.ktiles + splits - 1) / splits;
     k.cd_pad = d->cd_pad;
     k.ws = (float*)d->workspace;
+    { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
     dim3 grid(d->cd_pad / c.bco, (px + c.bpx - 1) / c.bpx, splits);
     const size_t lds = (size_t)c.nst * (c.bco + c.bpx) * 128;
     int prof = -1;
