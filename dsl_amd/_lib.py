@@ -50,7 +50,7 @@ class GnDesc(C.Structure):
                 ('h', I5), ('w', I5), ('eps', C.c_float),
                 ('x', C.c_void_p), ('y', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
                 ('stats', C.c_void_p), ('dy', C.c_void_p), ('dx', C.c_void_p), ('dgamma', C.c_void_p),
-                ('dbeta', C.c_void_p), ('red', C.c_void_p)]
+                ('dbeta', C.c_void_p), ('red', C.c_void_p), ('prezeroed', C.c_int32)]
 
 
 class FcosDesc(C.Structure):
@@ -82,6 +82,12 @@ class DetDesc(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('scale', C.c_void_p), ('out', C.c_void_p),
+                ('cout', C.c_int32), ('cout_pad', C.c_int32), ('taps', C.c_int32), ('cin', C.c_int32),
+                ('block_start', C.c_int32), ('tiles_ci', C.c_int32), ('tiles_co', C.c_int32), ('pad_', C.c_int32)]
+
+
 class Op(C.Structure):
     _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 7), ('desc', C.c_void_p),
                 ('p', C.c_void_p * 4), ('l', C.c_int64 * 2)]
@@ -103,7 +109,7 @@ _SIGS = {
     'dsl_sumsq': [_vp, _l, _vp, _vp],
     'dsl_sgd_step': [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _i, _vp],
     'dsl_ema_lerp': [_vp, _vp, _l, _f, _vp], 'dsl_cast_bf16': [_vp, _vp, _l, _vp],
-    'dsl_pack_dgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'dsl_pack_dgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_pack_dgrad_batched': [_vp, _i, _i, _vp],
     'dsl_detect_workspace_bytes': [_vp], 'dsl_fcos_detect': [_vp, _vp],
     'dsl_run_ops': [_vp, _i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp],
 }

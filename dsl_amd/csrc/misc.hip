@@ -387,7 +387,7 @@ extern "C" int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream) {
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   dim3 grid((maxhw + GN_PPB - 1) / GN_PPB, d->nseg * d->n);
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(d->red, 0, sizeof(float) * 2 * d->nseg * d->n * d->groups, st);
+  if (!d->prezeroed) hipMemsetAsync(d->red, 0, sizeof(float) * 2 * d->nseg * d->n * d->groups, st);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, k);
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, st, k);
   DSL_LAUNCH_CHECK("gn forward");
@@ -405,9 +405,11 @@ extern "C" int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream) {
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   dim3 grid((maxhw + GN_PPB - 1) / GN_PPB, d->nseg * d->n);
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(d->red, 0, sizeof(float) * 2 * d->nseg * d->n * d->groups, st);
-  hipMemsetAsync(d->dgamma, 0, sizeof(float) * d->c, st);
-  hipMemsetAsync(d->dbeta, 0, sizeof(float) * d->c, st);
+  if (!d->prezeroed) {
+    hipMemsetAsync(d->red, 0, sizeof(float) * 2 * d->nseg * d->n * d->groups, st);
+    hipMemsetAsync(d->dgamma, 0, sizeof(float) * d->c, st);
+    hipMemsetAsync(d->dbeta, 0, sizeof(float) * d->c, st);
+  }
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, st, k);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(256), 0, st, k);
   DSL_LAUNCH_CHECK("gn backward");

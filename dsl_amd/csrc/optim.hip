@@ -88,6 +88,36 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
   }
 }
 
+__global__ void pack_dgrad_batched_kernel(const dsl_pack_item* __restrict__ items, int n) {
+  __shared__ float tile[32][33];
+  // locate this block's conv (n <= a few dozen: linear scan of the prefix sums)
+  int it = 0;
+  while (it + 1 < n && (int)blockIdx.x >= items[it + 1].block_start) ++it;
+  const dsl_pack_item I = items[it];
+  int b = blockIdx.x - I.block_start;
+  const int tci = b % I.tiles_ci;
+  b /= I.tiles_ci;
+  const int tco = b % I.tiles_co;
+  const int t = b / I.tiles_co;
+  const int ci0 = tci * 32, co0 = tco * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < I.cout && ci < I.cin) {
+      v = I.w[((long long)co * I.taps + t) * I.cin + ci];
+      if (I.scale) v *= I.scale[co];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  uint16_t* out = (uint16_t*)I.out;
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < I.cin && co < I.cout_pad) out[((long long)ci * I.taps + t) * I.cout_pad + co] = f2bf(tile[tx][r]);
+  }
+}
+
 int nblocks(long long n4, int cap) {
   long long b = (n4 + 255) / 256;
   if (b > cap) b = cap;
@@ -138,5 +168,12 @@ extern "C" int dsl_pack_dgrad(const float* w, const float* scale, void* out, int
   hipLaunchKernelGGL(pack_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, scale, (uint16_t*)out, cout,
                      cout_pad, taps, cin);
   DSL_LAUNCH_CHECK("pack_dgrad_kernel");
+  return 0;
+}
+
+extern "C" int dsl_pack_dgrad_batched(const dsl_pack_item* items_dev, int n, int total_blocks, void* stream) {
+  DSL_CHECK(items_dev && n > 0 && total_blocks > 0, "dsl_pack_dgrad_batched: bad arguments");
+  hipLaunchKernelGGL(pack_dgrad_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n);
+  DSL_LAUNCH_CHECK("pack_dgrad_batched_kernel");
   return 0;
 }

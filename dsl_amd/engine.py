@@ -63,6 +63,9 @@ class OpList:
     def sum2x2(self, g, out, n, h, w, ch, cw, c):
         self._add(L.OP_SUM2X2, i=(n, h, w, ch, cw, c), p=(g, out))
 
+    def memset(self, ptr, nbytes, value=0):
+        self._add(L.OP_MEMSET, i=(value,), p=(ptr,), l=(nbytes,))
+
     def pack_image(self, img, out, n, h, w):
         self._add(L.OP_PACK_IMAGE, i=(n, h, w), p=(img, out))
 
@@ -97,6 +100,12 @@ class Plan:
         # split-K scratch shared by all convs of the plan (they run back to back on one stream); the library
         # lowers its split factor if a conv would need more than this
         self.conv_ws = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
+        # one pre-zeroed pool for every GroupNorm reduction buffer of the step (8 forward + 8 backward slices):
+        # a single memset at the start of the forward list replaces one memset per GN launch
+        self._gn_slice = 5 * N * 32 * 2
+        self.zero_pool = torch.zeros(16 * self._gn_slice, dtype=torch.float32, device=dev)
+        self._gn_next = 0
+        self.fwd.memset(self.zero_pool, self.zero_pool.numel() * 4)
         self._build_forward()
         if training:
             self.lossplan = FcosLossPlan(N, self.level_sizes, dev, max_gt=max_gt)
@@ -202,6 +211,7 @@ class Plan:
                 base = f'bbox_head.{tower}.{i}.gn'
                 gd = ops.gn_desc(pre, act, st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'), stats,
                                  self._gn_red(), n=N, hw=ls)
+                gd.prezeroed = 1
                 f.gn_fwd(gd)
                 lays.append(dict(spec=spec, xin=xin, pre=pre, act=act, stats=stats, gn=base))
                 xin = act
@@ -216,9 +226,10 @@ class Plan:
                              flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.regctr_b'), workspace=self.conv_ws))
 
     def _gn_red(self):
-        if 'gn_red' not in self.bufs:
-            self.buf('gn_red', 5 * self.N * 32, 2, dtype=torch.float32)
-        return self.bufs['gn_red']
+        assert self._gn_next < 16
+        ptr = self.zero_pool.data_ptr() + self._gn_next * self._gn_slice * 4
+        self._gn_next += 1
+        return ptr
 
     # ---------------------------------------------------------------------------------------------
     def _wgrad(self, ol, spec, dy, x, n, out_hw, in_hw, cy=None, cd=None, wregion=None, bregion=None):
@@ -269,6 +280,11 @@ class Plan:
         g_feats = self.buf('g_feats', M, 256)
         # ================= segment 0: head + FPN =================
         ol = OpList()
+        # the 16 GN gamma/beta gradient vectors are contiguous in the flat gradient buffer: one memset
+        g0 = reg['bbox_head.cls_convs.0.gn.weight'][0]
+        g1 = reg['bbox_head.reg_convs.3.gn.bias'][0] + reg['bbox_head.reg_convs.3.gn.bias'][1]
+        assert g1 - g0 == 16 * 256
+        ol.memset(st.grad.data_ptr() + g0 * 4, (g1 - g0) * 4)
         for ti, tower in enumerate(('cls_convs', 'reg_convs')):
             lays = self.tower[tower]
             if tower == 'cls_convs':
@@ -285,6 +301,7 @@ class Plan:
                 gd = ops.gn_desc(lay['pre'], lay['act'], st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'),
                                  lay['stats'], self._gn_red(), n=N, hw=ls, dy=gA, dx=gB,
                                  dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad))
+                gd.prezeroed = 1
                 ol.gn_bwd(gd)
                 self._wgrad(ol, lay['spec'], gB, lay['xin'], N, ls, ls)
                 if i > 0:

@@ -88,6 +88,7 @@ def gn_desc(x, y, gamma, beta, stats, red, *, n, hw, c=256, groups=32, eps=1e-5,
     d.h, d.w = _segs(hw)
     d.eps = eps
     d.x, d.y, d.gamma, d.beta, d.stats, d.red = (L.ptr(t) for t in (x, y, gamma, beta, stats, red))
+    d.prezeroed = 0
     d.dy, d.dx, d.dgamma, d.dbeta = (L.ptr(t) for t in (dy, dx, dgamma, dbeta))
     d._keep = (x, y, gamma, beta, stats, red, dy, dx, dgamma, dbeta)
     return d

@@ -240,6 +240,7 @@ class ParamStore:
             off += s.cout
         self.bn_scale = torch.cat(scs).contiguous()
         self.bn_bias = torch.cat(bis).contiguous()
+        self._pack_tab = None        # holds pointers into bn_scale
         self.frozen16 = self.frozen.bfloat16()
         w = self.fview('backbone.conv1.weight')           # [64][7][7][3] -> [64][448], k = tap*8 + c
         wp = torch.zeros(64, 7 * 64, device=dev)
@@ -256,22 +257,35 @@ class ParamStore:
         self.repack_dgrad(sp)
 
     def repack_dgrad(self, sp=None):
+        """All dgrad packs in ONE launch (dsl_pack_dgrad_batched) from a device-resident item table."""
+        import ctypes as C
         lay, total = self.wT_layout()
         if self.wT16 is None or self.wT16.device != self.device:
             self.wT16 = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
+            self._pack_tab = None
         sp = sp or L.stream_ptr()
-        esz = 2
-        for name, (off, n) in lay.items():
-            if name == 'head.cls':
-                w, co, cop, taps, cin, sc = self.tview('head.cls_w'), 80, 128, 9, 256, None
-            elif name == 'head.regctr':
-                w, co, cop, taps, cin, sc = self.tview('head.regctr_w'), 5, 64, 9, 256, None
-            else:
-                s = self.convs[name]
-                w, co, cop, taps, cin = self.tview(name + '.weight'), s.cout, s.cout_pad, s.k * s.k, s.cin
-                sc = self.bn_scale[self.bn_off[s.bn]:] if s.bn else None
-            L.check(L.lib.dsl_pack_dgrad(L.ptr(w), L.ptr(sc), self.wT16.data_ptr() + off * esz, co, cop, taps, cin, sp),
-                    'dsl_pack_dgrad')
+        if getattr(self, '_pack_tab', None) is None:
+            items, start = [], 0
+            for name, (off, n) in lay.items():
+                if name == 'head.cls':
+                    w, co, cop, taps, cin, sc = self.tview('head.cls_w'), 80, 128, 9, 256, None
+                elif name == 'head.regctr':
+                    w, co, cop, taps, cin, sc = self.tview('head.regctr_w'), 5, 64, 9, 256, None
+                else:
+                    s = self.convs[name]
+                    w, co, cop, taps, cin = self.tview(name + '.weight'), s.cout, s.cout_pad, s.k * s.k, s.cin
+                    sc = self.bn_scale[self.bn_off[s.bn]:] if s.bn else None
+                it = L.PackItem()
+                it.w, it.scale, it.out = w.data_ptr(), (sc.data_ptr() if sc is not None else 0), self.wT16.data_ptr() + off * 2
+                it.cout, it.cout_pad, it.taps, it.cin = co, cop, taps, cin
+                it.tiles_ci, it.tiles_co, it.block_start = (cin + 31) // 32, (cop + 31) // 32, start
+                start += it.tiles_ci * it.tiles_co * taps
+                items.append(it)
+            arr = (L.PackItem * len(items))(*items)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+            self._pack_tab = (host.to(self.device), len(items), start)
+        tab, n, blocks = self._pack_tab
+        L.check(L.lib.dsl_pack_dgrad_batched(L.ptr(tab), n, blocks, sp), 'dsl_pack_dgrad_batched')
 
     def refresh(self):
         assert self.device.type == 'cuda', 'the HIP packs live on the GPU'

@@ -129,6 +129,7 @@ typedef struct dsl_gn_desc {
   float* dgamma;          /* fp32 [c], overwritten */
   float* dbeta;           /* fp32 [c], overwritten */
   float* red;             /* fp32 scratch [nseg*n*groups][2] */
+  int32_t prezeroed;      /* 1: caller already zeroed red (and dgamma/dbeta for bwd): skip the memsets */
 } dsl_gn_desc;
 int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream);
 int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream);
@@ -202,6 +203,13 @@ int dsl_cast_bf16(const float* x, void* y, long n, void* stream);
 /* KRSC fp32 -> CRSK bf16 ("dgrad pack"), optional per-cout scale fold. */
 int dsl_pack_dgrad(const float* w, const float* scale, void* out, int cout, int cout_pad, int taps,
                    int cin, void* stream);
+/* the same for many convs in ONE launch: `items` is a DEVICE array of n entries */
+typedef struct dsl_pack_item {
+  const float* w; const float* scale; void* out;
+  int32_t cout, cout_pad, taps, cin;
+  int32_t block_start, tiles_ci, tiles_co, pad_;       /* block_start: prefix sum of tiles_ci*tiles_co*taps */
+} dsl_pack_item;
+int dsl_pack_dgrad_batched(const dsl_pack_item* items_dev, int n, int total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Teacher sweep post-processing (fcos_head.py:406-548, core/post_processing/bbox_nms.py:7-94)
