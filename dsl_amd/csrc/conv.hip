@@ -826,18 +826,50 @@ __device__ __forceinline__ void wait_frags(Frag (&fa)[CT], Frag (&fb)[IT]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// v2 weight gradient: DMA-to-LDS operands, 256-wide tiles, 8 waves.  Same math/outputs as wgrad_kernel.
-template <int BCO, int BCI, int WCO, int WCI>
+// v2 weight gradient: DMA-to-LDS operands, 256-wide tiles, 8 waves, NST-deep ring of KS-pixel stages with
+// counted vmcnt waits (the pixel streams come from HBM: one stage of lookahead does not cover the latency).
+// Same math/outputs as wgrad_kernel.
+struct SegSel {          // per-segment decode constants, selected with v_cndmask chains (no memory access:
+  int px0;               // indexing kernel-argument arrays or LDS tables by a runtime segment id makes hipcc
+  uint32_t m1lo, m1hi, d1, m2lo, m2hi, d2;   // drain the DMA queue with s_waitcnt vmcnt(0) inside the K loop)
+  int sh, sw;
+  long long xoff;
+};
+__device__ __forceinline__ SegSel seg_select(const WgK& p, int gp) {
+  SegSel r;
+  r.px0 = p.pxstart[0];
+  r.m1lo = (uint32_t)p.dhw[0].m; r.m1hi = (uint32_t)(p.dhw[0].m >> 32); r.d1 = p.dhw[0].d;
+  r.m2lo = (uint32_t)p.dwd[0].m; r.m2hi = (uint32_t)(p.dwd[0].m >> 32); r.d2 = p.dwd[0].d;
+  r.sh = p.sh[0]; r.sw = p.sw[0]; r.xoff = p.xoff[0];
+#pragma unroll
+  for (int s = 1; s < DSL_MAX_SEG; ++s) {
+    const bool in = s < p.nseg && gp >= p.pxstart[s];
+    r.px0 = in ? p.pxstart[s] : r.px0;
+    r.m1lo = in ? (uint32_t)p.dhw[s].m : r.m1lo; r.m1hi = in ? (uint32_t)(p.dhw[s].m >> 32) : r.m1hi;
+    r.d1 = in ? p.dhw[s].d : r.d1;
+    r.m2lo = in ? (uint32_t)p.dwd[s].m : r.m2lo; r.m2hi = in ? (uint32_t)(p.dwd[s].m >> 32) : r.m2hi;
+    r.d2 = in ? p.dwd[s].d : r.d2;
+    r.sh = in ? p.sh[s] : r.sh; r.sw = in ? p.sw[s] : r.sw;
+    r.xoff = in ? p.xoff[s] : r.xoff;
+  }
+  return r;
+}
+
+template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
 __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = WCO * WCI;
   constexpr int YB = BCO * 2, XB = BCI * 2;          // bytes per pixel row of each tile
-  constexpr int TILE_Y = 64 * YB, TILE_X = 64 * XB, STAGE = TILE_Y + TILE_X;
+  constexpr int TILE_Y = KS * YB, TILE_X = KS * XB, STAGE = TILE_Y + TILE_X;
   constexpr int NY = TILE_Y / 1024, NX = TILE_X / 1024;      // 1 KB DMA instructions per tile
   constexpr int LY = NY / NW, LX = NX / NW;                   // per wave
+  constexpr int LPT = LY + LX;
   constexpr int CT = BCO / WCO / 32, IT = BCI / WCI / 32;
-  static_assert(NY % NW == 0 && NX % NW == 0, "tile / wave mismatch");
+  constexpr int KK = KS / 16;                                  // MFMA k-steps per stage
+  static_assert(NY % NW == 0 && NX % NW == 0 && LY >= 1 && LX >= 1, "tile / wave mismatch");
   static_assert(YB >= 256 && XB >= 256, "64-byte-chunk swizzle needs >= 4 chunks per row");
+  static_assert(KK == 2 || KK == 4, "stage depth");
+  static_assert((NST - 2) * LPT <= 63 && NST >= 2 && NST <= 4, "vmcnt range");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -860,22 +892,6 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
   const int kt1 = min(kt0 + p.tiles_per_split, p.ktiles);
   const int totpx = p.pxstart[p.nseg];
   const gptr_t zero = (gptr_t)g_zero_line;
-
-  // Per-segment decode constants live in LDS (carved after the stages): indexing the kernel-argument
-  // arrays with a runtime segment id makes hipcc emit vector loads + s_waitcnt vmcnt(0) inside the K loop,
-  // which drains the DMA queue every step.
-  int* segtab = reinterpret_cast<int*>(smem + 2 * STAGE);     // [nseg][12]
-  if (tid < p.nseg) {
-    int* t = segtab + tid * 12;
-    t[0] = p.pxstart[tid];
-    t[1] = (int)(p.dhw[tid].m & 0xffffffffu); t[2] = (int)(p.dhw[tid].m >> 32); t[3] = (int)p.dhw[tid].d;
-    t[4] = (int)(p.dwd[tid].m & 0xffffffffu); t[5] = (int)(p.dwd[tid].m >> 32); t[6] = (int)p.dwd[tid].d;
-    t[7] = p.sh[tid]; t[8] = p.sw[tid];
-    t[9] = (int)(p.xoff[tid] & 0xffffffff); t[10] = (int)(p.xoff[tid] >> 32);
-  }
-  const int px1 = p.nseg > 1 ? p.pxstart[1] : 0x7fffffff, px2 = p.nseg > 2 ? p.pxstart[2] : 0x7fffffff;
-  const int px3 = p.nseg > 3 ? p.pxstart[3] : 0x7fffffff, px4 = p.nseg > 4 ? p.pxstart[4] : 0x7fffffff;
-  __syncthreads();
 
   // per DMA instruction this lane's (row, source channel) inside the tile
   int yrow[LY], ych[LY], xrow[LX], xch[LX];
@@ -904,15 +920,13 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
 
   // Transpose reads are issued through inline asm: given the builtin (an addrspace(3) access) hipcc orders
   // every ds_read behind the in-flight LDS-DMA with s_waitcnt vmcnt(0), which would serialise DMA and MFMA.
-  // The hazards are handled by hand: DMA data is read one barrier after its vmcnt(0); fragment registers are
-  // consumed only after an explicit lgkmcnt(0) + sched_barrier (the MFMA builtins are register-only).
+  // The hazards are handled by hand: DMA data is read one barrier after its counted vmcnt wait; fragment
+  // registers are consumed only after an explicit lgkmcnt(0) naming them.
   const int g16 = lane >> 4, l16 = lane & 15;
   const int iblk = (g16 & 1) * 16, kblk = (g16 >> 1) * 8;
   const int krow_l = kblk + (l16 >> 2);
   const int ccol_l = iblk + 4 * (l16 & 3);
   const unsigned lds_base = (unsigned)(size_t)smem;      // low 32 bits of a flat LDS address = the LDS offset
-  // per-lane byte offsets (within a tile) of the fragment rows for kk = 0, hh = 0; other (kk, hh) add
-  // (kk*16 + hh*4) * rowbytes, and (krow & 3) is unchanged by multiples of 4 rows
   unsigned a_off[CT], b_off[IT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
@@ -960,77 +974,81 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
       for (int it = 0; it < IT; ++it)
         acc[ct][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b[it], acc[ct][it], 0, 0, 0);
   };
-  auto compute = [&](int buf) {
-    const unsigned st = lds_base + buf * STAGE;
+  auto compute = [&](int slot) {
+    const unsigned st = lds_base + slot * STAGE;
     Frag fa0[CT], fb0[IT], fa1[CT], fb1[IT];
     issue(st, 0, fa0, fb0);
     wait_frags<CT, IT>(fa0, fb0);
     issue(st, 1, fa1, fb1);           // next fragments fly while the MFMAs of this step run
     mma(fa0, fb0);
     wait_frags<CT, IT>(fa1, fb1);
-    issue(st, 2, fa0, fb0);
-    mma(fa1, fb1);
-    wait_frags<CT, IT>(fa0, fb0);
-    issue(st, 3, fa1, fb1);
-    mma(fa0, fb0);
-    wait_frags<CT, IT>(fa1, fb1);
+    if constexpr (KK == 4) {
+      issue(st, 2, fa0, fb0);
+      mma(fa1, fb1);
+      wait_frags<CT, IT>(fa0, fb0);
+      issue(st, 3, fa1, fb1);
+      mma(fa0, fb0);
+      wait_frags<CT, IT>(fa1, fb1);
+    }
     mma(fa1, fb1);
   };
 
-  // one loop, DMA for tile kc+1 written inline (a second call site would need a lambda, and hipcc drops the
-  // host stub of this kernel when the DMA address code lives in a lambda)
-  for (int kc = kt0 - 1; kc < kt1; ++kc) {
+  // DMA of one stage (tile index kt -> ring slot): address math first, then the burst of LPT instructions.
+  // Written once and inlined at its single call site inside the loop.
+  int slot_c = 0;                // ring slot of the tile being computed
+  int slot_i = 0;                // ring slot the next DMA goes to
+  for (int kc = kt0 - (NST - 1); kc < kt1; ++kc) {
+    const int kl = kc + NST - 1;             // tile whose DMA is issued in this iteration
     if (kc >= kt0) {
-      // the DMA of tile kc must have landed before anyone reads it: with the LDS reads hidden in inline asm
-      // hipcc no longer emits vmcnt(0) for the barrier's fence on its own
-      wait_vmcnt<0>();
-      __syncthreads();                       // ... and compute(kc-1) is done everywhere
+      // tile kc must have landed: tiles kc+1 .. min(kc+NST-2, kt1-1) may still be in flight
+      const int ahead = min(kt1 - 1 - kc, NST - 2);
+      if (NST >= 4 && ahead >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LPT>();
+      else if (NST >= 3 && ahead >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * LPT>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();          // everyone's part of tile kc landed; compute(kc-1) finished everywhere
     }
-    if (kc + 1 < kt1 && !((p.dbg & 1) && kc >= kt0)) {
-        const int kt = kc + 1, buf = (kt - kt0) & 1;
-        unsigned char* stage = smem + buf * STAGE;
-      // all address math (incl. the LDS table reads) first, while no DMA is outstanding; then the DMA burst
-      long long gx[LX];        // element offset into p.x, -1 = zero line
-  #pragma unroll
-      for (int i = 0; i < LX; ++i) {
-        const int gp = kt * 64 + xrow[i];
-        long long g = -1;
-        if (gp < totpx) {
-          const int seg = (gp >= px1) + (gp >= px2) + (gp >= px3) + (gp >= px4);
-          const int* t = segtab + seg * 12;
-          const uint32_t q = gp - t[0];
-          const uint64_t m1 = ((uint64_t)(uint32_t)t[2] << 32) | (uint32_t)t[1];
-          const uint64_t m2 = ((uint64_t)(uint32_t)t[5] << 32) | (uint32_t)t[4];
+    if (kl < kt1 && !((p.dbg & 1) && kc >= kt0)) {
+      unsigned char* stage = smem + slot_i * STAGE;
+      // every lane decodes ONE pixel row of the stage (row = lane) and the DMA instructions pick their rows'
+      // source offsets up with a lane shuffle: one decode per stage instead of one per DMA instruction
+      int my_off = -1;             // element offset of this row's source pixel (channel ci0), -1 = zero line
+      {
+        const int gp = kl * KS + lane;
+        if (lane < KS && gp < totpx) {
+          const SegSel t = seg_select(p, gp);
+          const uint32_t q = gp - t.px0;
+          const uint64_t m1 = ((uint64_t)t.m1hi << 32) | t.m1lo, m2 = ((uint64_t)t.m2hi << 32) | t.m2lo;
           const uint32_t img = (uint32_t)(((uint64_t)q * m1) >> 40);
-          const uint32_t rem = q - img * (uint32_t)t[3];
+          const uint32_t rem = q - img * t.d1;
           const uint32_t y = (uint32_t)(((uint64_t)rem * m2) >> 40);
-          const uint32_t x = rem - y * (uint32_t)t[6];
-          const int sh = t[7], sw = t[8];
+          const uint32_t x = rem - y * t.d2;
           const int sy = (int)y * p.stride + tr - p.pad, sx = (int)x * p.stride + ts - p.pad;
-          if ((unsigned)sy < (unsigned)sh && (unsigned)sx < (unsigned)sw) {
-            const long long xoff = ((long long)t[10] << 32) | (uint32_t)t[9];
-            const long long pix = xoff + ((long long)img * sh + sy) * sw + sx;
-            g = pix * p.cs + ci0 + xch[i];
-          }
+          if ((unsigned)sy < (unsigned)t.sh && (unsigned)sx < (unsigned)t.sw)
+            my_off = (int)((t.xoff + ((long long)img * t.sh + sy) * t.sw + sx) * p.cs + ci0);
         }
-        gx[i] = g;
       }
-  #pragma unroll
+      int gx[LX];
+#pragma unroll
+      for (int i = 0; i < LX; ++i) gx[i] = __shfl(my_off, xrow[i], 64);
+#pragma unroll
       for (int i = 0; i < LY; ++i) {
-        const int gp = kt * 64 + yrow[i];
+        const int gp = kl * KS + yrow[i];
         const gptr_t g = gp < totpx ? (gptr_t)(p.dy + (long long)gp * p.cy + co0 + ych[i]) : zero;
         __builtin_amdgcn_global_load_lds(g, (lptr_t)(stage + (wave + NW * i) * 1024), 16, 0, 0);
       }
-  #pragma unroll
-      for (int i = 0; i < LX; ++i)
-      {
+#pragma unroll
+      for (int i = 0; i < LX; ++i) {
         // keep the select in a named variable: passing the ?: expression straight into the builtin makes
         // hipcc silently drop this kernel's host stub
-        const gptr_t g = gx[i] >= 0 ? (gptr_t)(p.x + gx[i]) : zero;
+        const gptr_t g = gx[i] >= 0 ? (gptr_t)(p.x + gx[i] + xch[i]) : zero;
         __builtin_amdgcn_global_load_lds(g, (lptr_t)(stage + TILE_Y + (wave + NW * i) * 1024), 16, 0, 0);
       }
     }
-    if (kc >= kt0 && !(p.dbg & 2)) compute((kc - kt0) & 1);
+    if (kl >= kt0) slot_i = (slot_i + 1 == NST) ? 0 : slot_i + 1;
+    if (kc >= kt0) {
+      if (!(p.dbg & 2)) compute(slot_c);
+      slot_c = (slot_c + 1 == NST) ? 0 : slot_c + 1;
+    }
   }
   if (p.dbg & 4) return;
 
@@ -1058,8 +1076,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     const int co = (int)(e / krow);
     const long long k = e - (long long)co * krow;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < splits; ++sp)
-      s += *reinterpret_cast<const f32x4*>(ws + ((long long)sp * cy + co) * krow + k);
+    const long long sstride = (long long)cy * krow;
+    const float* base = ws + (long long)co * krow + k;
+    int sp = 0;
+    for (; sp + 4 <= splits; sp += 4) {      // 4 independent loads in flight per thread
+      const f32x4 a = *reinterpret_cast<const f32x4*>(base + sp * sstride);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(base + (sp + 1) * sstride);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(base + (sp + 2) * sstride);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(base + (sp + 3) * sstride);
+      s += (a + b) + (c + d);
+    }
+    for (; sp < splits; ++sp) s += *reinterpret_cast<const f32x4*>(base + sp * sstride);
     if (scale) s *= scale[co];
     *reinterpret_cast<f32x4*>(dw + e) = s;
   }
@@ -1327,6 +1354,7 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
     xo += (long long)d->n * d->sh[s] * d->sw[s];
   }
   DSL_CHECK(px < (1 << 20), "dsl_conv2d_wgrad: %d pixels exceed the 2^20 fast-division range", px);
+  DSL_CHECK(xo * d->cs < (1LL << 31), "dsl_conv2d_wgrad: X has more than 2^31 elements");
   k.pxstart[d->nseg] = px;
   k.cs = d->cs; k.cy = d->cy; k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad;
   k.ktiles = ktiles;
@@ -1345,22 +1373,27 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
     k.splits = splits;
     { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
     dim3 grid2(k.gx * k.gy * ((splits + 7) / 8) * 8);
-    const size_t lds2 = 2 * (size_t)128 * (bco + bci) + 256;
-#define LAUNCHW(A, B, C_, D)                                                                                          \
+    const int kss[5] = {64, 64, 64, 64, 64}, nsts[5] = {2, 2, 3, 3, 2};
+    const int ks = kss[cfg];
+    // the stage length of this tile configuration defines the K-tile unit
+    k.ktiles = (px + ks - 1) / ks;
+    k.tiles_per_split = (k.ktiles + splits - 1) / splits;
+    const size_t lds2 = (size_t)nsts[cfg] * ks * 2 * (bco + bci);
+#define LAUNCHW(A, B, C_, D, KS_, S_)                                                                                 \
   do {                                                                                                               \
     static bool a_ = false;                                                                                          \
     if (!a_) {                                                                                                       \
-      hipFuncSetAttribute((const void*)wgrad_glds_kernel<A, B, C_, D>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                          (int)lds2);                                                                                \
+      hipFuncSetAttribute((const void*)wgrad_glds_kernel<A, B, C_, D, KS_, S_>,                                      \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                    \
       a_ = true;                                                                                                     \
     }                                                                                                                \
-    hipLaunchKernelGGL((wgrad_glds_kernel<A, B, C_, D>), grid2, dim3(64 * C_ * D), lds2, st, k);                      \
+    hipLaunchKernelGGL((wgrad_glds_kernel<A, B, C_, D, KS_, S_>), grid2, dim3(64 * C_ * D), lds2, st, k);             \
   } while (0)
     switch (cfg) {
-      case 1: LAUNCHW(256, 256, 2, 4); break;
-      case 2: LAUNCHW(256, 128, 4, 2); break;
-      case 3: LAUNCHW(128, 256, 2, 4); break;
-      default: LAUNCHW(128, 128, 2, 2); break;
+      case 1: LAUNCHW(256, 256, 2, 4, 64, 2); break;
+      case 2: LAUNCHW(256, 128, 4, 2, 64, 3); break;
+      case 3: LAUNCHW(128, 256, 2, 4, 64, 3); break;
+      default: LAUNCHW(128, 128, 2, 2, 64, 2); break;
     }
 #undef LAUNCHW
   } else if (bco == 128) {
