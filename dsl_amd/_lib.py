@@ -20,7 +20,7 @@ F5 = C.c_float * MAX_SEG
 CONV_RELU_OUT, CONV_RELU_IN, CONV_OUT_F32, CONV_MASK_FIRST, CONV_MASK_LAST, CONV_ADD_UPSAMPLE, \
     CONV_SMALL_C = 1, 2, 4, 8, 16, 32, 64
 (OP_CONV, OP_WGRAD, OP_GN_FWD, OP_GN_BWD, OP_MAXPOOL, OP_SUM2X2, OP_COLSUM, OP_MEMSET, OP_PACK_IMAGE,
- OP_ASSIGN, OP_LOSS) = range(1, 12)
+ OP_ASSIGN, OP_LOSS, OP_FORK, OP_JOIN) = range(1, 14)
 
 
 class ConvDesc(C.Structure):

@@ -15,12 +15,52 @@ void dsl_set_error(const char* fmt, ...) {
 extern "C" const char* dsl_last_error(void) { return g_err; }
 extern "C" int dsl_version(void) { return 100; }
 
+namespace {
+// one side stream + a ring of events per device, created lazily (host objects, no device memory)
+constexpr int kEvRing = 128;
+hipStream_t g_side[16] = {};
+hipEvent_t g_ev[16][kEvRing] = {};
+int g_evpos[16] = {};
+hipStream_t side_stream(int dev) {
+  if (!g_side[dev]) {
+    hipStreamCreateWithFlags(&g_side[dev], hipStreamNonBlocking);
+    for (int i = 0; i < kEvRing; ++i) hipEventCreateWithFlags(&g_ev[dev][i], hipEventDisableTiming);
+  }
+  return g_side[dev];
+}
+hipEvent_t next_event(int dev) {
+  g_evpos[dev] = (g_evpos[dev] + 1) % kEvRing;
+  return g_ev[dev][g_evpos[dev]];
+}
+}  // namespace
+
 extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
   DSL_CHECK(ops || n_ops == 0, "dsl_run_ops: null op list");
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t main_st = (hipStream_t)stream;
+  int dev = 0;
+  hipGetDevice(&dev);
+  DSL_CHECK(dev >= 0 && dev < 16, "dsl_run_ops: device index %d out of range", dev);
   for (int k = 0; k < n_ops; ++k) {
     const dsl_op& o = ops[k];
     int rc = 0;
+    hipStream_t st = main_st;
+    if (o.i[6] == 1 || o.kind == DSL_OP_FORK || o.kind == DSL_OP_JOIN) {
+      hipStream_t side = side_stream(dev);
+      if (o.kind == DSL_OP_FORK) {
+        hipEvent_t e = next_event(dev);
+        hipEventRecord(e, main_st);
+        hipStreamWaitEvent(side, e, 0);
+        continue;
+      }
+      if (o.kind == DSL_OP_JOIN) {
+        hipEvent_t e = next_event(dev);
+        hipEventRecord(e, side);
+        hipStreamWaitEvent(main_st, e, 0);
+        continue;
+      }
+      st = side;
+    }
+    void* stream = (void*)st;      // shadows the argument: the op goes to the selected stream
     switch (o.kind) {
       case DSL_OP_CONV: rc = dsl_conv2d((const dsl_conv_desc*)o.desc, stream); break;
       case DSL_OP_WGRAD: rc = dsl_conv2d_wgrad((const dsl_wgrad_desc*)o.desc, stream); break;

@@ -42,8 +42,17 @@ class OpList:
     def conv(self, d):
         self._add(L.OP_CONV, d)
 
-    def wgrad(self, d):
-        self._add(L.OP_WGRAD, d)
+    def wgrad(self, d, side=False):
+        """side=True: on the library's side stream, after a FORK (the weight gradient only depends on tensors
+        that are complete at this point and are never overwritten within the step)."""
+        if side:
+            self._add(L.OP_FORK)
+            self._add(L.OP_WGRAD, d, i=(0, 0, 0, 0, 0, 0, 1))
+        else:
+            self._add(L.OP_WGRAD, d)
+
+    def join(self):
+        self._add(L.OP_JOIN)
 
     def gn_fwd(self, d):
         self._add(L.OP_GN_FWD, d)
@@ -232,7 +241,7 @@ class Plan:
         return ptr
 
     # ---------------------------------------------------------------------------------------------
-    def _wgrad(self, ol, spec, dy, x, n, out_hw, in_hw, cy=None, cd=None, wregion=None, bregion=None):
+    def _wgrad(self, ol, spec, dy, x, n, out_hw, in_hw, cy=None, cd=None, wregion=None, bregion=None, side=False):
         st = self.store
         scale = st.bn_ptrs(spec.bn)[0] if (spec is not None and spec.bn) else None
         name = wregion or (spec.name + '.weight')
@@ -246,7 +255,7 @@ class Plan:
                            cs=256 if spec is None else spec.cin, cy=cy or spec.cout_pad, cd=cd or spec.cout,
                            kh=k, kw=k, stride=1 if spec is None else spec.stride, pad=1 if spec is None else spec.pad,
                            scale=scale, db=db, workspace=self._wg_ws(n, out_hw, in_hw, spec, cy))
-        ol.wgrad(d)
+        ol.wgrad(d, side=side)
 
     def _wg_ws(self, n, out_hw, in_hw, spec, cy):
         need = ops.wgrad_workspace_bytes(n=n, grid=out_hw, src_hw=in_hw, cs=256 if spec is None else spec.cin,
@@ -271,12 +280,15 @@ class Plan:
                              addend=addend, lda=cd, mask=mask, ldm=cd, workspace=self.conv_ws)
 
     def _build_backward(self):
+        """Backward op lists.  The data-gradient chain runs on the caller's stream; every weight gradient is
+        forked onto the library's side stream (its inputs - the forward activation and a gradient buffer that is
+        written exactly once per step - are complete at the fork point), so the many small, under-filled
+        backbone launches of the chain overlap with weight-gradient work.  Each segment ends with a JOIN."""
         st, N, ls = self.store, self.N, self.level_sizes
         lp = self.lossplan
         reg = st.train_regions
         M = self.M
-        gA = self.buf('gA', M, 256)
-        gB = self.buf('gB', M, 256)
+        SIDE = True
         g_feats = self.buf('g_feats', M, 256)
         # ================= segment 0: head + FPN =================
         ol = OpList()
@@ -287,28 +299,31 @@ class Plan:
         ol.memset(st.grad.data_ptr() + g0 * 4, (g1 - g0) * 4)
         for ti, tower in enumerate(('cls_convs', 'reg_convs')):
             lays = self.tower[tower]
+            g_act = self.buf(f'g_{tower}_act3', M, 256)
             if tower == 'cls_convs':
                 self._wgrad(ol, None, lp.g_cls, lays[3]['act'], N, ls, ls, cy=128, cd=80, wregion='head.cls_w',
-                            bregion='head.cls_b')
-                ol.conv(self._dgrad('head.cls', lp.g_cls, gA, N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1))
+                            bregion='head.cls_b', side=SIDE)
+                ol.conv(self._dgrad('head.cls', lp.g_cls, g_act, N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1))
             else:
                 self._wgrad(ol, None, lp.g_rc, lays[3]['act'], N, ls, ls, cy=64, cd=5, wregion='head.regctr_w',
-                            bregion='head.regctr_b')
-                ol.conv(self._dgrad('head.regctr', lp.g_rc, gA, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1))
+                            bregion='head.regctr_b', side=SIDE)
+                ol.conv(self._dgrad('head.regctr', lp.g_rc, g_act, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1))
             for i in (3, 2, 1, 0):
                 lay = lays[i]
                 base = lay['gn']
+                g_pre = self.buf(f'g_{tower}_pre{i}', M, 256)
                 gd = ops.gn_desc(lay['pre'], lay['act'], st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'),
-                                 lay['stats'], self._gn_red(), n=N, hw=ls, dy=gA, dx=gB,
+                                 lay['stats'], self._gn_red(), n=N, hw=ls, dy=g_act, dx=g_pre,
                                  dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad))
                 gd.prezeroed = 1
                 ol.gn_bwd(gd)
-                self._wgrad(ol, lay['spec'], gB, lay['xin'], N, ls, ls)
+                self._wgrad(ol, lay['spec'], g_pre, lay['xin'], N, ls, ls, side=SIDE)
                 if i > 0:
-                    ol.conv(self._dgrad(lay['spec'].name, gB, gA, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
+                    g_act = self.buf(f'g_{tower}_act{i - 1}', M, 256)
+                    ol.conv(self._dgrad(lay['spec'].name, g_pre, g_act, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
                 else:
-                    ol.conv(self._dgrad(lay['spec'].name, gB, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1,
-                                        addend=g_feats if ti == 1 else None))
+                    ol.conv(self._dgrad(lay['spec'].name, g_pre, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1,
+                                        pad=1, addend=g_feats if ti == 1 else None))
         # ---- FPN backward ----
         cv = st.convs
         fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
@@ -323,17 +338,17 @@ class Plan:
         s0 = self.buf('s0', N, hw4[0], hw4[1], 256)
         s1 = self.buf('s1', N, hw5[0], hw5[1], 256)
         # P7 = fpn4(relu(P6))
-        self._wgrad(ol, fc[4], gseg[4], p6r, N, [hw7], [hw6])
+        self._wgrad(ol, fc[4], gseg[4], p6r, N, [hw7], [hw6], side=SIDE)
         ol.conv(self._dgrad(fc[4].name, gseg[4], g_p6, N, [hw7], [hw6], cs=256, cd=256, k=3, stride=2, pad=1,
                             addend=gseg[3], mask=p6r, mask_first=True))
         # P6 = fpn3(P5)
-        self._wgrad(ol, fc[3], g_p6, self.feat_seg[2], N, [hw6], [hw5])
+        self._wgrad(ol, fc[3], g_p6, self.feat_seg[2], N, [hw6], [hw5], side=SIDE)
         ol.conv(self._dgrad(fc[3].name, g_p6, g_p5, N, [hw6], [hw5], cs=256, cd=256, k=3, stride=2, pad=1,
                             addend=gseg[2]))
         # P3..P5 = fpn_i(lat_i)
-        self._wgrad(ol, fc[2], g_p5, lat[2], N, [hw5], [hw5])
-        self._wgrad(ol, fc[1], gseg[1], lat[1], N, [hw4], [hw4])
-        self._wgrad(ol, fc[0], gseg[0], lat[0], N, [hw3], [hw3])
+        self._wgrad(ol, fc[2], g_p5, lat[2], N, [hw5], [hw5], side=SIDE)
+        self._wgrad(ol, fc[1], gseg[1], lat[1], N, [hw4], [hw4], side=SIDE)
+        self._wgrad(ol, fc[0], gseg[0], lat[0], N, [hw3], [hw3], side=SIDE)
         ol.conv(self._dgrad(fc[0].name, gseg[0], g_lat[0], N, [hw3], [hw3], cs=256, cd=256, k=3, stride=1, pad=1))
         ol.sum2x2(g_lat[0], s0, N, hw4[0], hw4[1], hw3[0], hw3[1], 256)
         ol.conv(self._dgrad(fc[1].name, gseg[1], g_lat[1], N, [hw4], [hw4], cs=256, cd=256, k=3, stride=1, pad=1,
@@ -346,12 +361,12 @@ class Plan:
         for i, (li, hw) in enumerate(((1, hw3), (2, hw4), (3, hw5))):
             cfeat = self.stage_out[li][0]
             cch = STAGE_PLANES[li] * 4
-            self._wgrad(ol, lc[i], g_lat[i], cfeat, N, [hw], [hw])
-            g0 = self.buf(f'g_stage{li}_0', N, hw[0], hw[1], cch)
-            g1 = self.buf(f'g_stage{li}_1', N, hw[0], hw[1], cch)
-            self.g_stage[li] = [g0, g1]
-            ol.conv(self._dgrad(lc[i].name, g_lat[i], g0, N, [hw], [hw], cs=256, cd=cch, k=1, stride=1, pad=0,
+            self._wgrad(ol, lc[i], g_lat[i], cfeat, N, [hw], [hw], side=SIDE)
+            g0b = self.buf(f'g_stage{li}_last', N, hw[0], hw[1], cch)
+            self.g_stage[li] = g0b
+            ol.conv(self._dgrad(lc[i].name, g_lat[i], g0b, N, [hw], [hw], cs=256, cd=cch, k=1, stride=1, pad=0,
                                 mask=cfeat, mask_first=True))
+        ol.join()
         buckets = st.grad_buckets()
         self.bwd_segments.append((ol, buckets[0]))
         # ================= backbone: layer4, layer3, layer2 =================
@@ -361,34 +376,34 @@ class Plan:
             blks = blocks_by_stage[li]
             hw = blks[0]['out_hw']
             planes = blks[0]['planes']
-            gA1 = self.buf(f'g_l{li}_a1', N, hw[0], hw[1], planes)
-            gA2 = self.buf(f'g_l{li}_a2', N, hw[0], hw[1], planes)
-            gout = self.g_stage[li]
-            cur = 0
+            g_pre = self.g_stage[li]          # gradient w.r.t. the (pre-ReLU-masked) output of the stage's last block
             for blk in reversed(blks):
                 p = blk['prefix']
                 c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
-                g_pre = gout[cur]
-                self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw])
+                gA2 = self.buf(p + '.g_a2', N, hw[0], hw[1], planes)
+                gA1 = self.buf(p + '.g_a1', N, hw[0], hw[1], planes)
+                self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw], side=SIDE)
                 ol.conv(self._dgrad(c3.name, g_pre, gA2, N, [hw], [hw], cs=c3.cout, cd=c3.cin, k=1, stride=1, pad=0,
                                     mask=blk['a2'], mask_last=True))
-                self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw])
+                self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw], side=SIDE)
                 ol.conv(self._dgrad(c2.name, gA2, gA1, N, [hw], [hw], cs=c2.cout, cd=c2.cin, k=3, stride=1, pad=1,
                                     mask=blk['a1'], mask_last=True))
-                self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']])
+                self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE)
                 if blk['b'] > 0:
-                    ol.conv(self._dgrad(c1.name, gA1, gout[cur ^ 1], N, [hw], [hw], cs=c1.cout, cd=c1.cin, k=1, stride=1,
+                    g_prev = self.buf(p + '.g_in', N, hw[0], hw[1], planes * 4)
+                    ol.conv(self._dgrad(c1.name, gA1, g_prev, N, [hw], [hw], cs=c1.cout, cd=c1.cin, k=1, stride=1,
                                         pad=0, addend=g_pre, mask=blk['xin'], mask_last=True))
-                    cur ^= 1
+                    g_pre = g_prev
                 else:
                     ds = cv[p + '.downsample.0']
-                    self._wgrad(ol, ds, g_pre, blk['xin'], N, [hw], [blk['in_hw']])
+                    self._wgrad(ol, ds, g_pre, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE)
                     if li > 1:      # data gradient into the previous stage's output (stride-2 scatter)
-                        tgt = self.g_stage[li - 1][0]
+                        tgt = self.g_stage[li - 1]
                         ihw = blk['in_hw']
                         for spec, dy in ((ds, g_pre), (c1, gA1)):
                             ol.conv(self._dgrad(spec.name, dy, tgt, N, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
+            ol.join()
             self.bwd_segments.append((ol, buckets[4 - li]))
 
     # ---------------------------------------------------------------------------------------------

@@ -238,10 +238,13 @@ int dsl_fcos_detect(const dsl_det_desc* d, void* stream);
  * ---------------------------------------------------------------------------------------- */
 enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, DSL_OP_MAXPOOL = 5,
        DSL_OP_SUM2X2 = 6, DSL_OP_COLSUM = 7, DSL_OP_MEMSET = 8, DSL_OP_PACK_IMAGE = 9,
-       DSL_OP_ASSIGN = 10, DSL_OP_LOSS = 11 };
+       DSL_OP_ASSIGN = 10, DSL_OP_LOSS = 11,
+       DSL_OP_FORK = 12,   /* side stream waits for everything queued so far on the caller's stream */
+       DSL_OP_JOIN = 13 }; /* caller's stream waits for everything queued so far on the side stream */
 typedef struct dsl_op {
   int32_t kind;
-  int32_t i[7];            /* small integer arguments for the simple ops */
+  int32_t i[7];            /* small integer arguments for the simple ops; i[6] = 1: run this op on the library's
+                            * side stream (independent work, e.g. weight gradients, overlapping the main chain) */
   const void* desc;        /* pointer to the op's descriptor (host memory, must stay alive) */
   void* p[4];              /* device pointers for the simple ops */
   int64_t l[2];
