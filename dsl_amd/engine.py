@@ -39,8 +39,11 @@ class OpList:
         self.items.append(o)
         self.arr = None
 
-    def conv(self, d):
-        self._add(L.OP_CONV, d)
+    def conv(self, d, side=False):
+        self._add(L.OP_CONV, d, i=(0, 0, 0, 0, 0, 0, 1 if side else 0))
+
+    def fork(self):
+        self._add(L.OP_FORK)
 
     def wgrad(self, d, side=False):
         """side=True: on the library's side stream, after a FORK (the weight gradient only depends on tensors
@@ -54,8 +57,8 @@ class OpList:
     def join(self):
         self._add(L.OP_JOIN)
 
-    def gn_fwd(self, d):
-        self._add(L.OP_GN_FWD, d)
+    def gn_fwd(self, d, side=False):
+        self._add(L.OP_GN_FWD, d, i=(0, 0, 0, 0, 0, 0, 1 if side else 0))
 
     def gn_bwd(self, d):
         self._add(L.OP_GN_BWD, d)
@@ -208,7 +211,11 @@ class Plan:
         # ---- head: shared weights, all 5 levels per launch ----
         ls = self.level_sizes
         self.tower = {}
+        # the two towers are independent chains: the regression tower (+ its predictor) runs on the side stream
+        self.conv_ws_side = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
+        f.fork()
         for tower in ('cls_convs', 'reg_convs'):
+            side = tower == 'reg_convs'
             xin = feats
             lays = []
             for i in range(4):
@@ -216,12 +223,15 @@ class Plan:
                 pre = self.buf(f'{tower}.{i}.pre', self.M, 256)
                 act = self.buf(f'{tower}.{i}.act', self.M, 256)
                 stats = self.buf(f'{tower}.{i}.stats', 5 * N * 32, 2, dtype=torch.float32)
-                f.conv(self._conv(spec, xin, pre, N, ls, ls))
+                cd_ = self._conv(spec, xin, pre, N, ls, ls)
+                if side:
+                    cd_.workspace, cd_.workspace_bytes = L.ptr(self.conv_ws_side), self.conv_ws_side.numel()
+                f.conv(cd_, side=side)
                 base = f'bbox_head.{tower}.{i}.gn'
                 gd = ops.gn_desc(pre, act, st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'), stats,
                                  self._gn_red(), n=N, hw=ls)
                 gd.prezeroed = 1
-                f.gn_fwd(gd)
+                f.gn_fwd(gd, side=side)
                 lays.append(dict(spec=spec, xin=xin, pre=pre, act=act, stats=stats, gn=base))
                 xin = act
             self.tower[tower] = lays
@@ -232,7 +242,8 @@ class Plan:
                              flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.cls_b'), workspace=self.conv_ws))
         f.conv(ops.conv_desc(self.tower['reg_convs'][3]['act'], st.t16_ptr('head.regctr_w'), regctr, n=N, grid=ls,
                              src_hw=ls, dst_hw=ls, cs=256, cd=5, cd_pad=64, ldd=8, kh=3, kw=3, stride=1, pad=1,
-                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.regctr_b'), workspace=self.conv_ws))
+                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.regctr_b'), workspace=self.conv_ws_side), side=True)
+        f._add(L.OP_JOIN)
 
     def _gn_red(self):
         assert self._gn_next < 16
