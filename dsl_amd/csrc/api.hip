@@ -16,17 +16,17 @@ extern "C" const char* dsl_last_error(void) { return g_err; }
 extern "C" int dsl_version(void) { return 100; }
 
 namespace {
-// one side stream + a ring of events per device, created lazily (host objects, no device memory)
-constexpr int kEvRing = 128;
-hipStream_t g_side[16] = {};
+// side streams + a ring of events per device, created lazily (host objects, no device memory)
+constexpr int kEvRing = 256, kSide = 3;
+hipStream_t g_side[16][kSide] = {};
 hipEvent_t g_ev[16][kEvRing] = {};
 int g_evpos[16] = {};
-hipStream_t side_stream(int dev) {
-  if (!g_side[dev]) {
-    hipStreamCreateWithFlags(&g_side[dev], hipStreamNonBlocking);
-    for (int i = 0; i < kEvRing; ++i) hipEventCreateWithFlags(&g_ev[dev][i], hipEventDisableTiming);
-  }
-  return g_side[dev];
+bool g_init[16] = {};
+void side_init(int dev) {
+  if (g_init[dev]) return;
+  for (int i = 0; i < kSide; ++i) hipStreamCreateWithFlags(&g_side[dev][i], hipStreamNonBlocking);
+  for (int i = 0; i < kEvRing; ++i) hipEventCreateWithFlags(&g_ev[dev][i], hipEventDisableTiming);
+  g_init[dev] = true;
 }
 hipEvent_t next_event(int dev) {
   g_evpos[dev] = (g_evpos[dev] + 1) % kEvRing;
@@ -40,25 +40,23 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
   int dev = 0;
   hipGetDevice(&dev);
   DSL_CHECK(dev >= 0 && dev < 16, "dsl_run_ops: device index %d out of range", dev);
+  auto pick = [&](int id) -> hipStream_t { return id <= 0 ? main_st : g_side[dev][(id - 1) % kSide]; };
   for (int k = 0; k < n_ops; ++k) {
     const dsl_op& o = ops[k];
     int rc = 0;
     hipStream_t st = main_st;
-    if (o.i[6] == 1 || o.kind == DSL_OP_FORK || o.kind == DSL_OP_JOIN) {
-      hipStream_t side = side_stream(dev);
-      if (o.kind == DSL_OP_FORK) {
+    if (o.i[6] > 0 || o.kind == DSL_OP_FORK || o.kind == DSL_OP_JOIN) {
+      side_init(dev);
+      if (o.kind == DSL_OP_FORK || o.kind == DSL_OP_JOIN) {
+        const int side_id = o.i[0] > 0 ? o.i[0] : 1, other = o.i[1];
+        hipStream_t from = o.kind == DSL_OP_FORK ? pick(other) : pick(side_id);
+        hipStream_t to = o.kind == DSL_OP_FORK ? pick(side_id) : pick(other);
         hipEvent_t e = next_event(dev);
-        hipEventRecord(e, main_st);
-        hipStreamWaitEvent(side, e, 0);
+        hipEventRecord(e, from);
+        hipStreamWaitEvent(to, e, 0);
         continue;
       }
-      if (o.kind == DSL_OP_JOIN) {
-        hipEvent_t e = next_event(dev);
-        hipEventRecord(e, side);
-        hipStreamWaitEvent(main_st, e, 0);
-        continue;
-      }
-      st = side;
+      st = pick(o.i[6]);
     }
     void* stream = (void*)st;      // shadows the argument: the op goes to the selected stream
     switch (o.kind) {
@@ -91,15 +89,16 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
 namespace {
 struct ProfRec { hipEvent_t a, b; int cls; double flops; };
 constexpr int kMaxRec = 1 << 15;
-bool g_prof_on = false;
+int g_prof_on = 0;       // 0 off, 1 = only class 0 (the dominant kernel), 2 = every class
 ProfRec* g_rec = nullptr;
 int g_nrec = 0, g_nevents = 0;
 }  // namespace
 
-bool dsl_prof_active() { return g_prof_on; }
+bool dsl_prof_active() { return g_prof_on != 0; }
 
 int dsl_prof_begin(int cls, double flops, hipStream_t st) {
   if (!g_prof_on || g_nrec >= kMaxRec) return -1;
+  if (g_prof_on == 1 && cls != 0) return -1;
   if (!g_rec) g_rec = (ProfRec*)calloc(kMaxRec, sizeof(ProfRec));
   if (g_nrec >= g_nevents) {
     hipEventCreate(&g_rec[g_nrec].a);
@@ -117,7 +116,7 @@ void dsl_prof_end(int id, hipStream_t st) {
 }
 
 extern "C" int dsl_prof_enable(int on) {
-  g_prof_on = on != 0;
+  g_prof_on = on;
   return 0;
 }
 extern "C" int dsl_prof_reset(void) {

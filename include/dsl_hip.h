@@ -239,12 +239,12 @@ int dsl_fcos_detect(const dsl_det_desc* d, void* stream);
 enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, DSL_OP_MAXPOOL = 5,
        DSL_OP_SUM2X2 = 6, DSL_OP_COLSUM = 7, DSL_OP_MEMSET = 8, DSL_OP_PACK_IMAGE = 9,
        DSL_OP_ASSIGN = 10, DSL_OP_LOSS = 11,
-       DSL_OP_FORK = 12,   /* side stream waits for everything queued so far on the caller's stream */
-       DSL_OP_JOIN = 13 }; /* caller's stream waits for everything queued so far on the side stream */
+       DSL_OP_FORK = 12,   /* side stream i[0] (default 1) waits for everything queued so far on stream i[1] (default 0 = caller's) */
+       DSL_OP_JOIN = 13 }; /* stream i[1] (default 0 = caller's) waits for everything queued so far on side stream i[0] (default 1) */
 typedef struct dsl_op {
   int32_t kind;
-  int32_t i[7];            /* small integer arguments for the simple ops; i[6] = 1: run this op on the library's
-                            * side stream (independent work, e.g. weight gradients, overlapping the main chain) */
+  int32_t i[7];            /* small integer arguments for the simple ops; i[6] = s > 0: run this op on the library's
+                            * side stream s (1..3; independent work, e.g. weight gradients, overlapping the main chain) */
   const void* desc;        /* pointer to the op's descriptor (host memory, must stay alive) */
   void* p[4];              /* device pointers for the simple ops */
   int64_t l[2];
@@ -256,6 +256,8 @@ int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream);
  * conv kernels is bracketed by a hipEvent pair on the launch stream.  Classes: 0 = conv_glds_kernel
  * <256,192,4,2,2> (forward + data gradient, the dominant kernel), 1 = every other forward/dgrad conv
  * kernel instance, 2 = the weight-gradient kernels.
+ * dsl_prof_enable(1) brackets only class 0 (cheap enough for a timed region), dsl_prof_enable(2) every class
+ * (event pairs on concurrently running streams perturb the overlap).
  * dsl_prof_read synchronises the events and returns per class: launches, total ms, algorithmic FLOPs.
  * ---------------------------------------------------------------------------------------- */
 #define DSL_PROF_CLASSES 3
