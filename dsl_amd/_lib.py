@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libdsl_hip.so')
+LIB_PATH = os.environ.get('DSL_HIP_LIB') or os.path.join(HERE, 'lib', 'libdsl_hip.so')   # override: kernel ablation builds (tools/)
 MAX_SEG = 5
 
 if not os.path.exists(LIB_PATH):

@@ -12,6 +12,8 @@
 // stores into NHWC.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -612,6 +614,282 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_glds_kernel(const ConvK p
 }
 
 // ================================================================================================
+// v3: software-pipelined DMA-to-LDS implicit GEMM
+//   * `buffer_load_dwordx4 ... lds` with 32-bit per-lane offsets: the padding / ragged-tile zero fill is the
+//     buffer out-of-range rule (offset 0x80000000 -> zeros land in LDS), the per-tap address is one running
+//     per-lane row offset + a scalar (SGPR) column/channel offset, validity is one bit test per pass
+//   * MFMA operand fragments double-buffered in registers: the ds_reads of K-step kk+1 are issued before the
+//     MFMAs of step kk, and the reads of the NEXT tile's step 0 before the MFMAs of this tile's step 3 -
+//     the s_barrier sits inside the MFMA stream instead of in front of an empty pipe
+//   * the ring slot of tile kt is free after its step-3 fragments are in registers, so NST slots hold NST
+//     tiles in flight / in use
+// Not handled here (host routes them to the v1 kernel): data-gradient with stride > 1, kh*kw > 16 per axis
+// limits (kh, kw <= 8), sources >= 2 GiB.
+// ================================================================================================
+template <int NMF, int NDS, int NVM>
+__device__ __forceinline__ void sched_stage() {      // NMF x { 1 MFMA [, 1 DS read for the first NDS] [, 1 VMEM for the first NVM] }
+#pragma unroll
+  for (int i = 0; i < NMF; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if (i < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+  }
+}
+
+template <int BCO, int BPX, int WCO, int WPX, int NST>
+__global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int T = 64 * WCO * WPX;
+  constexpr int RPP = T / 8;                 // tile rows filled per pass (8 lanes per 128-byte row)
+  constexpr int WPASS = BCO / RPP, XPASS = BPX / RPP;
+  constexpr int TILE_W = BCO * 128;
+  constexpr int STAGE = (BCO + BPX) * 128;
+  constexpr int PT = BPX / WPX / 32;         // 32-pixel MFMA tiles per wave
+  static_assert(BCO / WCO == 64, "each wave owns 64 couts");
+  static_assert(BCO % RPP == 0 && BPX % RPP == 0 && (BPX / WPX) % 32 == 0, "tile/thread mismatch");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_co = wave / WPX, wave_px = wave % WPX;
+  const int co0 = blockIdx.x * BCO;
+  const int px0 = blockIdx.y * BPX;
+  const int totpx = p.pxstart[p.nseg];
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ ((tid >> 4) & 7);     // source chunk that belongs in LDS slot (tid & 7) of this row
+
+  // buffer resources: base shifted back by `margin` so that every VALID tap has a non-negative per-lane offset
+  // (the hardware range-checks the per-lane offset, not the scalar one)
+  const unsigned margin = (unsigned)(p.kw * p.cs * 2);
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.src) - margin), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, 0x7fffffff, 0x00020000);
+
+  const int kt0 = blockIdx.z * p.kt_per_split;
+#ifdef DSL_ABLATE_BUILD
+  const int kt1 = (p.dbg & 8) ? kt0 + 1 : min(kt0 + p.kt_per_split, p.ktiles);
+#else
+  const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+#endif
+  int cidx = kt0 % p.kc;
+  int tap_r = (kt0 / p.kc) / p.kw, tap_s = (kt0 / p.kc) % p.kw;
+
+  unsigned r_cur[XPASS], r_step[XPASS], r_mask[XPASS];
+#pragma unroll
+  for (int i = 0; i < XPASS; ++i) {
+    const int gp = px0 + lrow + RPP * i;
+    int seg = 0, img = 0, y = 0, x = 0;
+    const bool ok = gp < totpx;
+    if (ok) decode_pixel(p, gp, seg, img, y, x);
+    const int sh = p.sh[seg], sw = p.sw[seg];
+    const int row0 = p.mode == 0 ? y * p.stride - p.pad : y + p.pad;               // source row of tap r = 0
+    const int col0 = p.mode == 0 ? x * p.stride - p.pad : x + p.pad - (p.kw - 1);  // leftmost source column
+    unsigned m = 0;
+    for (int r = 0; r < p.kh; ++r) {
+      const int sy = p.mode == 0 ? row0 + r : row0 - r;
+      if (ok && (unsigned)sy < (unsigned)sh) m |= 1u << r;
+    }
+    for (int s_ = 0; s_ < p.kw; ++s_) {
+      const int sx = p.mode == 0 ? col0 + s_ : x + p.pad - s_;
+      if (ok && (unsigned)sx < (unsigned)sw) m |= 0x100u << s_;
+    }
+    r_mask[i] = m;
+    const unsigned pitch = (unsigned)(sw * p.cs * 2);
+    r_step[i] = p.mode == 0 ? pitch : 0u - pitch;
+    const unsigned base = (unsigned)(((int)(p.soff[seg]) + img * sh * sw + row0 * sw + col0) * p.cs + chunk * 8) * 2u + margin;
+    r_cur[i] = base + (unsigned)tap_r * r_step[i];
+  }
+  const unsigned w_voff = (unsigned)(lrow * (int)p.wrow + chunk * 8) * 2u;
+  const unsigned w_pass = (unsigned)(RPP * (int)p.wrow) * 2u;
+  unsigned w_soff = (unsigned)(co0 * (int)p.wrow + kt0 * BK) * 2u;
+
+  // ---- DMA of one K tile = LPT "pieces" per thread (XPASS pixel passes, then WPASS weight passes), issued a few at
+  // a time between the MFMAs: a burst of all pieces right after the barrier fills the CU's address queue and
+  // every wave then blocks on issue with an empty MFMA pipe.
+  // Branch-free: past the last tile every lane goes out of range (zeros land in a slot nobody reads), so each
+  // iteration issues exactly LPT DMA instructions and the vmcnt bookkeeping is a compile-time constant.
+  constexpr int LPT = WPASS + XPASS;
+  constexpr int P0 = (LPT + 1) / 3;                   // pieces issued right after the barrier (stage 3)
+  constexpr int P1 = P0 + (LPT - P0 + 1) / 2;         // pieces [P0, P1) in stage 0, [P1, LPT) in stage 1
+  int kt_next = kt0;               // K tile being fetched
+  int ld_slot = 0;                 // ... and the ring slot it goes to
+  auto pieces = [&](auto lo_c, auto hi_c) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+    unsigned char* stage = smem + ld_slot * STAGE;
+    const bool live = kt_next < kt1;
+    const unsigned sel = live ? ((1u << tap_r) | (0x100u << tap_s)) : 0xffffffffu;
+    const unsigned s_off = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.cs * 2 + cidx * 128);
+    const unsigned wv = live ? w_voff : 0x80000000u;
+#pragma unroll
+    for (int j = LO; j < HI; ++j) {
+#ifdef DSL_ABLATE_BUILD
+      if (p.dbg & (j < XPASS ? 1 : 2)) continue;
+#endif
+      if (j < XPASS) {
+        const unsigned v = (r_mask[j] & sel) == sel ? r_cur[j] : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lptr_t)(stage + TILE_W + (j * RPP + wave * 8) * 128), 16, v, s_off, 0, 0);
+      } else {
+        const int i = j - XPASS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lptr_t)(stage + (i * RPP + wave * 8) * 128), 16, wv,
+                                                 w_soff + i * w_pass, 0, 0);
+      }
+    }
+    if (HI == LPT) {               // tile fully issued: advance to the next (r, s, channel-block) and ring slot
+      ++kt_next;
+      ld_slot = (ld_slot + 1 == NST) ? 0 : ld_slot + 1;
+      w_soff += BK * 2;
+      const bool c_wrap = cidx + 1 == p.kc;
+      const bool s_wrap = c_wrap && tap_s + 1 == p.kw;
+      cidx = c_wrap ? 0 : cidx + 1;
+      tap_s = s_wrap ? 0 : (c_wrap ? tap_s + 1 : tap_s);
+      tap_r += s_wrap ? 1 : 0;
+      const unsigned adv = s_wrap ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int i = 0; i < XPASS; ++i) r_cur[i] += r_step[i] & adv;
+    }
+  };
+  using c0_t = std::integral_constant<int, 0>;
+  using cp0_t = std::integral_constant<int, P0>;
+  using cp1_t = std::integral_constant<int, P1>;
+  using clpt_t = std::integral_constant<int, LPT>;
+
+  f32x16 acc[2][PT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int fswz = (frow >> 1) & 7;
+  const int a_off = (wave_co * 64 + frow) * 128;
+  const int b_off = TILE_W + (wave_px * (32 * PT) + frow) * 128;
+  bf16x8 fa[2][2], fb[2][PT];
+  auto lds_read = [&](const unsigned char* base, int kk, int f) {
+    const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) fa[f][ct] = *reinterpret_cast<const bf16x8*>(base + a_off + ct * 32 * 128 + coff);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) fb[f][pt] = *reinterpret_cast<const bf16x8*>(base + b_off + pt * 32 * 128 + coff);
+  };
+  auto mma_half = [&](int f, int ct) {
+#ifdef DSL_ABLATE_BUILD
+    if (p.dbg & 4) return;
+#endif
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+      acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
+  };
+  auto mma = [&](int f) {
+    mma_half(f, 0);
+    mma_half(f, 1);
+  };
+
+  static_assert((NST - 1) * LPT <= 63, "vmcnt range");
+  // prologue: NST-1 whole tiles + the first pieces of the NST-th
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) pieces(c0_t{}, clpt_t{});
+  pieces(c0_t{}, cp0_t{});
+  wait_vmcnt<(NST - 2) * LPT + P0>();
+  __builtin_amdgcn_s_barrier();
+  lds_read(smem, 0, 0);
+  int slot = 0;
+  for (int kt = kt0; kt < kt1 - 1; ++kt) {
+    const unsigned char* base = smem + slot * STAGE;
+    const int nslot = (slot + 1 == NST) ? 0 : slot + 1;
+    lds_read(base, 1, 1);
+    pieces(cp0_t{}, cp1_t{});
+    mma(0);
+    lds_read(base, 2, 0);
+    pieces(cp1_t{}, clpt_t{});
+    mma(1);
+    lds_read(base, 3, 1);
+    mma(0);
+    mma_half(1, 0);
+    sched_stage<2 * PT, 2 + PT, P1 - P0>();
+    sched_stage<2 * PT, 2 + PT, LPT - P1>();
+    sched_stage<2 * PT, 2 + PT, 0>();
+    sched_stage<PT, 0, 0>();
+    __builtin_amdgcn_sched_barrier(0);     // keep these MFMAs in front of the waits below
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tile kt are in registers (issued >= PT MFMAs ago)
+    wait_vmcnt<(NST - 2) * LPT>();         // tile kt+1 landed (tiles kt+2 .. kt+NST-1 may stay in flight)
+    __builtin_amdgcn_s_barrier();          // ... and both hold for every wave
+    lds_read(smem + nslot * STAGE, 0, 0);
+    pieces(c0_t{}, cp0_t{});               // start refilling the slot tile kt just vacated with tile kt+NST
+    mma_half(1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + PT, 0);
+    sched_stage<PT, 0, P0>();
+    slot = nslot;
+  }
+  {                                        // last tile
+    const unsigned char* base = smem + slot * STAGE;
+    lds_read(base, 1, 1);
+    mma(0);
+    lds_read(base, 2, 0);
+    mma(1);
+    lds_read(base, 3, 1);
+    mma(0);
+    mma(1);
+    sched_stage<2 * PT, 2 + PT, 0>();
+    sched_stage<2 * PT, 2 + PT, 0>();
+    sched_stage<2 * PT, 2 + PT, 0>();
+  }
+  wait_vmcnt<0>();                         // the out-of-range tail DMAs still write (zeros) into the ring
+#ifdef DSL_ABLATE_BUILD
+  if (p.dbg & 16) return;
+#endif
+
+  if (p.splits > 1) {                      // split-K: raw fp32 partial tile -> workspace [split][pixel][cd_pad]
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int gp = px0 + wave_px * (32 * PT) + pt * 32 + (lane & 31);
+      if (gp >= totpx) continue;
+      float* row = p.ws + ((long long)blockIdx.z * totpx + gp) * p.cd_pad;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = co0 + wave_co * 64 + ct * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(row + co) = o;
+        }
+    }
+    return;
+  }
+
+  // ---- epilogue staged through LDS (see conv_glds_kernel)
+  constexpr int ROWB = BCO * 4 + 16;
+  constexpr int CPX = 32 * WPX;
+  constexpr int GPR = BCO / 8;
+  static_assert(CPX * ROWB <= NST * STAGE, "epilogue staging must fit in the stage memory");
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wave_co * 64 + ct * 32 + 8 * g + 4 * fhalf;
+        f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
+      }
+    __syncthreads();
+    for (int id = tid; id < CPX * GPR; id += T) {
+      const int pl = id / GPR, cg = id - pl * GPR;
+      const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
+      const int co = co0 + cg * 8;
+      if (gp >= totpx || co >= p.cd) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32 + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      long long dpix, apix;
+      conv_out_index(p, gp, dpix, apix);
+      conv_epilogue8(p, dpix, apix, co, v);
+    }
+  }
+}
+
+// ================================================================================================
 // weight gradient
 // ================================================================================================
 struct WgK {
@@ -1110,7 +1388,12 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
   const int force = (d->flags >> 8) & 15;          // test hook: 1..5 = v2 config, 15 = v1 kernel
   const int force_split = (d->flags >> 12) & 15;   // test hook: split-K factor
   int pick = -1, splits = 1;
-  const bool v1_only = smallc || (d->flags & DSL_CONV_RELU_IN);
+  long long src_px = 0;
+  for (int sg = 0; sg < d->nseg; ++sg) src_px += (long long)d->n * d->sh[sg] * d->sw[sg];
+  // the DMA kernels address the source with 32-bit buffer offsets and per-axis tap masks
+  const bool dma_ok = !(d->mode == 1 && d->stride > 1) && d->kh <= 8 && d->kw <= 8 &&
+                      src_px * d->cs * 2 + (long long)d->kw * d->cs * 2 < 0x7fff0000LL;
+  const bool v1_only = smallc || (d->flags & DSL_CONV_RELU_IN) || !dma_ok;
   if (!v1_only && force != 15) {
     double best = 1e300;
     for (int c = 0; c < kNumCfg; ++c) {
@@ -1239,14 +1522,36 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     }                                                                                                         \
     hipLaunchKernelGGL((conv_glds_kernel<A, B, C_, D, S_>), grid, dim3(64 * C_ * D), lds, st, k);              \
   } while (0)
-    switch (pick) {
-      case 0: LAUNCH2(256, 192, 4, 2, 2); break;
-      case 1: LAUNCH2(256, 128, 4, 2, 3); break;
-      case 2: LAUNCH2(128, 256, 2, 4, 3); break;
-      case 3: LAUNCH2(128, 128, 2, 2, 2); break;
-      default: LAUNCH2(64, 256, 1, 4, 2); break;
+#define LAUNCH3(A, B, C_, D, S_)                                                                               \
+  do {                                                                                                        \
+    static bool attr_set3 = false;                                                                            \
+    if (!attr_set3) {                                                                                         \
+      hipFuncSetAttribute((const void*)conv_pipe_kernel<A, B, C_, D, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)lds);                                                                          \
+      attr_set3 = true;                                                                                       \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_>), grid, dim3(64 * C_ * D), lds, st, k);              \
+  } while (0)
+    static const bool use_v2 = getenv("DSL_CONV_V2") != nullptr;
+    if (use_v2) {
+      switch (pick) {
+        case 0: LAUNCH2(256, 192, 4, 2, 2); break;
+        case 1: LAUNCH2(256, 128, 4, 2, 3); break;
+        case 2: LAUNCH2(128, 256, 2, 4, 3); break;
+        case 3: LAUNCH2(128, 128, 2, 2, 2); break;
+        default: LAUNCH2(64, 256, 1, 4, 2); break;
+      }
+    } else {
+      switch (pick) {
+        case 0: LAUNCH3(256, 192, 4, 2, 2); break;
+        case 1: LAUNCH3(256, 128, 4, 2, 3); break;
+        case 2: LAUNCH3(128, 256, 2, 4, 3); break;
+        case 3: LAUNCH3(128, 128, 2, 2, 2); break;
+        default: LAUNCH3(64, 256, 1, 4, 2); break;
+      }
     }
 #undef LAUNCH2
+#undef LAUNCH3
     dsl_prof_end(prof, st);
     if (splits > 1) {
       const long long total = (long long)px * (d->cd_pad / 4);
