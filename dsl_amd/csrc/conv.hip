@@ -766,6 +766,9 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   const int b_off = TILE_W + (wave_px * (32 * PT) + frow) * 128;
   bf16x8 fa[2][2], fb[2][PT];
   auto lds_read = [&](const unsigned char* base, int kk, int f) {
+#ifdef DSL_ABLATE_BUILD
+    if (p.dbg & 64) return;
+#endif
     const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) fa[f][ct] = *reinterpret_cast<const bf16x8*>(base + a_off + ct * 32 * 128 + coff);
@@ -813,6 +816,9 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
     __builtin_amdgcn_sched_barrier(0);     // keep these MFMAs in front of the waits below
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tile kt are in registers (issued >= PT MFMAs ago)
     wait_vmcnt<(NST - 2) * LPT>();         // tile kt+1 landed (tiles kt+2 .. kt+NST-1 may stay in flight)
+#ifdef DSL_ABLATE_BUILD
+    if (!(p.dbg & 32))
+#endif
     __builtin_amdgcn_s_barrier();          // ... and both hold for every wave
     lds_read(smem + nslot * STAGE, 0, 0);
     pieces(c0_t{}, cp0_t{});               // start refilling the slot tile kt just vacated with tile kt+NST
@@ -1376,47 +1382,67 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // host side
 // ================================================================================================
 namespace {
-// v2 (DMA-to-LDS) tile configurations {BCO, BPX, workgroups per CU, relative per-CU rate}
-struct TileCfg { int bco, bpx, occ, nst; double rate; };
-constexpr int kNumCfg = 5;
-const TileCfg kCfgs[kNumCfg] = {{256, 192, 1, 2, 1.00}, {256, 128, 1, 3, 0.90}, {128, 256, 1, 3, 0.90},
-                                {128, 128, 2, 2, 0.75}, {64, 256, 2, 2, 0.60}};
+// DMA-to-LDS tile configurations {BCO, BPX, workgroups per CU, ring depth}
+struct TileCfg { int bco, bpx, occ, nst; };
+constexpr int kNumCfg = 6;
+const TileCfg kCfgs[kNumCfg] = {{256, 192, 1, 2}, {256, 128, 1, 3}, {128, 256, 1, 3}, {128, 128, 2, 2}, {64, 256, 2, 2},
+                                {128, 64, 2, 3}};
+
+// strided data-gradients gather with per-tap divisibility tests: only the v2 kernel's general address path does that
+inline bool conv_v2_only(const dsl_conv_desc* d) { return d->mode == 1 && d->stride > 1; }
+
+// Launch-time cost model (microseconds) of one (tile config, split-K factor) choice.  Calibrated on MI355X
+// (tools/ablate_pipe.py, tools/bench_conv.py): per K tile a workgroup needs bco*bpx/32 MFMA cycles of its CU and
+// (bco+bpx)*128 B through the CU's 64 B/clk vector-memory path (~54 B/clk measured); co-resident workgroups share
+// both; the two overlap imperfectly.  Output and split-K partial traffic are HBM-rate terms.
+double conv_cost_us(const TileCfg& c, long long px, int cd_pad, int ktiles, int sp, bool out_f32) {
+  const long long wgs = (long long)(cd_pad / c.bco) * ((px + c.bpx - 1) / c.bpx) * sp;
+  const long long slots = 256LL * c.occ;
+  const long long rounds = (wgs + slots - 1) / slots;
+  const long long per_cu = (wgs + 255) / 256;
+  const double share = (double)(per_cu < c.occ ? per_cu : c.occ);     // workgroups sharing a CU in a round
+  const double mfma = c.bco * c.bpx / 32.0, dma = (c.bco + c.bpx) * 128 / 54.0;
+  const double tile = share * (1.15 * (mfma > dma ? mfma : dma) + 0.5 * (mfma > dma ? dma : mfma));
+  const int kt = (ktiles + sp - 1) / sp;
+  double t = 4.0 + rounds * (kt * tile + 2500.0) / 2240.0;            // launch + prologue, main loop at ~2.24 GHz
+  t += (double)px * cd_pad * (out_f32 ? 4 : 2) / 4.0e6;                // output write
+  if (sp > 1) t += 3.0 + 2.0 * sp * px * cd_pad * 4 / 4.0e6;          // partial write + read, second launch
+  return t;
+}
 
 // picks the tile configuration (-1 = v1 kernel) and the split-K factor for a conv
 void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out, int* splits_out) {
   const bool smallc = (d->flags & DSL_CONV_SMALL_C) != 0;
-  const int force = (d->flags >> 8) & 15;          // test hook: 1..5 = v2 config, 15 = v1 kernel
+  const int force = (d->flags >> 8) & 15;          // test hook: 1..6 = tile config, 15 = v1 kernel
   const int force_split = (d->flags >> 12) & 15;   // test hook: split-K factor
   int pick = -1, splits = 1;
   long long src_px = 0;
   for (int sg = 0; sg < d->nseg; ++sg) src_px += (long long)d->n * d->sh[sg] * d->sw[sg];
   // the DMA kernels address the source with 32-bit buffer offsets and per-axis tap masks
-  const bool dma_ok = !(d->mode == 1 && d->stride > 1) && d->kh <= 8 && d->kw <= 8 &&
-                      src_px * d->cs * 2 + (long long)d->kw * d->cs * 2 < 0x7fff0000LL;
+  const bool dma_ok = conv_v2_only(d) || (d->kh <= 8 && d->kw <= 8 && src_px * d->cs * 2 + (long long)d->kw * d->cs * 2 < 0x7fff0000LL);
   const bool v1_only = smallc || (d->flags & DSL_CONV_RELU_IN) || !dma_ok;
   if (!v1_only && force != 15) {
     double best = 1e300;
+    const bool out_f32 = (d->flags & DSL_CONV_OUT_F32) != 0;
     for (int c = 0; c < kNumCfg; ++c) {
       if (d->cd_pad % kCfgs[c].bco) continue;
       if (force >= 1 && force <= kNumCfg && force - 1 != c) continue;
-      const long long wgs = (long long)(d->cd_pad / kCfgs[c].bco) * ((px + kCfgs[c].bpx - 1) / kCfgs[c].bpx);
-      const long long slots = 256LL * kCfgs[c].occ;
-      int sp = 1;
-      if (d->workspace && wgs * 2 <= slots && ktiles >= 16) {
-        sp = (int)((slots + wgs - 1) / wgs);
-        if (sp > ktiles / 4) sp = ktiles / 4;
-        if (sp > 16) sp = 16;
-        while (sp > 1 && (size_t)sp * px * d->cd_pad * 4 > d->workspace_bytes) --sp;
-        if (sp < 1) sp = 1;
+      if (c == 5 && conv_v2_only(d)) continue;       // the 128x64 tile exists for the pipelined kernel only
+      for (int sp = 1; sp <= 16; ++sp) {
+        if (sp > 1 && (!d->workspace || sp > ktiles / 2 || (size_t)sp * px * d->cd_pad * 4 > d->workspace_bytes)) break;
+        if (force_split > 1 && sp != force_split) continue;
+        const double t = conv_cost_us(kCfgs[c], px, d->cd_pad, ktiles, sp, out_f32);
+        if (t < best) { best = t; pick = c; splits = sp; }
       }
-      const long long rounds = (wgs * sp + slots - 1) / slots;
-      double t = (double)rounds * kCfgs[c].occ * kCfgs[c].bco * kCfgs[c].bpx / kCfgs[c].rate / sp;
-      if (sp > 1) t += 0.02 * kCfgs[c].bco * kCfgs[c].bpx;      // second pass + launch
-      if (t < best) { best = t; pick = c; splits = sp; }
     }
-    if (pick >= 0 && force_split > 1 && d->workspace && (size_t)force_split * px * d->cd_pad * 4 <= d->workspace_bytes &&
-        force_split <= ktiles)
-      splits = force_split;
+    if (pick < 0 && force_split > 1) {               // forced split not feasible: ignore it
+      for (int c = 0; c < kNumCfg; ++c) {
+        if (d->cd_pad % kCfgs[c].bco || (force >= 1 && force <= kNumCfg && force - 1 != c)) continue;
+        if (c == 5 && conv_v2_only(d)) continue;
+        const double t = conv_cost_us(kCfgs[c], px, d->cd_pad, ktiles, 1, out_f32);
+        if (t < best) { best = t; pick = c; splits = 1; }
+      }
+    }
   }
   *pick_out = pick;
   *splits_out = splits;
@@ -1532,8 +1558,8 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     }                                                                                                         \
     hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_>), grid, dim3(64 * C_ * D), lds, st, k);              \
   } while (0)
-    static const bool use_v2 = getenv("DSL_CONV_V2") != nullptr;
-    if (use_v2) {
+    static const bool force_v2 = getenv("DSL_CONV_V2") != nullptr;
+    if (force_v2 || conv_v2_only(d)) {
       switch (pick) {
         case 0: LAUNCH2(256, 192, 4, 2, 2); break;
         case 1: LAUNCH2(256, 128, 4, 2, 3); break;
@@ -1547,7 +1573,8 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
         case 1: LAUNCH3(256, 128, 4, 2, 3); break;
         case 2: LAUNCH3(128, 256, 2, 4, 3); break;
         case 3: LAUNCH3(128, 128, 2, 2, 2); break;
-        default: LAUNCH3(64, 256, 1, 4, 2); break;
+        case 4: LAUNCH3(64, 256, 1, 4, 2); break;
+        default: LAUNCH3(128, 64, 2, 2, 3); break;
       }
     }
 #undef LAUNCH2
