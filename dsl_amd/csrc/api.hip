@@ -150,3 +150,20 @@ extern "C" int dsl_probe_tr16(const uint16_t* img, const int32_t* lane_off, uint
   DSL_LAUNCH_CHECK("probe_tr16_kernel");
   return 0;
 }
+
+// ---- probe: XCC id of each workgroup + XCD-local (workgroup-scope, L2-resident) float atomics --------------
+// The XCD-aware workgroup mappings of the conv / wgrad kernels assume block b runs on XCD b % 8; this probe pins
+// that (HW_REG_XCC_ID) and that workgroup-scope global_atomic_add_f32 into per-XCD buffers is complete after the
+// kernel.
+__global__ void probe_xcc_kernel(int* xcc_of_block, float* acc /* [8][256] */) {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+  if (threadIdx.x == 0) xcc_of_block[blockIdx.x] = (int)x;
+  __hip_atomic_fetch_add(acc + (x & 7) * 256 + threadIdx.x, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+extern "C" int dsl_probe_xcc(int32_t* xcc_of_block, float* acc, int nblocks, void* stream) {
+  hipLaunchKernelGGL(probe_xcc_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, xcc_of_block, acc);
+  DSL_LAUNCH_CHECK("probe_xcc_kernel");
+  return 0;
+}

@@ -908,6 +908,7 @@ struct WgK {
   int ktiles, tiles_per_split, ctiles_per_tap;
   int dbg;                  // ablation knobs (DSL_ABLATE env): 1 = skip DMA after the first tile, 2 = skip MFMA
   int gx, gy, splits;       // v2: workgroup grid (cout tiles, column tiles) and split count for the XCD-aware 1-D launch
+  int chunk;                // v2: consecutive work items (split-major) per XCD
   long long krow;
   const uint16_t* dy;
   const uint16_t* x;
@@ -1158,14 +1159,15 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_co = wave / WCI, wave_ci = wave % WCI;
-  // XCD-aware work mapping (block b runs on XCD b % 8): all (cout tile, tap, cin tile) workgroups of one
-  // pixel split share an XCD, so its dY / X pixel range is fetched into that XCD's L2 once instead of once
-  // per tap.  Placement only affects speed.
+  // XCD-aware work mapping (block b runs on XCD b % 8): the (cout tile, tap, cin tile) workgroups of one pixel
+  // split are neighbours on one XCD, so its dY / X pixel range is fetched into that XCD's L2 once instead of
+  // once per tap.  Placement only affects speed.
   const int tiles_per_split_wg = p.gx * p.gy;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int sp = xcd + 8 * (jj / tiles_per_split_wg);
-  if (sp >= p.splits) return;
-  const int rem_wg = jj % tiles_per_split_wg;
+  const int witem = xcd * p.chunk + jj;              // work items are split-major: an XCD owns a contiguous range
+  if (jj >= p.chunk || witem >= tiles_per_split_wg * p.splits) return;
+  const int sp = witem / tiles_per_split_wg;
+  const int rem_wg = witem - sp * tiles_per_split_wg;
   const int co0 = (rem_wg % p.gx) * BCO;
   const int colt = rem_wg / p.gx;
   const int ctiles = p.cs / BCI;
@@ -1644,9 +1646,19 @@ static int wgrad_geometry(const dsl_wgrad_desc* d, int* ktiles, int* tiles, int*
 extern "C" int dsl_wgrad_splits(const dsl_wgrad_desc* d) {
   int ktiles, tiles, bco;
   const int cfg = wgrad_geometry(d, &ktiles, &tiles, &bco);
-  const int target = (cfg == 0 || cfg == 4) ? 768 : 300;     // 2 small workgroups per CU vs one 8-wave workgroup
-  int splits = (target + tiles - 1) / tiles;
   const int max_by_k = ktiles / 4 > 0 ? ktiles / 4 : 1;    // at least 4 K stages per split
+  int splits;
+  if (cfg == 0) {
+    splits = (768 + tiles - 1) / tiles;                    // v1: 2-3 small workgroups per CU
+  } else {
+    const int per_cu = cfg == 4 ? 2 : 1;                   // 128x128 tiles: two workgroups per CU
+    // one full round, never a nearly-empty second one.  (Accumulating the split partials with XCD-local L2 float
+    // atomics instead of writing them out was measured: 117 vs 85 us on the head shape - L2 atomics retire about
+    // two lanes per clock per channel.)
+    splits = 256 * per_cu / tiles;
+    if (splits < 1) splits = 1;
+  }
+  if (const char* e = getenv("DSL_WGRAD_SPLITS")) { const int v = atoi(e); if (v > 0 && cfg != 0) splits = v; }
   if (splits > max_by_k) splits = max_by_k;
   if (splits < 1) splits = 1;
   if (splits > 256) splits = 256;
@@ -1704,7 +1716,8 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
     k.gy = d->kh * d->kw * d->cs / bci;
     k.splits = splits;
     { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
-    dim3 grid2(k.gx * k.gy * ((splits + 7) / 8) * 8);
+    k.chunk = (k.gx * k.gy * splits + 7) / 8;
+    dim3 grid2(k.chunk * 8);
     const int kss[5] = {64, 64, 64, 64, 64}, nsts[5] = {2, 2, 3, 3, 2};
     const int ks = kss[cfg];
     // the stage length of this tile configuration defines the K-tile unit

@@ -268,6 +268,9 @@ int dsl_prof_read(int64_t* launches, double* ms, double* flops);
 /* hardware probes used by the tests */
 int dsl_probe_tr16(const uint16_t* lds_image /* 4096 u16 */, const int32_t* lane_off /* 64 u16-offsets */,
                    uint16_t* out /* [64][4] */, void* stream);
+/* xcc_of_block[b] = HW_REG_XCC_ID of workgroup b; every workgroup adds 1.0 to acc[xcc][0..255] (8 x 256 floats,
+ * zeroed by the caller) with workgroup-scope atomics */
+int dsl_probe_xcc(int32_t* xcc_of_block, float* acc, int nblocks, void* stream);
 
 #ifdef __cplusplus
 }

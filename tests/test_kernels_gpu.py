@@ -53,6 +53,25 @@ def sync():
     torch.cuda.synchronize()
 
 
+@pytest.mark.gpu
+def test_probe_xcc_local_atomics(K):
+    """Workgroup b runs on XCD b % 8 (what the XCD-aware tile mappings of the conv / wgrad kernels assume) and
+    workgroup-scope float atomics into per-XCD buffers are complete after the kernel."""
+    L, _ = K
+    nb = 4096
+    xcc = torch.full((nb,), -1, dtype=torch.int32, device='cuda')
+    acc = torch.zeros(8, 256, dtype=torch.float32, device='cuda')
+    L.check(L.lib.dsl_probe_xcc(L.ptr(xcc), L.ptr(acc), nb, L.stream_ptr()))
+    torch.cuda.synchronize()
+    x = xcc.cpu()
+    assert int(x.min()) >= 0 and int(x.max()) <= 7
+    counts = torch.bincount(x.long(), minlength=8).float()
+    assert (counts > 0).all(), counts
+    assert torch.equal(x, torch.arange(nb, dtype=torch.int32) % 8)
+    assert torch.equal(acc.cpu(), counts[:, None].expand(8, 256)), (acc[:, 0].cpu(), counts)
+    print('blocks per XCD', counts.tolist(), 'block->xcc head', x[:16].tolist())
+
+
 # ------------------------------------------------------------------------------------------------
 def test_probe_tr16(K):
     """Documents the ds_read_b64_tr_b16 semantics the weight-gradient kernel relies on:

@@ -85,3 +85,14 @@ print(f"{'list':5s} {'op':52s} {'us':>7s} {'TF':>6s} {'GB/s':>6s} {'floor':>6s} 
 for r in sorted(rows, key=lambda r: -(r[2] - r[5])):
     lname, desc, t, fl, by, floor = r
     print(f'{lname:5s} {desc:52s} {t*1e6:7.1f} {fl/t/1e12:6.0f} {by/t/1e9:6.0f} {floor*1e6:6.1f} {(t-floor)*1e6:6.1f}')
+
+cats = {}
+for lname, desc, t, fl, by, floor in rows:
+    k = desc.split()[0] + (' ' + desc.split()[1] if desc.split()[0] in ('conv', 'dgrad', 'wgrad') else '')
+    a = cats.setdefault(k, [0, 0.0, 0.0])
+    a[0] += 1
+    a[1] += t
+    a[2] += floor
+print('# by category: count, standalone ms, floor ms')
+for k, (c, t, f) in sorted(cats.items(), key=lambda kv: -kv[1][1]):
+    print(f'#   {k:12s} {c:4d} {t*1e3:7.3f} {f*1e3:7.3f}')
