@@ -20,7 +20,8 @@ F5 = C.c_float * MAX_SEG
 CONV_RELU_OUT, CONV_RELU_IN, CONV_OUT_F32, CONV_MASK_FIRST, CONV_MASK_LAST, CONV_ADD_UPSAMPLE, \
     CONV_SMALL_C = 1, 2, 4, 8, 16, 32, 64
 (OP_CONV, OP_WGRAD, OP_GN_FWD, OP_GN_BWD, OP_MAXPOOL, OP_SUM2X2, OP_COLSUM, OP_MEMSET, OP_PACK_IMAGE,
- OP_ASSIGN, OP_LOSS, OP_FORK, OP_JOIN) = range(1, 14)
+ OP_ASSIGN, OP_LOSS, OP_FORK, OP_JOIN, OP_WGRAD_GROUP, OP_RECORD, OP_WAIT) = range(1, 17)
+MAX_GROUP = 8
 
 
 class ConvDesc(C.Structure):
@@ -95,13 +96,15 @@ class Op(C.Structure):
 
 lib.dsl_last_error.restype = C.c_char_p
 lib.dsl_wgrad_workspace_bytes.restype = C.c_size_t
+if hasattr(lib, 'dsl_wgrad_group_workspace_bytes'):
+    lib.dsl_wgrad_group_workspace_bytes.restype = C.c_size_t
 lib.dsl_conv2d_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_detect_workspace_bytes'):
     lib.dsl_detect_workspace_bytes.restype = C.c_size_t
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
     'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_workspace_bytes': [_vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
-    'dsl_wgrad_workspace_bytes': [_vp],
+    'dsl_wgrad_workspace_bytes': [_vp], 'dsl_wgrad_group_workspace_bytes': [_vp, _i], 'dsl_conv2d_wgrad_group': [_vp, _i, _vp],
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
     'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp],
     'dsl_sum2x2': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], 'dsl_colsum': [_vp, _vp, _l, _i, _i, _vp],

@@ -22,10 +22,13 @@ hipStream_t g_side[16][kSide] = {};
 hipEvent_t g_ev[16][kEvRing] = {};
 int g_evpos[16] = {};
 bool g_init[16] = {};
+hipEvent_t g_named[16][16] = {};        // DSL_OP_RECORD / DSL_OP_WAIT slots
+bool g_named_set[16][16] = {};
 void side_init(int dev) {
   if (g_init[dev]) return;
   for (int i = 0; i < kSide; ++i) hipStreamCreateWithFlags(&g_side[dev][i], hipStreamNonBlocking);
   for (int i = 0; i < kEvRing; ++i) hipEventCreateWithFlags(&g_ev[dev][i], hipEventDisableTiming);
+  for (int i = 0; i < 16; ++i) hipEventCreateWithFlags(&g_named[dev][i], hipEventDisableTiming);
   g_init[dev] = true;
 }
 hipEvent_t next_event(int dev) {
@@ -45,6 +48,17 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
     const dsl_op& o = ops[k];
     int rc = 0;
     hipStream_t st = main_st;
+    if (o.kind == DSL_OP_RECORD || o.kind == DSL_OP_WAIT) {
+      side_init(dev);
+      DSL_CHECK(o.i[1] >= 0 && o.i[1] < 16, "dsl_run_ops: event slot %d out of range", o.i[1]);
+      if (o.kind == DSL_OP_RECORD) {
+        hipEventRecord(g_named[dev][o.i[1]], pick(o.i[0]));
+        g_named_set[dev][o.i[1]] = true;
+      } else if (g_named_set[dev][o.i[1]]) {
+        hipStreamWaitEvent(pick(o.i[0]), g_named[dev][o.i[1]], 0);
+      }
+      continue;
+    }
     if (o.i[6] > 0 || o.kind == DSL_OP_FORK || o.kind == DSL_OP_JOIN) {
       side_init(dev);
       if (o.kind == DSL_OP_FORK || o.kind == DSL_OP_JOIN) {
@@ -62,6 +76,7 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
     switch (o.kind) {
       case DSL_OP_CONV: rc = dsl_conv2d((const dsl_conv_desc*)o.desc, stream); break;
       case DSL_OP_WGRAD: rc = dsl_conv2d_wgrad((const dsl_wgrad_desc*)o.desc, stream); break;
+      case DSL_OP_WGRAD_GROUP: rc = dsl_conv2d_wgrad_group((const dsl_wgrad_desc*)o.desc, o.i[0], stream); break;
       case DSL_OP_GN_FWD: rc = dsl_groupnorm_relu_fwd((const dsl_gn_desc*)o.desc, stream); break;
       case DSL_OP_GN_BWD: rc = dsl_groupnorm_relu_bwd((const dsl_gn_desc*)o.desc, stream); break;
       case DSL_OP_MAXPOOL: rc = dsl_maxpool3x3s2(o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], stream); break;

@@ -909,6 +909,9 @@ struct WgK {
   int dbg;                  // ablation knobs (DSL_ABLATE env): 1 = skip DMA after the first tile, 2 = skip MFMA
   int gx, gy, splits;       // v2: workgroup grid (cout tiles, column tiles) and split count for the XCD-aware 1-D launch
   int chunk;                // v2: consecutive work items (split-major) per XCD
+  int group;                // v2: convolutions sharing this geometry in one launch (dsl_conv2d_wgrad_group)
+  const uint16_t* dyv[DSL_MAX_GROUP];
+  const uint16_t* xv[DSL_MAX_GROUP];
   long long krow;
   const uint16_t* dy;
   const uint16_t* x;
@@ -1162,12 +1165,24 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
   // XCD-aware work mapping (block b runs on XCD b % 8): the (cout tile, tap, cin tile) workgroups of one pixel
   // split are neighbours on one XCD, so its dY / X pixel range is fetched into that XCD's L2 once instead of
   // once per tap.  Placement only affects speed.
-  const int tiles_per_split_wg = p.gx * p.gy;
+  const int tiles_per_member = p.gx * p.gy;
+  const int tiles_per_split_wg = tiles_per_member * p.group;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int witem = xcd * p.chunk + jj;              // work items are split-major: an XCD owns a contiguous range
   if (jj >= p.chunk || witem >= tiles_per_split_wg * p.splits) return;
   const int sp = witem / tiles_per_split_wg;
-  const int rem_wg = witem - sp * tiles_per_split_wg;
+  const int rem_sp = witem - sp * tiles_per_split_wg;
+  const int member = rem_sp / tiles_per_member;      // which convolution of the group
+  const int rem_wg = rem_sp - member * tiles_per_member;
+  // member pointers by select chain, once, outside the K loop (a runtime-indexed kernel-argument load inside the
+  // loop would make hipcc drain the DMA queue)
+  const uint16_t* dy_p = p.dyv[0];
+  const uint16_t* x_p = p.xv[0];
+#pragma unroll
+  for (int g = 1; g < DSL_MAX_GROUP; ++g) {
+    dy_p = member == g ? p.dyv[g] : dy_p;
+    x_p = member == g ? p.xv[g] : x_p;
+  }
   const int co0 = (rem_wg % p.gx) * BCO;
   const int colt = rem_wg / p.gx;
   const int ctiles = p.cs / BCI;
@@ -1319,14 +1334,14 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
 #pragma unroll
       for (int i = 0; i < LY; ++i) {
         const int gp = kl * KS + yrow[i];
-        const gptr_t g = gp < totpx ? (gptr_t)(p.dy + (long long)gp * p.cy + co0 + ych[i]) : zero;
+        const gptr_t g = gp < totpx ? (gptr_t)(dy_p + (long long)gp * p.cy + co0 + ych[i]) : zero;
         __builtin_amdgcn_global_load_lds(g, (lptr_t)(stage + (wave + NW * i) * 1024), 16, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < LX; ++i) {
         // keep the select in a named variable: passing the ?: expression straight into the builtin makes
         // hipcc silently drop this kernel's host stub
-        const gptr_t g = gx[i] >= 0 ? (gptr_t)(p.x + gx[i] + xch[i]) : zero;
+        const gptr_t g = gx[i] >= 0 ? (gptr_t)(x_p + gx[i] + xch[i]) : zero;
         __builtin_amdgcn_global_load_lds(g, (lptr_t)(stage + TILE_Y + (wave + NW * i) * 1024), 16, 0, 0);
       }
     }
@@ -1347,23 +1362,36 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int co = co0 + wave_co * (32 * CT) + ct * 32 + (j & 3) + 8 * (j >> 2) + 4 * fhalf;
-        p.ws[((long long)sp * p.cy + co) * p.krow + col] = acc[ct][it][j];
+        p.ws[(((long long)sp * p.group + member) * p.cy + co) * p.krow + col] = acc[ct][it][j];
       }
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                    const float* __restrict__ scale, int splits, int cy, int cd,
+struct RedK {
+  float* dw[DSL_MAX_GROUP];
+  const float* scale[DSL_MAX_GROUP];
+};
+
+// sums the split partials ws[split][member][cy][krow] of member blockIdx.y into its dW (x scale)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, const RedK r, int splits, int group, int cy, int cd,
                                     long long krow) {
+  const int member = blockIdx.y;
+  float* __restrict__ dw = r.dw[0];
+  const float* __restrict__ scale = r.scale[0];
+#pragma unroll
+  for (int g = 1; g < DSL_MAX_GROUP; ++g) {
+    dw = member == g ? r.dw[g] : dw;
+    scale = member == g ? r.scale[g] : scale;
+  }
   const long long total4 = (long long)cd * krow / 4;
+  const long long sstride = (long long)group * cy * krow;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
        i += (long long)gridDim.x * blockDim.x) {
     const long long e = i * 4;
     const int co = (int)(e / krow);
     const long long k = e - (long long)co * krow;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const long long sstride = (long long)cy * krow;
-    const float* base = ws + (long long)co * krow + k;
+    const float* base = ws + ((long long)member * cy + co) * krow + k;
     int sp = 0;
     for (; sp + 4 <= splits; sp += 4) {      // 4 independent loads in flight per thread
       const f32x4 a = *reinterpret_cast<const f32x4*>(base + sp * sstride);
@@ -1643,9 +1671,10 @@ static int wgrad_geometry(const dsl_wgrad_desc* d, int* ktiles, int* tiles, int*
   return cfg;
 }
 
-extern "C" int dsl_wgrad_splits(const dsl_wgrad_desc* d) {
+static int wgrad_splits_for(const dsl_wgrad_desc* d, int count) {
   int ktiles, tiles, bco;
   const int cfg = wgrad_geometry(d, &ktiles, &tiles, &bco);
+  tiles *= count;
   const int max_by_k = ktiles / 4 > 0 ? ktiles / 4 : 1;    // at least 4 K stages per split
   int splits;
   if (cfg == 0) {
@@ -1656,7 +1685,6 @@ extern "C" int dsl_wgrad_splits(const dsl_wgrad_desc* d) {
     // atomics instead of writing them out was measured: 117 vs 85 us on the head shape - L2 atomics retire about
     // two lanes per clock per channel.)
     splits = 256 * per_cu / tiles;
-    if (splits < 1) splits = 1;
   }
   if (const char* e = getenv("DSL_WGRAD_SPLITS")) { const int v = atoi(e); if (v > 0 && cfg != 0) splits = v; }
   if (splits > max_by_k) splits = max_by_k;
@@ -1665,24 +1693,58 @@ extern "C" int dsl_wgrad_splits(const dsl_wgrad_desc* d) {
   return splits;
 }
 
+extern "C" int dsl_wgrad_splits(const dsl_wgrad_desc* d) { return wgrad_splits_for(d, 1); }
+
 extern "C" size_t dsl_wgrad_workspace_bytes(const dsl_wgrad_desc* d) {
   const int splits = d->splits > 0 ? d->splits : dsl_wgrad_splits(d);
   return (size_t)splits * d->cy * (size_t)d->kh * d->kw * d->cs * sizeof(float);
 }
 
+extern "C" size_t dsl_wgrad_group_workspace_bytes(const dsl_wgrad_desc* descs, int count) {
+  if (!descs || count < 1) return 0;
+  if (count == 1) return dsl_wgrad_workspace_bytes(descs);
+  return (size_t)wgrad_splits_for(descs, count) * count * descs->cy * (size_t)descs->kh * descs->kw * descs->cs * sizeof(float);
+}
+
 extern "C" int dsl_colsum(const void* x, float* out, long rows, int c, int ld, void* stream);
 
-extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
-  DSL_CHECK(d != nullptr, "dsl_conv2d_wgrad: null descriptor");
+static bool wgrad_same_geometry(const dsl_wgrad_desc* a, const dsl_wgrad_desc* b) {
+  if (a->nseg != b->nseg || a->n != b->n || a->cs != b->cs || a->cy != b->cy || a->cd != b->cd || a->kh != b->kh ||
+      a->kw != b->kw || a->stride != b->stride || a->pad != b->pad)
+    return false;
+  for (int s = 0; s < a->nseg; ++s)
+    if (a->gh[s] != b->gh[s] || a->gw[s] != b->gw[s] || a->sh[s] != b->sh[s] || a->sw[s] != b->sw[s]) return false;
+  return true;
+}
+
+// `count` convolutions of one geometry as one launch (count == 1: the plain weight gradient)
+static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
+  const dsl_wgrad_desc* d = descs;
+  DSL_CHECK(d != nullptr && count >= 1 && count <= DSL_MAX_GROUP, "dsl_conv2d_wgrad: bad group (count=%d)", count);
   DSL_CHECK(d->nseg >= 1 && d->nseg <= DSL_MAX_SEG, "dsl_conv2d_wgrad: nseg=%d", d->nseg);
   DSL_CHECK(d->cs % 128 == 0, "dsl_conv2d_wgrad: Cin=%d must be a multiple of 128", d->cs);
   DSL_CHECK(d->cy % 64 == 0 && d->cd <= d->cy, "dsl_conv2d_wgrad: bad cy=%d cd=%d", d->cy, d->cd);
-  DSL_CHECK(d->dy && d->x && d->dw && d->workspace, "dsl_conv2d_wgrad: null pointer");
+  for (int g = 0; g < count; ++g) {
+    DSL_CHECK(descs[g].dy && descs[g].x && descs[g].dw, "dsl_conv2d_wgrad: null pointer (member %d)", g);
+    DSL_CHECK(wgrad_same_geometry(d, &descs[g]), "dsl_conv2d_wgrad_group: member %d has a different geometry", g);
+  }
+  DSL_CHECK(d->workspace, "dsl_conv2d_wgrad: null workspace");
   int ktiles, tiles, bco;
   const int cfg = wgrad_geometry(d, &ktiles, &tiles, &bco);
-  const int splits = d->splits > 0 ? d->splits : dsl_wgrad_splits(d);
-  DSL_CHECK(d->workspace_bytes >= dsl_wgrad_workspace_bytes(d), "dsl_conv2d_wgrad: workspace too small (%zu < %zu)",
-            d->workspace_bytes, dsl_wgrad_workspace_bytes(d));
+  if (cfg == 0 && count > 1) {          // the register-staged kernel has no group form: run the members one by one
+    for (int g = 0; g < count; ++g) {
+      dsl_wgrad_desc t = descs[g];
+      t.workspace = d->workspace;
+      t.workspace_bytes = d->workspace_bytes;
+      t.splits = 0;
+      const int rc = wgrad_launch(&t, 1, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  const int splits = count == 1 ? (d->splits > 0 ? d->splits : dsl_wgrad_splits(d)) : wgrad_splits_for(d, count);
+  const size_t need = (size_t)splits * count * d->cy * (size_t)d->kh * d->kw * d->cs * sizeof(float);
+  DSL_CHECK(d->workspace_bytes >= need, "dsl_conv2d_wgrad: workspace too small (%zu < %zu)", d->workspace_bytes, need);
   WgK k;
   memset(&k, 0, sizeof(k));
   k.nseg = d->nseg; k.n = d->n;
@@ -1706,8 +1768,13 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
   k.ctiles_per_tap = d->cs / 128;
   k.krow = (long long)d->kh * d->kw * d->cs;
   k.dy = (const uint16_t*)d->dy; k.x = (const uint16_t*)d->x; k.ws = (float*)d->workspace;
+  k.group = count;
+  for (int g = 0; g < DSL_MAX_GROUP; ++g) {
+    k.dyv[g] = (const uint16_t*)descs[g < count ? g : 0].dy;
+    k.xv[g] = (const uint16_t*)descs[g < count ? g : 0].x;
+  }
   hipStream_t st = (hipStream_t)stream;
-  const int prof = dsl_prof_active() ? dsl_prof_begin(2, 2.0 * px * (double)d->cd * d->kh * d->kw * d->cs, st) : -1;
+  const int prof = dsl_prof_active() ? dsl_prof_begin(2, 2.0 * count * px * (double)d->cd * d->kh * d->kw * d->cs, st) : -1;
   if (cfg >= 1) {
     const int bcis[5] = {128, 256, 128, 256, 128};
     const int bci = bcis[cfg];
@@ -1716,7 +1783,7 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
     k.gy = d->kh * d->kw * d->cs / bci;
     k.splits = splits;
     { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
-    k.chunk = (k.gx * k.gy * splits + 7) / 8;
+    k.chunk = (k.gx * k.gy * count * splits + 7) / 8;
     dim3 grid2(k.chunk * 8);
     const int kss[5] = {64, 64, 64, 64, 64}, nsts[5] = {2, 2, 3, 3, 2};
     const int ks = kss[cfg];
@@ -1758,10 +1825,29 @@ extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
   DSL_LAUNCH_CHECK("wgrad_kernel");
   const long long total4 = (long long)d->cd * k.krow / 4;
   int rb = (int)((total4 + 255) / 256);
-  if (rb > 4096) rb = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)d->workspace, d->dw,
-                     d->scale, splits, d->cy, d->cd, k.krow);
+  if (rb > 4096 / count) rb = 4096 / count;
+  RedK r;
+  for (int g = 0; g < DSL_MAX_GROUP; ++g) {
+    r.dw[g] = descs[g < count ? g : 0].dw;
+    r.scale[g] = descs[g < count ? g : 0].scale;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb, count), dim3(256), 0, st, (const float*)d->workspace, r, splits, count,
+                     d->cy, d->cd, k.krow);
   DSL_LAUNCH_CHECK("wgrad_reduce_kernel");
-  if (d->db) return dsl_colsum(d->dy, d->db, (long)px, d->cd, d->cy, stream);
+  for (int g = 0; g < count; ++g)
+    if (descs[g].db) {
+      const int rc = dsl_colsum(descs[g].dy, descs[g].db, (long)px, d->cd, d->cy, stream);
+      if (rc) return rc;
+    }
   return 0;
+}
+
+extern "C" int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream) {
+  DSL_CHECK(d != nullptr, "dsl_conv2d_wgrad: null descriptor");
+  return wgrad_launch(d, 1, stream);
+}
+
+extern "C" int dsl_conv2d_wgrad_group(const dsl_wgrad_desc* descs, int count, void* stream) {
+  DSL_CHECK(descs != nullptr, "dsl_conv2d_wgrad_group: null descriptors");
+  return wgrad_launch(descs, count, stream);
 }

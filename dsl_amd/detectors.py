@@ -261,10 +261,11 @@ class FCOS(nn.Module):
         """Hand-written backward; gradient buckets are all-reduced as each segment's kernels are queued
         (bulk RCCL traffic overlaps the remaining backward, as torch DDP does at mmdet/apis/train.py:92-96)."""
         self._pending = []
-        for ol, (lo, hi) in plan.bwd_segments:
+        for ol, ready in plan.bwd_segments:
             ol.run()
             if self.world_size > 1:
-                self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
+                for lo, hi in ready:        # buckets whose gradients are complete once this list has run
+                    self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
         self._rebind_grads()
 
     def wait_grads(self):

@@ -54,8 +54,21 @@ class OpList:
         else:
             self._add(L.OP_WGRAD, d)
 
+    def wgrad_group(self, arr, side=False):
+        """arr: ops.wgrad_group(...) array (same-geometry convolutions, one launch)."""
+        if side:
+            self._add(L.OP_FORK)
+        self._add(L.OP_WGRAD_GROUP, arr, i=(len(arr), 0, 0, 0, 0, 0, 1 if side else 0))
+
     def join(self):
         self._add(L.OP_JOIN)
+
+    def record(self, slot, stream=1):
+        """Named event: everything queued so far on `stream` (1 = the side stream)."""
+        self._add(L.OP_RECORD, i=(stream, slot))
+
+    def wait(self, slot, stream=0):
+        self._add(L.OP_WAIT, i=(stream, slot))
 
     def gn_fwd(self, d, side=False):
         self._add(L.OP_GN_FWD, d, i=(0, 0, 0, 0, 0, 0, 1 if side else 0))
@@ -252,7 +265,9 @@ class Plan:
         return ptr
 
     # ---------------------------------------------------------------------------------------------
-    def _wgrad(self, ol, spec, dy, x, n, out_hw, in_hw, cy=None, cd=None, wregion=None, bregion=None, side=False):
+    def _wgrad(self, ol, spec, dy, x, n, out_hw, in_hw, cy=None, cd=None, wregion=None, bregion=None, side=False,
+               emit=True):
+        """emit=False: only build the descriptor (for a later grouped launch)."""
         st = self.store
         scale = st.bn_ptrs(spec.bn)[0] if (spec is not None and spec.bn) else None
         name = wregion or (spec.name + '.weight')
@@ -266,17 +281,37 @@ class Plan:
                            cs=256 if spec is None else spec.cin, cy=cy or spec.cout_pad, cd=cd or spec.cout,
                            kh=k, kw=k, stride=1 if spec is None else spec.stride, pad=1 if spec is None else spec.pad,
                            scale=scale, db=db, workspace=self._wg_ws(n, out_hw, in_hw, spec, cy))
-        ol.wgrad(d, side=side)
+        if emit:
+            ol.wgrad(d, side=side)
+        return d
+
+    def _wgrad_group(self, ol, descs, side=True):
+        """One launch for same-geometry convolutions (the blocks of a ResNet stage, the layers of a head tower): the
+        split-K partial traffic of the group is what ONE of its members would need alone."""
+        if not descs:
+            return
+        if len(descs) == 1:
+            ol.wgrad(descs[0], side=side)
+            return
+        arr0 = (L.WgradDesc * len(descs))()
+        for i, d in enumerate(descs):
+            C.memmove(C.addressof(arr0[i]), C.addressof(d), C.sizeof(L.WgradDesc))
+        need = L.lib.dsl_wgrad_group_workspace_bytes(arr0, len(descs))
+        ol.wgrad_group(ops.wgrad_group(descs, workspace=self._wg_buf(need)), side=side)
 
     def _wg_ws(self, n, out_hw, in_hw, spec, cy):
         need = ops.wgrad_workspace_bytes(n=n, grid=out_hw, src_hw=in_hw, cs=256 if spec is None else spec.cin,
                                          cy=cy or spec.cout_pad, cd=1, kh=3 if spec is None else spec.k,
                                          kw=3 if spec is None else spec.k, stride=1 if spec is None else spec.stride,
                                          pad=1 if spec is None else spec.pad)
+        return self._wg_buf(need)
+
+    def _wg_buf(self, need):
+        """The split-K partial-tile scratch of the weight gradients (they run one after the other on the side stream)."""
         ws = self.bufs.get('wg_ws')
         if ws is None or ws.numel() < need:
             # grow: descriptors built earlier keep pointing at the old (smaller, still alive) buffer
-            ws = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=self.dev)
+            ws = torch.empty(max(need, 96 << 20), dtype=torch.uint8, device=self.dev)
             self.bufs.setdefault('wg_ws_old', []).append(self.bufs.get('wg_ws'))
             self.bufs['wg_ws'] = ws
         return ws
@@ -300,6 +335,8 @@ class Plan:
         reg = st.train_regions
         M = self.M
         SIDE = True
+        GROUP_LAST = True  # ... also in the last segment (nothing left on the main stream to overlap its tail with)
+        GROUP = True       # same-geometry weight gradients (tower layers, the blocks of a stage) as one launch
         g_feats = self.buf('g_feats', M, 256)
         # ================= segment 0: head + FPN =================
         ol = OpList()
@@ -319,6 +356,7 @@ class Plan:
                 self._wgrad(ol, None, lp.g_rc, lays[3]['act'], N, ls, ls, cy=64, cd=5, wregion='head.regctr_w',
                             bregion='head.regctr_b', side=SIDE)
                 ol.conv(self._dgrad('head.regctr', lp.g_rc, g_act, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1))
+            tower_group = []
             for i in (3, 2, 1, 0):
                 lay = lays[i]
                 base = lay['gn']
@@ -328,13 +366,15 @@ class Plan:
                                  dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad))
                 gd.prezeroed = 1
                 ol.gn_bwd(gd)
-                self._wgrad(ol, lay['spec'], g_pre, lay['xin'], N, ls, ls, side=SIDE)
+                tower_group.append(self._wgrad(ol, lay['spec'], g_pre, lay['xin'], N, ls, ls, side=SIDE, emit=not GROUP))
                 if i > 0:
                     g_act = self.buf(f'g_{tower}_act{i - 1}', M, 256)
                     ol.conv(self._dgrad(lay['spec'].name, g_pre, g_act, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
                 else:
                     ol.conv(self._dgrad(lay['spec'].name, g_pre, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1,
                                         pad=1, addend=g_feats if ti == 1 else None))
+            if GROUP:
+                self._wgrad_group(ol, tower_group)
         # ---- FPN backward ----
         cv = st.convs
         fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
@@ -377,9 +417,12 @@ class Plan:
             self.g_stage[li] = g0b
             ol.conv(self._dgrad(lc[i].name, g_lat[i], g0b, N, [hw], [hw], cs=256, cd=cch, k=1, stride=1, pad=0,
                                 mask=cfeat, mask_first=True))
-        ol.join()
         buckets = st.grad_buckets()
-        self.bwd_segments.append((ol, buckets[0]))
+        # no JOIN here: this segment's weight gradients keep running on the side stream under the next segment's
+        # data-gradient chain; slot s marks "side-stream work of segment s queued", the NEXT segment ends by waiting
+        # for it, after which bucket s is complete and its all-reduce may start
+        ol.record(0)
+        self.bwd_segments.append((ol, []))
         # ================= backbone: layer4, layer3, layer2 =================
         blocks_by_stage = {li: [b for b in self.blocks if b['stage'] == li] for li in (1, 2, 3)}
         for li in (3, 2, 1):
@@ -388,18 +431,23 @@ class Plan:
             hw = blks[0]['out_hw']
             planes = blks[0]['planes']
             g_pre = self.g_stage[li]          # gradient w.r.t. the (pre-ReLU-masked) output of the stage's last block
+            g3, g2, g1 = [], [], []           # same-geometry weight gradients of this stage's blocks
             for blk in reversed(blks):
                 p = blk['prefix']
                 c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
                 gA2 = self.buf(p + '.g_a2', N, hw[0], hw[1], planes)
                 gA1 = self.buf(p + '.g_a1', N, hw[0], hw[1], planes)
-                self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw], side=SIDE)
+                grp = GROUP and (li > 1 or GROUP_LAST)
+                g3.append(self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw], side=SIDE, emit=not grp))
                 ol.conv(self._dgrad(c3.name, g_pre, gA2, N, [hw], [hw], cs=c3.cout, cd=c3.cin, k=1, stride=1, pad=0,
                                     mask=blk['a2'], mask_last=True))
-                self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw], side=SIDE)
+                g2.append(self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw], side=SIDE, emit=not grp))
                 ol.conv(self._dgrad(c2.name, gA2, gA1, N, [hw], [hw], cs=c2.cout, cd=c2.cin, k=3, stride=1, pad=1,
                                     mask=blk['a1'], mask_last=True))
-                self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE)
+                d1 = self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE,
+                                 emit=not (grp and blk['b'] > 0))
+                if blk['b'] > 0:
+                    g1.append(d1)
                 if blk['b'] > 0:
                     g_prev = self.buf(p + '.g_in', N, hw[0], hw[1], planes * 4)
                     ol.conv(self._dgrad(c1.name, gA1, g_prev, N, [hw], [hw], cs=c1.cout, cd=c1.cin, k=1, stride=1,
@@ -414,8 +462,17 @@ class Plan:
                         for spec, dy in ((ds, g_pre), (c1, gA1)):
                             ol.conv(self._dgrad(spec.name, dy, tgt, N, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
-            ol.join()
-            self.bwd_segments.append((ol, buckets[4 - li]))
+            if GROUP and (li > 1 or GROUP_LAST):
+                for grp_descs in (g3, g2, g1):
+                    self._wgrad_group(ol, grp_descs)
+            seg = 4 - li                      # 1, 2, 3
+            ol.record(seg)
+            ol.wait(seg - 1)                  # previous segment's weight gradients done -> its bucket is complete
+            ready = [buckets[seg - 1]]
+            if li == 1:                       # last segment: everything must be complete when the list returns
+                ol.join()
+                ready.append(buckets[seg])
+            self.bwd_segments.append((ol, ready))
 
     # ---------------------------------------------------------------------------------------------
     def forward(self, img=None):

@@ -75,6 +75,30 @@ def wgrad_workspace_bytes(*, n, grid, src_hw, cs, cy, cd, kh, kw, stride=1, pad=
     return lib.dsl_wgrad_workspace_bytes(C.byref(d))
 
 
+def wgrad_group(descs, workspace=None):
+    """Packs same-geometry wgrad descriptors into one contiguous array for dsl_conv2d_wgrad_group; element 0 carries
+    the group's workspace."""
+    assert 1 <= len(descs) <= L.MAX_GROUP
+    arr = (L.WgradDesc * len(descs))()
+    for i, d in enumerate(descs):
+        C.memmove(C.addressof(arr[i]), C.addressof(d), C.sizeof(L.WgradDesc))
+        arr[i].splits = 0
+    need = lib.dsl_wgrad_group_workspace_bytes(arr, len(descs))
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device='cuda')
+    nbytes = workspace.numel() * workspace.element_size()
+    assert nbytes >= need, (nbytes, need)
+    arr[0].workspace, arr[0].workspace_bytes = L.ptr(workspace), nbytes
+    arr._keep = (list(descs), workspace)
+    return arr
+
+
+def conv2d_wgrad_group(descs, workspace=None):
+    arr = wgrad_group(descs, workspace)
+    L.check(lib.dsl_conv2d_wgrad_group(arr, len(descs), L.stream_ptr()), 'dsl_conv2d_wgrad_group')
+    return arr
+
+
 def conv2d_wgrad(*a, **k):
     d = wgrad_desc(*a, **k)
     L.check(lib.dsl_conv2d_wgrad(C.byref(d), L.stream_ptr()), 'dsl_conv2d_wgrad')

@@ -25,6 +25,7 @@ extern "C" {
 #endif
 
 #define DSL_MAX_SEG 5
+#define DSL_MAX_GROUP 8   /* convolutions per grouped weight-gradient launch */
 
 int dsl_version(void);
 const char* dsl_last_error(void);
@@ -101,6 +102,13 @@ typedef struct dsl_wgrad_desc {
 int dsl_wgrad_splits(const dsl_wgrad_desc* d);
 size_t dsl_wgrad_workspace_bytes(const dsl_wgrad_desc* d);
 int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream);
+/* The weight gradients of `count` (<= DSL_MAX_GROUP) convolutions that share one geometry - every descriptor
+ * field except dy, x, scale, dw, db - as ONE launch: the workgroups that fill the chip come from `count` times
+ * more output tiles, so `count` times fewer pixel splits and fp32 partial tiles are needed (ResNet blocks of
+ * one stage, the FCOS tower layers).  Uses descs[0].workspace (>= dsl_wgrad_group_workspace_bytes); the
+ * members' `splits` fields are ignored. */
+size_t dsl_wgrad_group_workspace_bytes(const dsl_wgrad_desc* descs, int count);
+int dsl_conv2d_wgrad_group(const dsl_wgrad_desc* descs, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Memory-bound fused layers
@@ -240,7 +248,10 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_SUM2X2 = 6, DSL_OP_COLSUM = 7, DSL_OP_MEMSET = 8, DSL_OP_PACK_IMAGE = 9,
        DSL_OP_ASSIGN = 10, DSL_OP_LOSS = 11,
        DSL_OP_FORK = 12,   /* side stream i[0] (default 1) waits for everything queued so far on stream i[1] (default 0 = caller's) */
-       DSL_OP_JOIN = 13 }; /* stream i[1] (default 0 = caller's) waits for everything queued so far on side stream i[0] (default 1) */
+       DSL_OP_JOIN = 13,   /* stream i[1] (default 0 = caller's) waits for everything queued so far on side stream i[0] (default 1) */
+       DSL_OP_WGRAD_GROUP = 14,  /* desc = dsl_wgrad_desc[i[0]] -> dsl_conv2d_wgrad_group */
+       DSL_OP_RECORD = 15, /* mark "everything queued so far on stream i[0]" in named event slot i[1] (0..15); survives the call */
+       DSL_OP_WAIT = 16 }; /* stream i[0] waits for named event slot i[1] (no-op if the slot was never recorded) */
 typedef struct dsl_op {
   int32_t kind;
   int32_t i[7];            /* small integer arguments for the simple ops; i[6] = s > 0: run this op on the library's

@@ -44,7 +44,10 @@ def _worker(rank, world, port, q):
         det.store.grad.copy_(torch.arange(det.store.n_train, dtype=torch.float32) % 7 + rank)
 
         class Plan:
-            bwd_segments = [(_NoOps(), b) for b in det.store.grad_buckets()]
+            # the engine's schedule: a bucket becomes complete one segment late (its weight gradients finish on the
+            # side stream under the next segment), the last segment releases the last two
+            _b = det.store.grad_buckets()
+            bwd_segments = [(_NoOps(), []), (_NoOps(), [_b[0]]), (_NoOps(), [_b[1]]), (_NoOps(), [_b[2], _b[3]])]
         det._run_backward(Plan)
         assert len(det._pending) == 4
         det.wait_grads()

@@ -283,6 +283,48 @@ def test_wgrad(K, case, cfg):
     assert torch.allclose(db.cpu(), dy.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize('count', [2, 3, 8])
+@pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_wgrad_group(K, case, count):
+    """dsl_conv2d_wgrad_group: `count` convolutions of one geometry in one launch == the same convolutions one by one."""
+    L, ops = K
+    _, N, Ci, Co, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(11 + count)
+    descs, refs, outs = [], [], []
+    for m in range(count):
+        x = rnd(N, Ci, H, W, g=g)
+        w = rnd(Co, Ci, k, k, g=g).requires_grad_()
+        y = F.conv2d(x, w, None, s, p)
+        Ho, Wo = y.shape[2:]
+        dy = rnd(N, Co, Ho, Wo, g=g)
+        y.backward(dy)
+        scale = (torch.rand(Co, generator=g) + 0.5) if m % 2 == 0 else None
+        ref = w.grad if scale is None else w.grad * scale[:, None, None, None]
+        dw = torch.full((Co, k, k, Ci), float('nan'), dtype=torch.float32, device='cuda')
+        db = torch.empty(Co, dtype=torch.float32, device='cuda') if m != 1 else None
+        descs.append(ops.wgrad_desc(nhwc(dy), nhwc(x), dw, n=N, grid=[(Ho, Wo)], src_hw=[(H, W)], cs=Ci, cy=Co, cd=Co,
+                                    kh=k, kw=k, stride=s, pad=p, scale=None if scale is None else scale.cuda(), db=db))
+        refs.append((ref.permute(0, 2, 3, 1), dy.sum((0, 2, 3))))
+        outs.append((dw, db))
+    ops.conv2d_wgrad_group(descs)
+    sync()
+    for (ref, rdb), (dw, db) in zip(refs, outs):
+        got = dw.cpu()
+        assert torch.allclose(got, ref, rtol=1e-2, atol=2e-2 * float(ref.abs().max())), (got - ref).abs().max()
+        if db is not None:
+            assert torch.allclose(db.cpu(), rdb, rtol=1e-3, atol=1e-2)
+
+
+def test_wgrad_group_rejects_mixed_geometry(K):
+    L, ops = K
+    a = ops.wgrad_desc(torch.zeros(2 * 8 * 8, 128, device='cuda', dtype=torch.bfloat16), torch.zeros(2 * 8 * 8, 128, device='cuda', dtype=torch.bfloat16),
+                       torch.zeros(128, 1, 1, 128, device='cuda'), n=2, grid=[(8, 8)], src_hw=[(8, 8)], cs=128, cy=128, cd=128, kh=1, kw=1)
+    b = ops.wgrad_desc(torch.zeros(2 * 8 * 8, 128, device='cuda', dtype=torch.bfloat16), torch.zeros(2 * 8 * 8, 256, device='cuda', dtype=torch.bfloat16),
+                       torch.zeros(128, 1, 1, 256, device='cuda'), n=2, grid=[(8, 8)], src_hw=[(8, 8)], cs=256, cy=128, cd=128, kh=1, kw=1)
+    with pytest.raises(RuntimeError, match='different geometry'):
+        ops.conv2d_wgrad_group([a, b], workspace=torch.empty(64 << 20, dtype=torch.uint8, device='cuda'))
+
+
 def test_wgrad_multilevel_padded_cout(K):
     """Head predictor weight gradient: 5 level segments, dY rows padded 80 -> 128 channels."""
     L, ops = K
