@@ -114,6 +114,7 @@ def main():
 
     model = build_detector(model_cfg()).cuda()      # random init, reference style, same seed on every rank
     model.lazy_log = True
+    model.eager_backward = True      # backward kernels are queued right behind the loss kernel (see FCOS.eager_backward)
     if world > 1:
         model = HipDistributedDataParallel(model)
     det = model.module if world > 1 else model

@@ -32,6 +32,7 @@ struct ConvK {
   int ident;                          // 1: destination pixel index == compute-grid pixel index (os 1, same sizes)
   int dbg;                            // ablation knobs (DSL_ABLATE env): 1 = DMA only for the first tiles, 2 = no MFMA, 4 = no epilogue
   int splits, kt_per_split, cd_pad;   // split-K over K tiles (v2 kernel): fp32 partials -> ws, then conv_splitk_epilogue_kernel
+  int gx, gy, xcd_chunk;              // v3: tile grid (cout tiles, pixel tiles) and tiles per XCD of the 1-D XCD-aware launch
   float* ws;
   long long wrow;
   const uint16_t* src;
@@ -651,8 +652,16 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_co = wave / WPX, wave_px = wave % WPX;
-  const int co0 = blockIdx.x * BCO;
-  const int px0 = blockIdx.y * BPX;
+  // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD owns a contiguous run of tiles in (cout tile
+  // fastest, then pixel tile, then K split) order, so neighbouring pixel tiles - which share their halo rows - and
+  // the cout tiles of one pixel range hit the same L2 instead of being fetched into up to three of them.
+  const int wi = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.xcd_chunk || wi >= p.gx * p.gy * p.splits) return;
+  const int bz = wi / (p.gx * p.gy);
+  const int rem_t = wi - bz * (p.gx * p.gy);
+  const int by = rem_t / p.gx;
+  const int co0 = (rem_t - by * p.gx) * BCO;
+  const int px0 = by * BPX;
   const int totpx = p.pxstart[p.nseg];
   const int lrow = tid >> 3;
   const int chunk = (tid & 7) ^ ((tid >> 4) & 7);     // source chunk that belongs in LDS slot (tid & 7) of this row
@@ -664,7 +673,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
       __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.src) - margin), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, 0x7fffffff, 0x00020000);
 
-  const int kt0 = blockIdx.z * p.kt_per_split;
+  const int kt0 = bz * p.kt_per_split;
 #ifdef DSL_ABLATE_BUILD
   const int kt1 = (p.dbg & 8) ? kt0 + 1 : min(kt0 + p.kt_per_split, p.ktiles);
 #else
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
     for (int pt = 0; pt < PT; ++pt) {
       const int gp = px0 + wave_px * (32 * PT) + pt * 32 + (lane & 31);
       if (gp >= totpx) continue;
-      float* row = p.ws + ((long long)blockIdx.z * totpx + gp) * p.cd_pad;
+      float* row = p.ws + ((long long)bz * totpx + gp) * p.cd_pad;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1565,6 +1574,9 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     k.ws = (float*)d->workspace;
     { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
     dim3 grid(d->cd_pad / c.bco, (px + c.bpx - 1) / c.bpx, splits);
+    k.gx = (int)grid.x;
+    k.gy = (int)grid.y;
+    k.xcd_chunk = (int)((grid.x * grid.y * grid.z + 7) / 8);
     const size_t lds = (size_t)c.nst * (c.bco + c.bpx) * 128;
     int prof = -1;
     if (dsl_prof_active()) prof = dsl_prof_begin(pick == 0 ? 0 : 1, 2.0 * px * (double)d->cd * d->kh * d->kw * d->cs, st);
@@ -1586,7 +1598,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
                           (int)lds);                                                                          \
       attr_set3 = true;                                                                                       \
     }                                                                                                         \
-    hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_>), grid, dim3(64 * C_ * D), lds, st, k);              \
+    hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_>), dim3(8 * k.xcd_chunk), dim3(64 * C_ * D), lds, st, k); \
   } while (0)
     static const bool force_v2 = getenv("DSL_CONV_V2") != nullptr;
     if (force_v2 || conv_v2_only(d)) {

@@ -137,12 +137,13 @@ class _TrainStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, det, plan):
-        ctx.det, ctx.plan = det, plan
+        ctx.det, ctx.plan, ctx.eager = det, plan, det.eager_backward
         return plan.lossplan.losses.clone()
 
     @staticmethod
     def backward(ctx, g):
-        ctx.det._run_backward(ctx.plan)
+        if not ctx.eager:                 # eager: the kernels were queued right behind the loss kernel
+            ctx.det._run_backward(ctx.plan)
         return None, None, None
 
 
@@ -168,6 +169,12 @@ class FCOS(nn.Module):
         self.world_size = 1
         self.CLASSES = None
         self.lazy_log = False         # True: log_vars stay device tensors (no per-iteration host sync)
+        # True: queue the backward kernel lists directly behind the loss kernel instead of when `loss.backward()`
+        # reaches the autograd bridge (the gradient of the summed loss is 1 either way - the bridge ignores its
+        # incoming gradient - so only the launch order changes: the host-side loss parsing then overlaps the GPU's
+        # backward instead of sitting between forward and backward).  For loops that always call loss.backward()
+        # once per train_step, as mmcv's OptimizerHook does.
+        self.eager_backward = False
         self._pending = []
 
     # ---- nn.Module surface redirected to the flat store ------------------------------------------
@@ -251,6 +258,8 @@ class FCOS(nn.Module):
         if work is not None:
             work.wait()
         plan.loss_ops.run()
+        if self.eager_backward and torch.is_grad_enabled():
+            self._run_backward(plan)
         out = _TrainStepFn.apply(self._anchor, self, plan)
         losses = OrderedDict(loss_cls=out[0], loss_bbox=out[1], loss_centerness=out[2])
         if sw != 0.0:

@@ -126,3 +126,26 @@ def test_sgd_step_and_ema_on_flat_store():
     # bf16 pack follows the master weights
     st = model.store
     assert torch.equal(st.train16.float().cpu(), st.train.cpu().bfloat16().float())
+
+
+def test_eager_backward_same_gradients():
+    """FCOS.eager_backward only moves the launch of the backward lists behind the loss kernel: same losses and the
+    same gradients as loss.backward() (up to the float-atomic reduction order inside the GN / loss kernels)."""
+    from oracle import fcos_oracle as O
+    torch.manual_seed(3)
+    img = torch.randn(2, 3, 128, 192).bfloat16().float()
+    gtb = [torch.tensor([[10., 12., 90., 100.], [40., 30., 150., 120.]]), torch.tensor([[5., 5., 60., 70.]])]
+    gtl = [torch.tensor([3, 17]), torch.tensor([60])]
+    metas = [dict(img_shape=(128, 192, 3), pad_shape=(128, 192, 3), scale_factor=1.0)] * 2
+    grads, losses = [], []
+    for eager in (False, True):
+        model = build()
+        model.eager_backward = eager
+        out = model.train_step(dict(img=img.cuda(), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl), None)
+        out['loss'].backward()
+        torch.cuda.synchronize()
+        grads.append(model.store.grad.clone())
+        losses.append(float(out['loss']))
+    assert abs(losses[0] - losses[1]) < 1e-4 * abs(losses[0])
+    assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
+    assert rel_l2(grads[1], grads[0]) < 1e-2
