@@ -132,6 +132,11 @@ class FCOSHead(nn.Module):
         return w
 
 
+class _LossDict(OrderedDict):
+    """The loss dict of forward_train; `.vec` (optional) holds the same scalars as one graph-connected tensor."""
+    vec = None
+
+
 class _TrainStepFn(torch.autograd.Function):
     """Bridges `loss.backward()` (mmcv OptimizerHook) to the hand-written backward kernel lists."""
 
@@ -261,9 +266,10 @@ class FCOS(nn.Module):
         if self.eager_backward and torch.is_grad_enabled():
             self._run_backward(plan)
         out = _TrainStepFn.apply(self._anchor, self, plan)
-        losses = OrderedDict(loss_cls=out[0], loss_bbox=out[1], loss_centerness=out[2])
+        losses = _LossDict(loss_cls=out[0], loss_bbox=out[1], loss_centerness=out[2])
         if sw != 0.0:
             losses['loss_sisoft'] = out[3]
+        losses.vec = out[:len(losses)]      # the same scalars as ONE tensor: lets _parse_losses avoid per-key device ops
         return losses
 
     def _run_backward(self, plan):
@@ -302,11 +308,21 @@ class FCOS(nn.Module):
         """detectors/base.py:175-208: total = sum of keys containing 'loss'; log vars averaged over ranks."""
         log_vars = OrderedDict()
         for name, value in losses.items():
-            log_vars[name] = value.mean() if isinstance(value, torch.Tensor) else sum(v.mean() for v in value)
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
-        log_vars['loss'] = loss
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value if value.dim() == 0 else value.mean()     # the HIP head returns scalars
+            else:
+                log_vars[name] = sum(v.mean() for v in value)
         keys = list(log_vars.keys())
-        vec = torch.stack([log_vars[k].detach() for k in keys])
+        # two device ops instead of one per key (stack + sum); the reference sums the keys containing 'loss'
+        vec0 = getattr(losses, 'vec', None)
+        stacked = vec0 if (vec0 is not None and vec0.numel() == len(keys)) else torch.stack([log_vars[k] for k in keys])
+        if all('loss' in k for k in keys):
+            loss = stacked.sum()
+        else:
+            loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        keys.append('loss')
+        vec = torch.cat([stacked.detach(), loss.detach().reshape(1)])
         if self.world_size > 1:      # ONE all-reduce for all log vars instead of one per key
             dist.all_reduce(vec, group=self.dist_group)
             vec = vec / self.world_size

@@ -9,6 +9,7 @@ What the lists compute is the reference's
 and its autograd backward, written out by hand (no autograd graph exists here).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -335,7 +336,7 @@ class Plan:
         reg = st.train_regions
         M = self.M
         SIDE = True
-        GROUP_LAST = True  # ... also in the last segment (nothing left on the main stream to overlap its tail with)
+        GROUP_LAST = os.environ.get('DSL_GROUP_LAST', '1') != '0'  # ... also in the last segment (nothing left on the main stream to overlap its tail with)
         GROUP = True       # same-geometry weight gradients (tower layers, the blocks of a stage) as one launch
         g_feats = self.buf('g_feats', M, 256)
         # ================= segment 0: head + FPN =================
