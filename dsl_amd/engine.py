@@ -286,7 +286,7 @@ class Plan:
             ol.wgrad(d, side=side)
         return d
 
-    def _wgrad_group(self, ol, descs, side=True):
+    def _wgrad_group(self, ol, descs, side=True, ws_name='wg_ws'):
         """One launch for same-geometry convolutions (the blocks of a ResNet stage, the layers of a head tower): the
         split-K partial traffic of the group is what ONE of its members would need alone."""
         if not descs:
@@ -298,7 +298,7 @@ class Plan:
         for i, d in enumerate(descs):
             C.memmove(C.addressof(arr0[i]), C.addressof(d), C.sizeof(L.WgradDesc))
         need = L.lib.dsl_wgrad_group_workspace_bytes(arr0, len(descs))
-        ol.wgrad_group(ops.wgrad_group(descs, workspace=self._wg_buf(need)), side=side)
+        ol.wgrad_group(ops.wgrad_group(descs, workspace=self._wg_buf(need, ws_name)), side=side)
 
     def _wg_ws(self, n, out_hw, in_hw, spec, cy):
         need = ops.wgrad_workspace_bytes(n=n, grid=out_hw, src_hw=in_hw, cs=256 if spec is None else spec.cin,
@@ -307,14 +307,14 @@ class Plan:
                                          pad=1 if spec is None else spec.pad)
         return self._wg_buf(need)
 
-    def _wg_buf(self, need):
-        """The split-K partial-tile scratch of the weight gradients (they run one after the other on the side stream)."""
-        ws = self.bufs.get('wg_ws')
+    def _wg_buf(self, need, name='wg_ws'):
+        """The split-K partial-tile scratch of the weight gradients (they run one after the other on one stream)."""
+        ws = self.bufs.get(name)
         if ws is None or ws.numel() < need:
             # grow: descriptors built earlier keep pointing at the old (smaller, still alive) buffer
             ws = torch.empty(max(need, 96 << 20), dtype=torch.uint8, device=self.dev)
-            self.bufs.setdefault('wg_ws_old', []).append(self.bufs.get('wg_ws'))
-            self.bufs['wg_ws'] = ws
+            self.bufs.setdefault(name + '_old', []).append(self.bufs.get(name))
+            self.bufs[name] = ws
         return ws
 
     def _dgrad(self, name, dy, dst, n, dy_hw, dst_hw, *, cs, cd, k, stride, pad, os=1, addend=None, mask=None,
@@ -464,8 +464,11 @@ class Plan:
                             ol.conv(self._dgrad(spec.name, dy, tgt, N, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
             if GROUP and (li > 1 or GROUP_LAST):
+                tail_main = (li == 1) and os.environ.get('DSL_TAIL_MAIN', '1') != '0'
                 for grp_descs in (g3, g2, g1):
-                    self._wgrad_group(ol, grp_descs)
+                    # last segment: the caller's stream has nothing left to do, it takes the last group itself
+                    self._wgrad_group(ol, grp_descs, side=not (tail_main and grp_descs is g1),
+                                      ws_name='wg_ws_main' if (tail_main and grp_descs is g1) else 'wg_ws')
             seg = 4 - li                      # 1, 2, 3
             ol.record(seg)
             ol.wait(seg - 1)                  # previous segment's weight gradients done -> its bucket is complete
