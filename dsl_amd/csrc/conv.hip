@@ -30,7 +30,7 @@ struct ConvK {
   int cs, cd, ldd, lda, ldm, kh, kw, stride, pad, mode, os, flags;
   int ktiles, kc;
   int ident;                          // 1: destination pixel index == compute-grid pixel index (os 1, same sizes)
-  int dbg;                            // ablation knobs (DSL_ABLATE env): 1 = DMA only for the first tiles, 2 = no MFMA, 4 = no epilogue
+  int dbg;                            // ablation knobs, compiled in only by tools/build_ablate.sh (-DDSL_ABLATE_BUILD; DSL_ABLATE env)
   int splits, kt_per_split, cd_pad;   // split-K over K tiles (v2 kernel): fp32 partials -> ws, then conv_splitk_epilogue_kernel
   int gx, gy, xcd_chunk;              // v3: tile grid (cout tiles, pixel tiles) and tiles per XCD of the 1-D XCD-aware launch
   float* ws;
@@ -555,12 +555,11 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_glds_kernel(const ConvK p
     else if (NST >= 3 && ahead >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * LPT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // everyone's DMA for tile kt landed; compute(kt-1) finished everywhere
-    if (kt + NST - 1 < kt1 && !(p.dbg & 1)) gload(kt + NST - 1, slot == 0 ? NST - 1 : slot - 1);
-    if (!(p.dbg & 2)) compute(slot);
+    if (kt + NST - 1 < kt1) gload(kt + NST - 1, slot == 0 ? NST - 1 : slot - 1);
+    compute(slot);
     slot = (slot + 1 == NST) ? 0 : slot + 1;
   }
 
-  if (p.dbg & 4) return;
   if (p.splits > 1) {                      // split-K: raw fp32 partial tile -> workspace [split][pixel][cd_pad]
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -915,7 +914,7 @@ struct WgK {
   FastDiv dhw[DSL_MAX_SEG], dwd[DSL_MAX_SEG];
   int cs, cy, kh, kw, stride, pad;
   int ktiles, tiles_per_split, ctiles_per_tap;
-  int dbg;                  // ablation knobs (DSL_ABLATE env): 1 = skip DMA after the first tile, 2 = skip MFMA
+  int dbg;                  // ablation knobs (ablation build only): 1 = skip DMA after the first tile, 2 = skip MFMA, 4 = no epilogue
   int gx, gy, splits;       // v2: workgroup grid (cout tiles, column tiles) and split count for the XCD-aware 1-D launch
   int chunk;                // v2: consecutive work items (split-major) per XCD
   int group;                // v2: convolutions sharing this geometry in one launch (dsl_conv2d_wgrad_group)
@@ -1317,7 +1316,11 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();          // everyone's part of tile kc landed; compute(kc-1) finished everywhere
     }
+#ifdef DSL_ABLATE_BUILD
     if (kl < kt1 && !((p.dbg & 1) && kc >= kt0)) {
+#else
+    if (kl < kt1) {
+#endif
       unsigned char* stage = smem + slot_i * STAGE;
       // every lane decodes ONE pixel row of the stage (row = lane) and the DMA instructions pick their rows'
       // source offsets up with a lane shuffle: one decode per stage instead of one per DMA instruction
@@ -1356,11 +1359,16 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
     }
     if (kl >= kt0) slot_i = (slot_i + 1 == NST) ? 0 : slot_i + 1;
     if (kc >= kt0) {
-      if (!(p.dbg & 2)) compute(slot_c);
+#ifdef DSL_ABLATE_BUILD
+      if (!(p.dbg & 2))
+#endif
+      compute(slot_c);
       slot_c = (slot_c + 1 == NST) ? 0 : slot_c + 1;
     }
   }
+#ifdef DSL_ABLATE_BUILD
   if (p.dbg & 4) return;
+#endif
 
   const int frow = lane & 31, fhalf = lane >> 5;
 #pragma unroll
@@ -1572,7 +1580,9 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     k.kt_per_split = (k.ktiles + splits - 1) / splits;
     k.cd_pad = d->cd_pad;
     k.ws = (float*)d->workspace;
+#ifdef DSL_ABLATE_BUILD
     { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
+#endif
     dim3 grid(d->cd_pad / c.bco, (px + c.bpx - 1) / c.bpx, splits);
     k.gx = (int)grid.x;
     k.gy = (int)grid.y;
@@ -1794,7 +1804,9 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     k.gx = d->cy / bco;
     k.gy = d->kh * d->kw * d->cs / bci;
     k.splits = splits;
+#ifdef DSL_ABLATE_BUILD
     { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
+#endif
     k.chunk = (k.gx * k.gy * count * splits + 7) / 8;
     dim3 grid2(k.chunk * 8);
     const int kss[5] = {64, 64, 64, 64, 64}, nsts[5] = {2, 2, 3, 3, 2};

@@ -1,3 +1,6 @@
+"""Head-tower weight gradient under the ablation knobs (needs tools/build_ablate.sh):
+  for a in 0 1 2 3 4 5 6 7; do DSL_HIP_LIB=$PWD/dsl_amd/lib/libdsl_hip_ablate.so DSL_ABLATE=$a python tools/ablate_wgrad.py; done
+bits: 1 = no DMA after the first stage, 2 = no MFMA / LDS reads, 4 = no partial-tile writes."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
