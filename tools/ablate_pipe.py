@@ -14,6 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     N = 2
     LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
     shapes = {'head': (256, 256, 3, LEVELS), 'fpn': (256, 256, 3, LEVELS[:1]), 'l3': (256, 256, 3, [(50, 84)]),
+              'l2': (128, 128, 3, [(100, 168)]), 'l4': (512, 512, 3, [(25, 42)]), 'l2b': (128, 512, 1, [(100, 168)]),
               'l3b': (1024, 256, 1, [(50, 84)])}
     for which in sys.argv[2:]:
         ci, co, k, lv = shapes[which]
