@@ -875,7 +875,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   constexpr int ROWB = BCO * 4 + 16;
   constexpr int CPX = 32 * WPX;
   constexpr int GPR = BCO / 8;
-  static_assert(CPX * ROWB <= NST * STAGE, "epilogue staging must fit in the stage memory");
+  static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     __syncthreads();
@@ -1430,28 +1430,35 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, const RedK r, 
 // ================================================================================================
 namespace {
 // DMA-to-LDS tile configurations {BCO, BPX, workgroups per CU, ring depth}
-struct TileCfg { int bco, bpx, occ, nst; };
+struct TileCfg { int bco, bpx, occ, nst, wpx; };     // wpx: pixel-waves of the pipelined kernel (epilogue staging = 32*wpx pixels)
 constexpr int kNumCfg = 6;
-const TileCfg kCfgs[kNumCfg] = {{256, 192, 1, 2}, {256, 128, 1, 3}, {128, 256, 1, 3}, {128, 128, 2, 2}, {64, 256, 2, 2},
-                                {128, 64, 2, 3}};
+const TileCfg kCfgs[kNumCfg] = {{256, 192, 1, 2, 2}, {256, 128, 1, 3, 2}, {128, 256, 1, 3, 4}, {128, 128, 2, 2, 4}, {64, 256, 2, 2, 4},
+                                {128, 64, 2, 3, 2}};
 
 // strided data-gradients gather with per-tap divisibility tests: only the v2 kernel's general address path does that
 inline bool conv_v2_only(const dsl_conv_desc* d) { return d->mode == 1 && d->stride > 1; }
 
 // Launch-time cost model (microseconds) of one (tile config, split-K factor) choice.  Calibrated on MI355X
-// (tools/ablate_pipe.py, tools/bench_conv.py): per K tile a workgroup needs bco*bpx/32 MFMA cycles of its CU and
+// (tools/ablate_pipe.py, tools/bench_conv.py; the constants were fitted to the forced-config sweep of
+// `tools/bench_conv.py 2 0,1,2,3,4,5,6`: the model picks the measured-best tile on 12 of its 13 shapes, 1.9 us total
+// regret): per K tile a workgroup needs bco*bpx/32 MFMA cycles of its CU and
 // (bco+bpx)*128 B through the CU's 64 B/clk vector-memory path (~54 B/clk measured); co-resident workgroups share
 // both; the two overlap imperfectly.  Output and split-K partial traffic are HBM-rate terms.
-double conv_cost_us(const TileCfg& c, long long px, int cd_pad, int ktiles, int sp, bool out_f32) {
+double conv_cost_us(int ci, long long px, int cd_pad, int ktiles, int sp, bool out_f32) {
+  const TileCfg& c = kCfgs[ci];
+  // per-config efficiency of the K loop (the 8-wave 128x128 tile keeps 2 waves per SIMD even alone on a CU)
+  static const double kEff[kNumCfg] = {1.0, 1.0, 1.0, 0.7, 1.1, 0.9};
   const long long wgs = (long long)(cd_pad / c.bco) * ((px + c.bpx - 1) / c.bpx) * sp;
   const long long slots = 256LL * c.occ;
   const long long rounds = (wgs + slots - 1) / slots;
   const long long per_cu = (wgs + 255) / 256;
   const double share = (double)(per_cu < c.occ ? per_cu : c.occ);     // workgroups sharing a CU in a round
   const double mfma = c.bco * c.bpx / 32.0, dma = (c.bco + c.bpx) * 128 / 54.0;
-  const double tile = share * (1.15 * (mfma > dma ? mfma : dma) + 0.5 * (mfma > dma ? dma : mfma));
+  const double tile = share * (1.15 * (mfma > dma ? mfma : dma) + 0.5 * (mfma > dma ? dma : mfma)) * kEff[ci];
+  // per-workgroup fill + epilogue: grows with the tile, and co-resident workgroups overlap each other's
+  const double fixed = (1000.0 + 0.05 * c.bco * c.bpx) * (share > 1.0 ? share / 2.0 : share);
   const int kt = (ktiles + sp - 1) / sp;
-  double t = 4.0 + rounds * (kt * tile + 2500.0) / 2240.0;            // launch + prologue, main loop at ~2.24 GHz
+  double t = 4.0 + rounds * (kt * tile + fixed) / 2240.0;             // launch, then the rounds at ~2.24 GHz
   t += (double)px * cd_pad * (out_f32 ? 4 : 2) / 4.0e6;                // output write
   if (sp > 1) t += 3.0 + 2.0 * sp * px * cd_pad * 4 / 4.0e6;          // partial write + read, second launch
   return t;
@@ -1478,7 +1485,7 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
       for (int sp = 1; sp <= 16; ++sp) {
         if (sp > 1 && (!d->workspace || sp > ktiles / 2 || (size_t)sp * px * d->cd_pad * 4 > d->workspace_bytes)) break;
         if (force_split > 1 && sp != force_split) continue;
-        const double t = conv_cost_us(kCfgs[c], px, d->cd_pad, ktiles, sp, out_f32);
+        const double t = conv_cost_us(c, px, d->cd_pad, ktiles, sp, out_f32);
         if (t < best) { best = t; pick = c; splits = sp; }
       }
     }
@@ -1486,7 +1493,7 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
       for (int c = 0; c < kNumCfg; ++c) {
         if (d->cd_pad % kCfgs[c].bco || (force >= 1 && force <= kNumCfg && force - 1 != c)) continue;
         if (c == 5 && conv_v2_only(d)) continue;
-        const double t = conv_cost_us(kCfgs[c], px, d->cd_pad, ktiles, 1, out_f32);
+        const double t = conv_cost_us(c, px, d->cd_pad, ktiles, 1, out_f32);
         if (t < best) { best = t; pick = c; splits = 1; }
       }
     }
@@ -1584,10 +1591,16 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
 #endif
     dim3 grid(d->cd_pad / c.bco, (px + c.bpx - 1) / c.bpx, splits);
+    static const bool force_v2 = getenv("DSL_CONV_V2") != nullptr;
+    const bool force_v2_kernel = force_v2 || conv_v2_only(d);
     k.gx = (int)grid.x;
     k.gy = (int)grid.y;
     k.xcd_chunk = (int)((grid.x * grid.y * grid.z + 7) / 8);
-    const size_t lds = (size_t)c.nst * (c.bco + c.bpx) * 128;
+    size_t lds = (size_t)c.nst * (c.bco + c.bpx) * 128;
+    if (!force_v2_kernel) {                // the pipelined kernel stages its epilogue in LDS: 32*wpx pixel rows of fp32
+      const size_t stg = (size_t)32 * c.wpx * (c.bco * 4 + 16);
+      if (stg > lds) lds = stg;
+    }
     int prof = -1;
     if (dsl_prof_active()) prof = dsl_prof_begin(pick == 0 ? 0 : 1, 2.0 * px * (double)d->cd * d->kh * d->kw * d->cs, st);
 #define LAUNCH2(A, B, C_, D, S_)                                                                               \
@@ -1610,8 +1623,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     }                                                                                                         \
     hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_>), dim3(8 * k.xcd_chunk), dim3(64 * C_ * D), lds, st, k); \
   } while (0)
-    static const bool force_v2 = getenv("DSL_CONV_V2") != nullptr;
-    if (force_v2 || conv_v2_only(d)) {
+    if (force_v2_kernel) {
       switch (pick) {
         case 0: LAUNCH2(256, 192, 4, 2, 2); break;
         case 1: LAUNCH2(256, 128, 4, 2, 3); break;
@@ -1624,7 +1636,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
         case 0: LAUNCH3(256, 192, 4, 2, 2); break;
         case 1: LAUNCH3(256, 128, 4, 2, 3); break;
         case 2: LAUNCH3(128, 256, 2, 4, 3); break;
-        case 3: LAUNCH3(128, 128, 2, 2, 2); break;
+        case 3: LAUNCH3(128, 128, 2, 4, 2); break;
         case 4: LAUNCH3(64, 256, 1, 4, 2); break;
         default: LAUNCH3(128, 64, 2, 2, 3); break;
       }
