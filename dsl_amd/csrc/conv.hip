@@ -1432,7 +1432,7 @@ namespace {
 // DMA-to-LDS tile configurations {BCO, BPX, workgroups per CU, ring depth}
 struct TileCfg { int bco, bpx, occ, nst, wpx; };     // wpx: pixel-waves of the pipelined kernel (epilogue staging = 32*wpx pixels)
 constexpr int kNumCfg = 6;
-const TileCfg kCfgs[kNumCfg] = {{256, 192, 1, 2, 2}, {256, 128, 1, 3, 2}, {128, 256, 1, 3, 4}, {128, 128, 2, 2, 4}, {64, 256, 2, 2, 4},
+const TileCfg kCfgs[kNumCfg] = {{256, 192, 1, 2, 2}, {256, 128, 1, 3, 2}, {128, 256, 1, 3, 4}, {128, 128, 2, 2, 4}, {64, 256, 2, 2, 8},
                                 {128, 64, 2, 3, 2}};
 
 // strided data-gradients gather with per-tap divisibility tests: only the v2 kernel's general address path does that
@@ -1447,7 +1447,7 @@ inline bool conv_v2_only(const dsl_conv_desc* d) { return d->mode == 1 && d->str
 double conv_cost_us(int ci, long long px, int cd_pad, int ktiles, int sp, bool out_f32) {
   const TileCfg& c = kCfgs[ci];
   // per-config efficiency of the K loop (the 8-wave 128x128 tile keeps 2 waves per SIMD even alone on a CU)
-  static const double kEff[kNumCfg] = {1.0, 1.0, 1.0, 0.7, 1.1, 0.9};
+  static const double kEff[kNumCfg] = {1.0, 1.0, 1.0, 0.7, 0.95, 0.9};
   const long long wgs = (long long)(cd_pad / c.bco) * ((px + c.bpx - 1) / c.bpx) * sp;
   const long long slots = 256LL * c.occ;
   const long long rounds = (wgs + slots - 1) / slots;
@@ -1637,7 +1637,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
         case 1: LAUNCH3(256, 128, 4, 2, 3); break;
         case 2: LAUNCH3(128, 256, 2, 4, 3); break;
         case 3: LAUNCH3(128, 128, 2, 4, 2); break;
-        case 4: LAUNCH3(64, 256, 1, 4, 2); break;
+        case 4: LAUNCH3(64, 256, 1, 8, 2); break;
         default: LAUNCH3(128, 64, 2, 2, 3); break;
       }
     }
