@@ -88,20 +88,26 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __re
   }
 }
 
-__global__ void pack_dgrad_batched_kernel(const dsl_pack_item* __restrict__ items, int n) {
-  __shared__ float tile[32][33];
-  // locate this block's conv (n <= a few dozen: linear scan of the prefix sums)
-  int it = 0;
-  while (it + 1 < n && (int)blockIdx.x >= items[it + 1].block_start) ++it;
-  const dsl_pack_item I = items[it];
+// one 64x64 (cout x cin) tile of one tap per block: 256-byte fp32 rows in, 128-byte bf16 rows out
+__global__ __launch_bounds__(256) void pack_dgrad_batched_kernel(const dsl_pack_item* __restrict__ items, int n) {
+  __shared__ float tile[64][65];
+  // locate this block's conv: binary search over the block_start prefix sums (a linear scan is a chain of up to
+  // n dependent global loads per block)
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= items[mid].block_start) lo = mid; else hi = mid - 1;
+  }
+  const dsl_pack_item I = items[lo];
   int b = blockIdx.x - I.block_start;
   const int tci = b % I.tiles_ci;
   b /= I.tiles_ci;
   const int tco = b % I.tiles_co;
   const int t = b / I.tiles_co;
-  const int ci0 = tci * 32, co0 = tco * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) {
+  const int ci0 = tci * 64, co0 = tco * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
     const int co = co0 + r, ci = ci0 + tx;
     float v = 0.f;
     if (co < I.cout && ci < I.cin) {
@@ -112,7 +118,8 @@ __global__ void pack_dgrad_batched_kernel(const dsl_pack_item* __restrict__ item
   }
   __syncthreads();
   uint16_t* out = (uint16_t*)I.out;
-  for (int r = ty; r < 32; r += 8) {
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
     const int ci = ci0 + r, co = co0 + tx;
     if (ci < I.cin && co < I.cout_pad) out[((long long)ci * I.taps + t) * I.cout_pad + co] = f2bf(tile[tx][r]);
   }

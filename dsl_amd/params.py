@@ -278,7 +278,7 @@ class ParamStore:
                 it = L.PackItem()
                 it.w, it.scale, it.out = w.data_ptr(), (sc.data_ptr() if sc is not None else 0), self.wT16.data_ptr() + off * 2
                 it.cout, it.cout_pad, it.taps, it.cin = co, cop, taps, cin
-                it.tiles_ci, it.tiles_co, it.block_start = (cin + 31) // 32, (cop + 31) // 32, start
+                it.tiles_ci, it.tiles_co, it.block_start = (cin + 63) // 64, (cop + 63) // 64, start     # 64x64 tiles (optim.hip)
                 start += it.tiles_ci * it.tiles_co * taps
                 items.append(it)
             arr = (L.PackItem * len(items))(*items)

@@ -215,7 +215,7 @@ int dsl_pack_dgrad(const float* w, const float* scale, void* out, int cout, int 
 typedef struct dsl_pack_item {
   const float* w; const float* scale; void* out;
   int32_t cout, cout_pad, taps, cin;
-  int32_t block_start, tiles_ci, tiles_co, pad_;       /* block_start: prefix sum of tiles_ci*tiles_co*taps */
+  int32_t block_start, tiles_ci, tiles_co, pad_;       /* 64x64 (cout x cin) tiles; block_start: prefix sum of tiles_ci*tiles_co*taps */
 } dsl_pack_item;
 int dsl_pack_dgrad_batched(const dsl_pack_item* items_dev, int n, int total_blocks, void* stream);
 
