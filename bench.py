@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 GFLOP_PER_IMAGE_STEP = 1185.8      # SURVEY.md §8d / BASELINE.md: fwd 419.55 + bwd 766.23 GFLOP per 800x1344 image
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
-DOMINANT = 'conv_pipe_kernel<256, 192, 4, 2, 2>'    # the kernel class 0 of dsl_prof_* brackets (largest share of the step)
+DOMINANT = 'conv_pipe_kernel<128, 128, 2, 4, 2>'    # the kernel class 0 of dsl_prof_* brackets (largest share of the step)
 
 
 def model_cfg(dsl=False):
@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--imgs-per-gpu', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket the conv kernels with HIP events')
-    ap.add_argument('--prof-all', action='store_true', help='bracket every conv / wgrad launch (perturbs stream overlap)')
+    ap.add_argument('--prof-light', action='store_true', help='bracket only the dominant kernel class in the instrumented pass')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -151,13 +151,13 @@ def main():
     dt, out = timed(args.steps)
     # (2) the same steps again with a HIP event pair around every launch of the dominant kernel (on its launch
     # stream).  Kept out of region (1) because the event records serialise the concurrently running streams
-    # (measured: -6 % throughput with class 0 only, -12 % with every conv / wgrad launch bracketed).
+    # (measured: -6 % throughput with one class, -12 % with every conv / wgrad launch bracketed).
     dt_prof = None
     if not args.no_prof:
         if world > 1:
             dist.barrier()
         L.lib.dsl_prof_reset()
-        L.lib.dsl_prof_enable(2 if args.prof_all else 1)
+        L.lib.dsl_prof_enable(1 if args.prof_light else 2)
         dt_prof, _ = timed(args.steps)
         L.lib.dsl_prof_enable(0)
     if world > 1:
@@ -179,25 +179,27 @@ def main():
             traffic = tj['kernels'][DOMINANT]['hbm_bytes_per_launch']
             traffic_src = 'profiles/traffic.json: ' + tj.get('source', '')
     if not args.no_prof:
-        launches = (C.c_int64 * 3)()
-        ms = (C.c_double * 3)()
-        fl = (C.c_double * 3)()
+        NC = 4
+        launches = (C.c_int64 * NC)()
+        ms = (C.c_double * NC)()
+        fl = (C.c_double * NC)()
         L.lib.dsl_prof_read(launches, ms, fl)
+
+        def cls(i):
+            return dict(achieved=round(fl[i] / (ms[i] * 1e-3) / 1e12, 1) if launches[i] else None,
+                        avg_launch_us=round(ms[i] * 1e3 / max(launches[i], 1), 2), launches_per_step=launches[i] // args.steps,
+                        ms_per_step=round(ms[i] / args.steps, 3))
         if launches[0]:
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel=DOMINANT + ' (forward + data-gradient implicit GEMM, 256x192 tile)',
+            roof = dict(bound='mfma', kernel=DOMINANT + ' (forward + data-gradient implicit GEMM, 8-wave 128x128 tile: the '
+                        'backbone / predictor convolutions; largest share of the step)',
                         achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, traffic_source=traffic_src, measured='HIP event pairs on the launch stream, second pass of the same %d steps '
-                        '(%.3f ms/step while instrumented)' % (args.steps, dt_prof / args.steps * 1e3),
+                        traffic=traffic, traffic_source=traffic_src, measured='HIP event pairs on the launch stream, second pass '
+                        'of the same %d steps (%.3f ms/step while instrumented)' % (args.steps, dt_prof / args.steps * 1e3),
                         launches_per_step=launches[0] // args.steps,
                         avg_launch_us=round(ms[0] * 1e3 / launches[0], 2),
                         algorithmic_gflop_per_launch=round(fl[0] / launches[0] / 1e9, 3),
-                        other_conv_kernels=dict(achieved=round(fl[1] / (ms[1] * 1e-3) / 1e12, 1) if launches[1] else None,
-                                                avg_launch_us=round(ms[1] * 1e3 / max(launches[1], 1), 2),
-                                                launches_per_step=launches[1] // args.steps),
-                        wgrad_kernels=dict(achieved=round(fl[2] / (ms[2] * 1e-3) / 1e12, 1) if launches[2] else None,
-                                           avg_launch_us=round(ms[2] * 1e3 / max(launches[2], 1), 2),
-                                           launches_per_step=launches[2] // args.steps),
+                        head_tile_256x192=cls(1), other_conv_kernels=cls(2), wgrad_kernels=cls(3),
                         whole_step_frac=round(value / world * GFLOP_PER_IMAGE_STEP / 1e3 / PEAK_BF16_TFLOPS, 4))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1602,7 +1602,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
       if (stg > lds) lds = stg;
     }
     int prof = -1;
-    if (dsl_prof_active()) prof = dsl_prof_begin(pick == 0 ? 0 : 1, 2.0 * px * (double)d->cd * d->kh * d->kw * d->cs, st);
+    if (dsl_prof_active()) prof = dsl_prof_begin(pick == 3 ? 0 : (pick == 0 ? 1 : 2), 2.0 * px * (double)d->cd * d->kh * d->kw * d->cs, st);
 #define LAUNCH2(A, B, C_, D, S_)                                                                               \
   do {                                                                                                        \
     static bool attr_set = false;                                                                             \
@@ -1669,7 +1669,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   int prof = -1;
   if (dsl_prof_active()) {
     const double cin_real = smallc ? 3.0 : (double)d->cs;
-    prof = dsl_prof_begin(1, 2.0 * px * (double)d->cd * d->kh * d->kw * cin_real, st);
+    prof = dsl_prof_begin(2, 2.0 * px * (double)d->cd * d->kh * d->kw * cin_real, st);
   }
   if (bco == 128) {
     if (smallc) LAUNCH(128, true); else LAUNCH(128, false);
@@ -1808,7 +1808,7 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     k.xv[g] = (const uint16_t*)descs[g < count ? g : 0].x;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int prof = dsl_prof_active() ? dsl_prof_begin(2, 2.0 * count * px * (double)d->cd * d->kh * d->kw * d->cs, st) : -1;
+  const int prof = dsl_prof_active() ? dsl_prof_begin(3, 2.0 * count * px * (double)d->cd * d->kh * d->kw * d->cs, st) : -1;
   if (cfg >= 1) {
     const int bcis[5] = {128, 256, 128, 256, 128};
     const int bci = bcis[cfg];

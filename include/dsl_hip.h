@@ -264,14 +264,15 @@ int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Live kernel timing with HIP events (bench.py roofline): when enabled, each launch of the MFMA
- * conv kernels is bracketed by a hipEvent pair on the launch stream.  Classes: 0 = conv_glds_kernel
- * <256,192,4,2,2> (forward + data gradient, the dominant kernel), 1 = every other forward/dgrad conv
- * kernel instance, 2 = the weight-gradient kernels.
+ * conv kernels is bracketed by a hipEvent pair on the launch stream.  Classes: 0 = conv_pipe_kernel
+ * <128,128,2,4,2> (forward + data gradient; the kernel with the largest share of the step), 1 = conv_pipe_kernel
+ * <256,192,4,2,2> (the head / FPN tile), 2 = every other forward/dgrad conv kernel instance, 3 = the
+ * weight-gradient kernels.
  * dsl_prof_enable(1) brackets only class 0 (cheap enough for a timed region), dsl_prof_enable(2) every class
  * (event pairs on concurrently running streams perturb the overlap).
  * dsl_prof_read synchronises the events and returns per class: launches, total ms, algorithmic FLOPs.
  * ---------------------------------------------------------------------------------------- */
-#define DSL_PROF_CLASSES 3
+#define DSL_PROF_CLASSES 4
 int dsl_prof_enable(int on);
 int dsl_prof_reset(void);
 int dsl_prof_read(int64_t* launches, double* ms, double* flops);
