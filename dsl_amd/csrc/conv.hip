@@ -1387,6 +1387,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
 struct RedK {
   float* dw[DSL_MAX_GROUP];
   const float* scale[DSL_MAX_GROUP];
+  float* db[DSL_MAX_GROUP];        // bias-gradient vectors to clear for the column-sum kernel that follows (or NULL)
 };
 
 // sums the split partials ws[split][member][cy][krow] of member blockIdx.y into its dW (x scale)
@@ -1399,6 +1400,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, const RedK r, 
   for (int g = 1; g < DSL_MAX_GROUP; ++g) {
     dw = member == g ? r.dw[g] : dw;
     scale = member == g ? r.scale[g] : scale;
+  }
+  if (blockIdx.x == 0) {
+    float* db = r.db[0];
+#pragma unroll
+    for (int g = 1; g < DSL_MAX_GROUP; ++g) db = member == g ? r.db[g] : db;
+    if (db)
+      for (int c = threadIdx.x; c < cd; c += blockDim.x) db[c] = 0.f;
   }
   const long long total4 = (long long)cd * krow / 4;
   const long long sstride = (long long)group * cy * krow;
@@ -1741,6 +1749,7 @@ extern "C" size_t dsl_wgrad_group_workspace_bytes(const dsl_wgrad_desc* descs, i
 }
 
 extern "C" int dsl_colsum(const void* x, float* out, long rows, int c, int ld, void* stream);
+int dsl_colsum_acc(const void* x, float* out, long rows, int c, int ld, void* stream);   // no memset: out += column sums
 
 static bool wgrad_same_geometry(const dsl_wgrad_desc* a, const dsl_wgrad_desc* b) {
   if (a->nseg != b->nseg || a->n != b->n || a->cs != b->cs || a->cy != b->cy || a->cd != b->cd || a->kh != b->kh ||
@@ -1866,13 +1875,14 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
   for (int g = 0; g < DSL_MAX_GROUP; ++g) {
     r.dw[g] = descs[g < count ? g : 0].dw;
     r.scale[g] = descs[g < count ? g : 0].scale;
+    r.db[g] = g < count ? descs[g].db : nullptr;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb, count), dim3(256), 0, st, (const float*)d->workspace, r, splits, count,
                      d->cy, d->cd, k.krow);
   DSL_LAUNCH_CHECK("wgrad_reduce_kernel");
   for (int g = 0; g < count; ++g)
-    if (descs[g].db) {
-      const int rc = dsl_colsum(descs[g].dy, descs[g].db, (long)px, d->cd, d->cy, stream);
+    if (descs[g].db) {       // db was cleared by the reduce kernel above
+      const int rc = dsl_colsum_acc(descs[g].dy, descs[g].db, (long)px, d->cd, d->cy, stream);
       if (rc) return rc;
     }
   return 0;

@@ -428,6 +428,17 @@ extern "C" int dsl_sum2x2(const void* g, void* out, int n, int h, int w, int ch,
   return 0;
 }
 
+// out += column sums (the caller cleared out): used behind the weight-gradient reduce kernel, which clears db
+int dsl_colsum_acc(const void* x, float* out, long rows, int c, int ld, void* stream) {
+  DSL_CHECK(x && out && c > 0 && c <= 2048 && ld % 8 == 0 && ld >= c, "dsl_colsum: bad arguments c=%d ld=%d", c, ld);
+  DSL_CHECK((c + 7) / 8 <= 256, "dsl_colsum: too many channels");
+  const int blocks = (int)((rows + CS_RPB - 1) / CS_RPB);
+  if (blocks > 0)
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, out, (long long)rows, c, ld);
+  DSL_LAUNCH_CHECK("colsum_kernel");
+  return 0;
+}
+
 extern "C" int dsl_colsum(const void* x, float* out, long rows, int c, int ld, void* stream) {
   DSL_CHECK(x && out && c > 0 && c <= 2048 && ld % 8 == 0 && ld >= c, "dsl_colsum: bad arguments c=%d ld=%d", c, ld);
   DSL_CHECK((c + 7) / 8 <= 256, "dsl_colsum: too many channels");

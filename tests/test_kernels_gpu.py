@@ -344,6 +344,30 @@ def test_wgrad_multilevel_padded_cout(K):
     assert torch.allclose(dw.cpu(), ref, rtol=1e-2, atol=2e-2 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('co', [5, 8])
+def test_wgrad_small_cout(K, co):
+    """conv_reg + conv_centerness weight gradient: 5 (8) real output channels in 64-channel dY rows over 5 level
+    segments, with the bias gradient (cleared by the reduce kernel, accumulated by the column-sum kernel)."""
+    L, ops = K
+    g = torch.Generator().manual_seed(23)
+    N, sizes, cy = 2, [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)], 64
+    xs = [rnd(N, 256, h, w, g=g) for h, w in sizes]
+    dys = [rnd(N, co, h, w, g=g) for h, w in sizes]
+    w = torch.zeros(co, 256, 3, 3, requires_grad=True)
+    sum((F.conv2d(x, w, None, 1, 1) * dy).sum() for x, dy in zip(xs, dys)).backward()
+    ref = w.grad.permute(0, 2, 3, 1)
+    dyp = torch.cat([torch.cat([d.permute(0, 2, 3, 1), torch.zeros(N, d.shape[2], d.shape[3], cy - co)], -1)
+                     .reshape(-1, cy) for d in dys]).bfloat16().cuda()
+    dw = torch.full((co, 3, 3, 256), float('nan'), dtype=torch.float32, device='cuda')
+    db = torch.full((co,), float('nan'), dtype=torch.float32, device='cuda')
+    ops.conv2d_wgrad(dyp, _multiseg(xs), dw, n=N, grid=sizes, src_hw=sizes, cs=256, cy=cy, cd=co, kh=3, kw=3, stride=1,
+                     pad=1, db=db)
+    sync()
+    assert torch.allclose(dw.cpu(), ref, rtol=1e-2, atol=2e-2 * float(ref.abs().max())), (dw.cpu() - ref).abs().max()
+    rdb = sum(d.sum((0, 2, 3)) for d in dys)
+    assert torch.allclose(db.cpu(), rdb, rtol=1e-3, atol=1e-2)
+
+
 def test_groupnorm_relu_fwd_bwd(K):
     L, ops = K
     g = torch.Generator().manual_seed(4)
