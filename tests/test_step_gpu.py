@@ -149,3 +149,28 @@ def test_eager_backward_same_gradients():
     assert abs(losses[0] - losses[1]) < 1e-4 * abs(losses[0])
     assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
     assert rel_l2(grads[1], grads[0]) < 1e-2
+
+
+def test_full_size_losses_and_assignment_vs_oracle():
+    """BASELINE.json configs[1] at its real size (2 x 3 x 800 x 1344, the bench.py workload): the three losses within
+    1e-3 relative of the fp32 CPU oracle, and bit-identical target assignment on all 44 800 locations."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import fcos_oracle as O
+    model = build()
+    b = bench.synth_batch(0, 2)
+    losses = model.forward_train(b['img'], b['img_metas'], b['gt_bboxes'], b['gt_labels'])
+    torch.cuda.synchronize()
+    l32, _, aux = O.train_step(O.synth_state_dict(0), b['img'].cpu(), b['gt_bboxes'], b['gt_labels'], None,
+                               emulate_bf16=False, want_grads=False)
+    for k, v in losses.items():
+        assert float(v.detach()) == pytest.approx(l32[k], rel=1e-3), (k, float(v.detach()), l32[k])
+    plan = next(iter(model._engine.plans.values()))
+    with torch.no_grad():
+        _, raux = O.fcos_loss([t.detach() for t in aux['cls']], [t.detach() for t in aux['reg']],
+                              [t.detach() for t in aux['ctr']], b['gt_bboxes'], b['gt_labels'], None, return_aux=True)
+    assert plan.lossplan.assign_idx.numel() == 2 * 22400
+    assert torch.equal(plan.lossplan.assign_idx.cpu().long(), raux['assign_idx'])
+    assert torch.equal(plan.lossplan.labels.cpu(), raux['labels'])
