@@ -1728,7 +1728,8 @@ static int wgrad_splits_for(const dsl_wgrad_desc* d, int count) {
     // two lanes per clock per channel.)
     splits = 256 * per_cu / tiles;
   }
-  if (const char* e = getenv("DSL_WGRAD_SPLITS")) { const int v = atoi(e); if (v > 0 && cfg != 0) splits = v; }
+  static const int forced_splits = [] { const char* e = getenv("DSL_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();   // tuning knob
+  if (forced_splits > 0 && cfg != 0) splits = forced_splits;
   if (splits > max_by_k) splits = max_by_k;
   if (splits < 1) splits = 1;
   if (splits > 256) splits = 256;

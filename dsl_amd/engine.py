@@ -336,7 +336,9 @@ class Plan:
         reg = st.train_regions
         M = self.M
         SIDE = True
-        GROUP_LAST = os.environ.get('DSL_GROUP_LAST', '1') != '0'  # ... also in the last segment (nothing left on the main stream to overlap its tail with)
+        # tuning knobs (both measured: on is better): group the last segment's weight gradients too, although nothing
+        # is left on the caller's stream to overlap their tail with ...
+        GROUP_LAST = os.environ.get('DSL_GROUP_LAST', '1') != '0'
         GROUP = True       # same-geometry weight gradients (tower layers, the blocks of a stage) as one launch
         g_feats = self.buf('g_feats', M, 256)
         # ================= segment 0: head + FPN =================
