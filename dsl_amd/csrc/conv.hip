@@ -636,7 +636,10 @@ __device__ __forceinline__ void sched_stage() {      // NMF x { 1 MFMA [, 1 DS r
   }
 }
 
-template <int BCO, int BPX, int WCO, int WPX, int NST>
+// SMC: the source has 8 channels per pixel (the NHWC8 image of the 7x7 stem): one 16-byte DMA lane is one TAP, a K tile
+// is 8 consecutive taps, so every lane gathers its own tap's pixel (K index = tap*8 + channel, as the stem weights
+// are packed).
+template <int BCO, int BPX, int WCO, int WPX, int NST, bool SMC = false>
 __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int T = 64 * WCO * WPX;
@@ -682,6 +685,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   int tap_r = (kt0 / p.kc) / p.kw, tap_s = (kt0 / p.kc) % p.kw;
 
   unsigned r_cur[XPASS], r_step[XPASS], r_mask[XPASS];
+  int r_y[XPASS], r_x[XPASS], r_hw[XPASS];            // SMC: top-left source pixel of the window, source size
 #pragma unroll
   for (int i = 0; i < XPASS; ++i) {
     const int gp = px0 + lrow + RPP * i;
@@ -689,6 +693,14 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
     const bool ok = gp < totpx;
     if (ok) decode_pixel(p, gp, seg, img, y, x);
     const int sh = p.sh[seg], sw = p.sw[seg];
+    if (SMC) {
+      r_y[i] = ok ? y * p.stride - p.pad : -100000;    // not ok: every tap fails the bounds test
+      r_x[i] = x * p.stride - p.pad;
+      r_hw[i] = (sh << 16) | sw;
+      r_cur[i] = (unsigned)(((int)(p.soff[seg]) + img * sh * sw + r_y[i] * sw + r_x[i]) * 16) + margin;
+      r_step[i] = r_mask[i] = 0;
+      continue;
+    }
     const int row0 = p.mode == 0 ? y * p.stride - p.pad : y + p.pad;               // source row of tap r = 0
     const int col0 = p.mode == 0 ? x * p.stride - p.pad : x + p.pad - (p.kw - 1);  // leftmost source column
     unsigned m = 0;
@@ -727,14 +739,31 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
     const unsigned sel = live ? ((1u << tap_r) | (0x100u << tap_s)) : 0xffffffffu;
     const unsigned s_off = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.cs * 2 + cidx * 128);
     const unsigned wv = live ? w_voff : 0x80000000u;
+    int s_tr = 0, s_ts = 0;
+    bool s_ok = false;
+    if (SMC) {                    // this lane's tap of the K tile
+      const int tap = kt_next * 8 + chunk;
+      s_tr = tap / p.kw;
+      s_ts = tap - s_tr * p.kw;
+      s_ok = live && tap < p.kh * p.kw;
+    }
 #pragma unroll
     for (int j = LO; j < HI; ++j) {
 #ifdef DSL_ABLATE_BUILD
       if (p.dbg & (j < XPASS ? 1 : 2)) continue;
 #endif
       if (j < XPASS) {
-        const unsigned v = (r_mask[j] & sel) == sel ? r_cur[j] : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lptr_t)(stage + TILE_W + (j * RPP + wave * 8) * 128), 16, v, s_off, 0, 0);
+        unsigned v, so;
+        if (SMC) {
+          const int sh = r_hw[j] >> 16, sw = r_hw[j] & 0xffff;
+          const bool in = s_ok && (unsigned)(r_y[j] + s_tr) < (unsigned)sh && (unsigned)(r_x[j] + s_ts) < (unsigned)sw;
+          v = in ? r_cur[j] + (unsigned)((s_tr * sw + s_ts) * 16) : 0x80000000u;
+          so = 0;
+        } else {
+          v = (r_mask[j] & sel) == sel ? r_cur[j] : 0x80000000u;
+          so = s_off;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lptr_t)(stage + TILE_W + (j * RPP + wave * 8) * 128), 16, v, so, 0, 0);
       } else {
         const int i = j - XPASS;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lptr_t)(stage + (i * RPP + wave * 8) * 128), 16, wv,
@@ -1482,7 +1511,8 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
   for (int sg = 0; sg < d->nseg; ++sg) src_px += (long long)d->n * d->sh[sg] * d->sw[sg];
   // the DMA kernels address the source with 32-bit buffer offsets and per-axis tap masks
   const bool dma_ok = conv_v2_only(d) || (d->kh <= 8 && d->kw <= 8 && src_px * d->cs * 2 + (long long)d->kw * d->cs * 2 < 0x7fff0000LL);
-  const bool v1_only = smallc || (d->flags & DSL_CONV_RELU_IN) || !dma_ok;
+  const bool smallc_pipe = smallc && d->cd_pad % 64 == 0 && !getenv("DSL_STEM_V1");    // stem: pipelined kernel, 64-cout tile
+  const bool v1_only = (smallc && !smallc_pipe) || (d->flags & DSL_CONV_RELU_IN) || !dma_ok;
   if (!v1_only && force != 15) {
     double best = 1e300;
     const bool out_f32 = (d->flags & DSL_CONV_OUT_F32) != 0;
@@ -1490,7 +1520,9 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
       if (d->cd_pad % kCfgs[c].bco) continue;
       if (force >= 1 && force <= kNumCfg && force - 1 != c) continue;
       if (c == 5 && conv_v2_only(d)) continue;       // the 128x64 tile exists for the pipelined kernel only
+      if (smallc && c != 4) continue;                // the 8-channel-source variant is instantiated for the 64x256 tile
       for (int sp = 1; sp <= 16; ++sp) {
+        if (sp > 1 && smallc) break;
         if (sp > 1 && (!d->workspace || sp > ktiles / 2 || (size_t)sp * px * d->cd_pad * 4 > d->workspace_bytes)) break;
         if (force_split > 1 && sp != force_split) continue;
         const double t = conv_cost_us(c, px, d->cd_pad, ktiles, sp, out_f32);
@@ -1610,7 +1642,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
       if (stg > lds) lds = stg;
     }
     int prof = -1;
-    if (dsl_prof_active()) prof = dsl_prof_begin(pick == 3 ? 0 : (pick == 0 ? 1 : 2), 2.0 * px * (double)d->cd * d->kh * d->kw * d->cs, st);
+    if (dsl_prof_active()) prof = dsl_prof_begin(pick == 3 ? 0 : (pick == 0 ? 1 : 2), 2.0 * px * (double)d->cd * d->kh * d->kw * (smallc ? 3.0 : (double)d->cs), st);
 #define LAUNCH2(A, B, C_, D, S_)                                                                               \
   do {                                                                                                        \
     static bool attr_set = false;                                                                             \
@@ -1645,7 +1677,15 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
         case 1: LAUNCH3(256, 128, 4, 2, 3); break;
         case 2: LAUNCH3(128, 256, 2, 4, 3); break;
         case 3: LAUNCH3(128, 128, 2, 4, 2); break;
-        case 4: LAUNCH3(64, 256, 1, 8, 2); break;
+        case 4:
+          if (smallc) {
+            static bool a4 = false;
+            if (!a4) { hipFuncSetAttribute((const void*)conv_pipe_kernel<64, 256, 1, 8, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a4 = true; }
+            hipLaunchKernelGGL((conv_pipe_kernel<64, 256, 1, 8, 2, true>), dim3(8 * k.xcd_chunk), dim3(512), lds, st, k);
+          } else {
+            LAUNCH3(64, 256, 1, 8, 2);
+          }
+          break;
         default: LAUNCH3(128, 64, 2, 2, 3); break;
       }
     }
