@@ -657,6 +657,9 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD owns a contiguous run of tiles in (cout tile
   // fastest, then pixel tile, then K split) order, so neighbouring pixel tiles - which share their halo rows - and
   // the cout tiles of one pixel range hit the same L2 instead of being fetched into up to three of them.
+#ifdef DSL_ABLATE_BUILD
+  if (p.dbg & 128) return;                   // launch + dispatch floor
+#endif
   const int wi = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= p.xcd_chunk || wi >= p.gx * p.gy * p.splits) return;
   const int bz = wi / (p.gx * p.gy);
@@ -789,6 +792,9 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   using cp1_t = std::integral_constant<int, P1>;
   using clpt_t = std::integral_constant<int, LPT>;
 
+#ifdef DSL_ABLATE_BUILD
+  if (p.dbg & 256) return;                   // + kernel-argument loads and the per-pixel decode
+#endif
   f32x16 acc[2][PT];
 #pragma unroll
   for (int a = 0; a < 2; ++a)

@@ -38,7 +38,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     print()
 else:
     env = dict(os.environ, DSL_HIP_LIB=os.path.join(ROOT, 'dsl_amd', 'lib', 'libdsl_hip_ablate.so'))
-    names = {0: 'full', 1: 'no pixel DMA', 2: 'no weight DMA', 3: 'no DMA', 4: 'no MFMA', 5: 'weights DMA only', 6: 'pixel DMA only', 7: 'nothing', 8: 'one K tile', 24: 'one K tile, no epilogue', 16: 'no epilogue', 23: 'LDS reads+barriers only', 19: 'MFMA+LDS, no epilogue', 51: 'MFMA+LDS, no barrier, no epi', 83: 'MFMA+barrier, no LDS reads, no epi', 115: 'MFMA only, no epi', 16: 'no epilogue', 48: 'no barrier, no epi', 80: 'no LDS reads, no epi'}
+    names = {0: 'full', 1: 'no pixel DMA', 2: 'no weight DMA', 3: 'no DMA', 4: 'no MFMA', 5: 'weights DMA only', 6: 'pixel DMA only', 7: 'nothing', 8: 'one K tile', 24: 'one K tile, no epilogue', 16: 'no epilogue', 23: 'LDS reads+barriers only', 19: 'MFMA+LDS, no epilogue', 51: 'MFMA+LDS, no barrier, no epi', 83: 'MFMA+barrier, no LDS reads, no epi', 115: 'MFMA only, no epi', 128: 'launch + dispatch only', 256: 'launch + decode prologue', 16: 'no epilogue', 48: 'no barrier, no epi', 80: 'no LDS reads, no epi'}
     for knob in ([int(a) for a in os.environ['KNOBS'].split(',')] if 'KNOBS' in os.environ else (0, 4, 1, 2, 3, 5, 6, 7, 8, 24, 16, 23)):
         env['DSL_ABLATE'] = str(knob)
         print(f'{names.get(knob, str(knob)):26s}', flush=True)
