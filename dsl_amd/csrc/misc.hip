@@ -302,11 +302,12 @@ __global__ void sum_children_kernel(const uint16_t* __restrict__ g, uint16_t* __
 
 // ---- column sums of a bf16 [rows][ld] matrix ---------------------------------------------------
 constexpr int CS_RPB = 128;
-__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ x, float* __restrict__ out,
+constexpr int CS_T = 512;      // 8 waves per block (see GN_T)
+__global__ __launch_bounds__(CS_T) void colsum_kernel(const uint16_t* __restrict__ x, float* __restrict__ out,
                                                       long long rows, int c, int ld) {
-  __shared__ float sh[256 * 8];
+  __shared__ float sh[CS_T * 8];
   const int cpr = (c + 7) / 8;                 // chunks per row actually needed
-  const int ppi = 256 / cpr;
+  const int ppi = CS_T / cpr;
   const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long r0 = (long long)blockIdx.x * CS_RPB, r1 = min(r0 + CS_RPB, rows);
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
 #pragma unroll
   for (int e = 0; e < 8; ++e) sh[threadIdx.x * 8 + e] = (prow < ppi) ? a[e] : 0.f;
   __syncthreads();
-  for (int ch = threadIdx.x; ch < c; ch += 256) {
+  for (int ch = threadIdx.x; ch < c; ch += CS_T) {
     float s = 0.f;
     for (int r = 0; r < ppi; ++r) s += sh[(r * cpr + ch / 8) * 8 + (ch % 8)];
     atomicAdd(out + ch, s);
@@ -431,22 +432,22 @@ extern "C" int dsl_sum2x2(const void* g, void* out, int n, int h, int w, int ch,
 // out += column sums (the caller cleared out): used behind the weight-gradient reduce kernel, which clears db
 int dsl_colsum_acc(const void* x, float* out, long rows, int c, int ld, void* stream) {
   DSL_CHECK(x && out && c > 0 && c <= 2048 && ld % 8 == 0 && ld >= c, "dsl_colsum: bad arguments c=%d ld=%d", c, ld);
-  DSL_CHECK((c + 7) / 8 <= 256, "dsl_colsum: too many channels");
+  DSL_CHECK((c + 7) / 8 <= CS_T, "dsl_colsum: too many channels");
   const int blocks = (int)((rows + CS_RPB - 1) / CS_RPB);
   if (blocks > 0)
-    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, out, (long long)rows, c, ld);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(CS_T), 0, (hipStream_t)stream, (const uint16_t*)x, out, (long long)rows, c, ld);
   DSL_LAUNCH_CHECK("colsum_kernel");
   return 0;
 }
 
 extern "C" int dsl_colsum(const void* x, float* out, long rows, int c, int ld, void* stream) {
   DSL_CHECK(x && out && c > 0 && c <= 2048 && ld % 8 == 0 && ld >= c, "dsl_colsum: bad arguments c=%d ld=%d", c, ld);
-  DSL_CHECK((c + 7) / 8 <= 256, "dsl_colsum: too many channels");
+  DSL_CHECK((c + 7) / 8 <= CS_T, "dsl_colsum: too many channels");
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(out, 0, sizeof(float) * c, st);
   const int blocks = (int)((rows + CS_RPB - 1) / CS_RPB);
   if (blocks > 0)
-    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)x, out, (long long)rows, c, ld);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(CS_T), 0, st, (const uint16_t*)x, out, (long long)rows, c, ld);
   DSL_LAUNCH_CHECK("colsum_kernel");
   return 0;
 }
