@@ -175,8 +175,9 @@ def main():
     tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic.json')
     if os.path.exists(tf):
         tj = json.load(open(tf))
-        if DOMINANT in tj.get('kernels', {}):
-            traffic = tj['kernels'][DOMINANT]['hbm_bytes_per_launch']
+        hit = [k for k in tj.get('kernels', {}) if k.startswith(DOMINANT[:-1])]     # the symbol carries further template args
+        if hit:
+            traffic = tj['kernels'][hit[0]]['hbm_bytes_per_launch']
             traffic_src = 'profiles/traffic.json: ' + tj.get('source', '')
     if not args.no_prof:
         NC = 4
