@@ -1,0 +1,113 @@
+"""The data-parallel training step with the REAL engine: two ranks (two processes sharing cuda:0, gloo collectives on
+device tensors) run forward + loss + hand-written backward with the bucketed, event-ordered gradient all-reduce, and
+the result must equal ONE process training on the concatenated batch (DDP averaging + reduce_mean normalisers ==
+the bigger batch)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import fcos_model_cfg, rel_l2
+
+pytestmark = pytest.mark.gpu
+H, W = 128, 192
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def make_batch(rank):
+    """Two images per rank; rank r's images are images [2r, 2r+1] of the 4-image global batch."""
+    from oracle import fcos_oracle as O
+    g = torch.Generator().manual_seed(77)
+    img = (torch.randn(4, 3, H, W, generator=g) * 30).bfloat16().float()
+    rng = np.random.RandomState(9)
+    gtb = [torch.from_numpy(O.synth_boxes(rng, 3, H=H, W=W, lo=8, hi=100)) for _ in range(4)]
+    gtl = [torch.from_numpy(rng.randint(0, 80, len(b)).astype('int64')) for b in gtb]
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), scale_factor=1.0)] * 4
+    sl = slice(0, 4) if rank is None else slice(2 * rank, 2 * rank + 2)
+    return dict(img=img[sl].cuda(), img_metas=metas[sl], gt_bboxes=gtb[sl], gt_labels=gtl[sl])
+
+
+def build():
+    from dsl_amd import detectors  # noqa: F401
+    from dsl_amd.registry import build_detector
+    from oracle import fcos_oracle as O
+    model = build_detector(fcos_model_cfg())
+    model.load_state_dict(O.synth_state_dict(0))
+    return model.cuda()
+
+
+def _worker(rank, world, port, q, eager, out_path):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from dsl_amd.parallel import HipDistributedDataParallel
+        model = build()
+        model.eager_backward = eager                 # must be the same on every rank: it changes the collective order
+        ddp = HipDistributedDataParallel(model)
+        out = ddp.train_step(make_batch(rank), None)
+        out['loss'].backward()
+        model.wait_grads()
+        torch.cuda.synchronize()
+        g = model.store.grad.detach().cpu()
+        lst = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(lst, g)
+        same = all(torch.equal(t, lst[0]) for t in lst)
+        logs = {k: float(v) for k, v in out['log_vars'].items()}
+        dist.destroy_process_group()
+        if rank == 0:
+            torch.save(g, out_path)          # (a tensor in the queue would die with this process)
+        q.put((rank, 'ok', same, None, logs))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc(), False, None, None))
+
+
+@pytest.mark.parametrize('eager', [False, True])
+def test_ddp_step_equals_big_batch(eager, tmp_path):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    out_path = str(tmp_path / 'g_ddp.pt')
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, eager, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=150) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.kill()
+    assert all(r[1] == 'ok' for r in res), [r[1] for r in res]
+    assert all(r[2] for r in res), 'ranks hold different gradients after the all-reduce'
+    g_ddp = torch.load(out_path)
+    logs = [r[4] for r in res]
+    assert logs[0] == pytest.approx(logs[1], rel=1e-6)                 # log vars are averaged over the ranks
+    # single process, the concatenated 4-image batch
+    model = build()
+    out = model.train_step(make_batch(None), None)
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    g_big = model.store.grad.detach().cpu()
+    assert torch.isfinite(g_ddp).all() and float(g_big.abs().max()) > 0
+    # two bf16-storage computations of the same gradient (2+2 images vs 4) decorrelate to the bf16 noise floor of
+    # the deep layers; the predictors, one conv away from the fp32 loss, pin the semantics
+    assert rel_l2(g_ddp, g_big) < 0.10, rel_l2(g_ddp, g_big)
+    reg = model.store.train_regions
+    for name in ('head.cls_w', 'head.cls_b', 'head.regctr_w', 'head.regctr_b'):
+        o, n = reg[name][:2]
+        assert rel_l2(g_ddp[o:o + n], g_big[o:o + n]) < 2e-2, (name, rel_l2(g_ddp[o:o + n], g_big[o:o + n]))
+    for k, v in out['log_vars'].items():
+        assert logs[0][k] == pytest.approx(float(v), rel=2e-3), (k, logs[0][k], float(v))
