@@ -102,10 +102,11 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    torch.cuda.set_device(local)
+    # test hooks (tests / dry runs on a 1-GPU box): DSL_BENCH_ONE_GPU=1 puts every rank on cuda:0, DSL_DIST_BACKEND=gloo
+    torch.cuda.set_device(0 if os.environ.get('DSL_BENCH_ONE_GPU') else local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+        dist.init_process_group(os.environ.get('DSL_DIST_BACKEND', 'nccl'))
 
     from dsl_amd import _lib as L
     from dsl_amd import detectors  # noqa: F401
