@@ -490,15 +490,21 @@ class Plan:
 class Engine:
     """Caches plans per (store, N, H, W, training) and runs the student step / the teacher forward."""
 
+    MAX_PLANS = 12      # multi-scale training (img_scale ranges) visits a few dozen padded shapes; a plan holds every
+                        # activation of its shape (~1.5 GB per 800x1344 image), so keep the most recently used ones
+
     def __init__(self):
-        self.plans = {}
+        self.plans = {}         # insertion-ordered: least recently used first
 
     def plan(self, store, N, H, W, training=True):
         key = (id(store), N, H, W, training)
-        p = self.plans.get(key)
+        p = self.plans.pop(key, None)
         if p is None:
+            while len(self.plans) >= self.MAX_PLANS:
+                torch.cuda.synchronize()                    # the evicted plan's buffers may still be in use on a stream
+                self.plans.pop(next(iter(self.plans)))
             p = Plan(store, N, H, W, training)
-            self.plans[key] = p
+        self.plans[key] = p
         if store.dirty:
             store.refresh()
         return p

@@ -174,3 +174,22 @@ def test_full_size_losses_and_assignment_vs_oracle():
     assert plan.lossplan.assign_idx.numel() == 2 * 22400
     assert torch.equal(plan.lossplan.assign_idx.cpu().long(), raux['assign_idx'])
     assert torch.equal(plan.lossplan.labels.cpu(), raux['labels'])
+
+
+def test_plan_cache_is_bounded_and_reuses_shapes():
+    """Multi-scale training visits many padded shapes: plans are cached per shape, least recently used evicted."""
+    model = build()
+    eng = model._get_engine()
+    eng.MAX_PLANS = 3
+    shapes = [(64, 96), (96, 128), (64, 128), (128, 128), (64, 96)]
+    gtb = [torch.tensor([[4., 6., 40., 50.]])]
+    gtl = [torch.tensor([7])]
+    vals = {}
+    for h, w in shapes:
+        img = torch.full((1, 3, h, w), 0.5).cuda()
+        losses = model.forward_train(img, [dict(img_shape=(h, w, 3))], gtb, gtl)
+        v = float(sum(losses.values()))
+        assert np.isfinite(v)
+        assert vals.setdefault((h, w), v) == pytest.approx(v, rel=1e-4)      # the re-built (64, 96) plan gives the same loss
+        assert len(eng.plans) <= 3
+    assert (id(model.store), 1, 64, 96, True) in eng.plans and (id(model.store), 1, 96, 128, True) not in eng.plans
