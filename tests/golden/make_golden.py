@@ -216,7 +216,51 @@ def gen_bboxes(model):
     save('bboxes_synth.npz', **d)
 
 
+def gen_adathres():
+    """Adaptive per-class thresholds / class weights of the pseudo-label refresh (runner/hooks/unlabel_pred_hook.py
+    `adathres`, :295-367).  The hook module itself needs pycocotools / mmcv.parallel / the dataset pipelines at import;
+    the function is plain Python over per-image JSON files, so it is run here from its own source text (read from the
+    reference tree at generation time - nothing of it is stored) on synthetic pseudo-label files, twice: without and
+    with the history file of the first call.  The fixture holds the inputs and the two outputs."""
+    import ast
+    import json
+    import tempfile
+    path = os.path.join(R.REF, 'mmdet/runner/hooks/unlabel_pred_hook.py')
+    src = open(path).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'adathres'][0]
+    ns = dict(os=os, json=json)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, 'exec'), ns)
+    adathres = ns['adathres']
+    rng = np.random.RandomState(11)
+    names = [f'cls{i}' for i in range(12)]                 # category names <-> ids 1..12 (COCO ids are 1-based)
+    cat2id = {n: i + 1 for i, n in enumerate(names)}
+    id2cat = {str(i + 1): n for i, n in enumerate(names)}
+    tmp = tempfile.mkdtemp()
+    rounds = []
+    files = [f'unl/img{i}.jpg' for i in range(40)]
+    for rnd in range(2):
+        per_img = []
+        for f in files:
+            k = int(rng.poisson(3))
+            tags = [names[j] for j in rng.randint(0, 10 if rnd == 0 else 12, k)]     # round 2 meets two unseen classes
+            scores = [round(float(v), 6) for v in rng.uniform(0.1, 0.99, k)]
+            with open(os.path.join(tmp, os.path.basename(f) + '.json'), 'w') as fh:
+                json.dump(dict(imageName=f, targetNum=k, rects=[[0, 0, 5, 5]] * k, tags=tags, masks=[[]] * k, scores=scores), fh)
+            per_img.append((tags, scores))
+        hist = os.path.join(tmp, 'thres.json')
+        adathres(0, True, hist, id2cat, cat2id, files, tmp, {})
+        out = json.load(open(hist))
+        rounds.append(dict(per_img=per_img, thres=out['thres'], weights=out['cat'], id_weights=out['id']))
+        print('adathres round', rnd, {k: round(v, 4) for k, v in list(out['thres'].items())[:4]})
+    with open(os.path.join(HERE, 'adathres.json'), 'w') as fh:
+        json.dump(dict(names=names, rounds=rounds), fh)
+    print('wrote adathres.json')
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['adathres']:
+        gen_adathres()
+        sys.exit(0)
     model = R.build_fcos(SUP_CFG)
     model.train()
     which = sys.argv[1:] or ['assign', 'loss', 'bboxes', 'net']

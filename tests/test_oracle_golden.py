@@ -165,3 +165,34 @@ def test_ema_and_sgd_formulas():
         opt.step()
         params, bufs = O.sgd_step(params, {'x.weight': g}, bufs, first_step=(step == 0))
         assert torch.allclose(params['x.weight'], p.detach(), rtol=1e-6)
+
+
+def test_adaptive_thresholds_match_reference_adathres():
+    """Pseudo-label refresh statistics: per-class thresholds and class weights equal the
+    reference's `adathres` (unlabel_pred_hook.py:295-367) on the same pseudo-label files, for the first call and for
+    a call with the previous call's history (fixture: tests/golden/adathres.json, made by make_golden.py adathres)."""
+    import json
+    import os
+    from dsl_amd.runner import UnlabelPredHook, adaptive_thresholds
+    d = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'adathres.json')))
+    idx = {n: i for i, n in enumerate(d['names'])}
+    prev = None
+    hook = UnlabelPredHook()
+    for rnd in d['rounds']:
+        by_c = {}
+        hook.bank = {}
+        for k, (tags, scores) in enumerate(rnd['per_img']):
+            for t, s in zip(tags, scores):
+                by_c.setdefault(idx[t], []).append(s)
+            hook.bank[f'im{k}'] = dict(rects=np.zeros((len(tags), 4), np.int64), tags=np.array([idx[t] for t in tags], np.int64),
+                                       scores=np.array(scores, np.float64))
+        thr, w = adaptive_thresholds(by_c, prev)
+        assert {d['names'][c] for c in thr} == set(rnd['thres'])
+        for name, v in rnd['thres'].items():
+            assert thr[idx[name]] == pytest.approx(v, rel=1e-9), name
+        for name, v in rnd['weights'].items():
+            assert w[idx[name]] == pytest.approx(v, rel=1e-9), name
+        # the hook's own bookkeeping gives the same numbers
+        hook.update_thresholds()
+        assert hook.thres == pytest.approx(thr) and hook.class_weights == pytest.approx(w)
+        prev = thr
