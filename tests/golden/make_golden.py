@@ -257,9 +257,58 @@ def gen_adathres():
     print('wrote adathres.json')
 
 
+def gen_pseudo_split():
+    """The (gt, ignore) split of stored pseudo labels: SemiCOCODataset._parse_ann_info (datasets/semicoco.py:184-291),
+    run from its own source text on synthetic per-image JSON files with (a) no threshold file yet (default band
+    [0.1, 0.4)), (b) a per-class threshold file that misses some classes."""
+    import ast
+    import json
+    import tempfile
+    import types
+    path = os.path.join(R.REF, 'mmdet/datasets/semicoco.py')
+    tree = ast.parse(open(path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'SemiCOCODataset'][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == '_parse_ann_info'][0]
+    ns = dict(os=os, json=json, np=np)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, 'exec'), ns)
+    parse = ns['_parse_ann_info']
+    rng = np.random.RandomState(13)
+    names = [f'cls{i}' for i in range(8)]
+    cat2id = {n: i for i, n in enumerate(names)}
+    tmp = tempfile.mkdtemp()
+    W, H = 200, 120
+    imgs = []
+    for k in range(12):
+        n = int(rng.poisson(4))
+        x1, y1 = rng.randint(-10, W, n), rng.randint(-10, H, n)
+        rects = np.stack([x1, y1, x1 + rng.randint(0, 80, n), y1 + rng.randint(0, 60, n)], 1).tolist()
+        tags = [names[j] for j in rng.randint(0, 8, n)]
+        scores = [round(float(v), 6) for v in rng.uniform(0.05, 0.99, n)]
+        with open(os.path.join(tmp, f'im{k}.jpg.json'), 'w') as fh:
+            json.dump(dict(imageName=f'im{k}.jpg', targetNum=n, rects=rects, tags=tags, masks=[[]] * n, scores=scores), fh)
+        imgs.append(dict(rects=rects, tags=tags, scores=scores))
+    thres_file = os.path.join(tmp, 'thres.json')
+    thres = {names[i]: float(v) for i, v in zip((0, 1, 2, 4, 5), (0.3, 0.32, 0.35, 0.31, 0.33))}     # classes 3, 6, 7 unseen
+    modes = []
+    for mode in ('no_file', 'file'):
+        if mode == 'file':
+            json.dump(dict(thres=thres), open(thres_file, 'w'))
+        self = types.SimpleNamespace(ann_path=tmp, thres=thres_file, default_thres=[0.1, 0.4], labelmapper=dict(cat2id=cat2id))
+        outs = []
+        for k in range(12):
+            a = parse(self, dict(filename=f'im{k}.jpg', width=W, height=H), None)
+            outs.append(dict(bboxes=a['bboxes'].tolist(), labels=a['labels'].tolist(), ignore=a['bboxes_ignore'].tolist()))
+        modes.append(dict(mode=mode, thres=thres if mode == 'file' else None, outs=outs))
+    json.dump(dict(names=names, wh=[W, H], imgs=imgs, modes=modes), open(os.path.join(HERE, 'pseudo_split.json'), 'w'))
+    print('wrote pseudo_split.json', sum(len(o['bboxes']) for o in modes[0]['outs']), sum(len(o['ignore']) for o in modes[0]['outs']))
+
+
 if __name__ == '__main__':
     if sys.argv[1:] == ['adathres']:
         gen_adathres()
+        sys.exit(0)
+    if sys.argv[1:] == ['pseudo_split']:
+        gen_pseudo_split()
         sys.exit(0)
     model = R.build_fcos(SUP_CFG)
     model.train()

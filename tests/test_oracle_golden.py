@@ -196,3 +196,19 @@ def test_adaptive_thresholds_match_reference_adathres():
         hook.update_thresholds()
         assert hook.thres == pytest.approx(thr) and hook.class_weights == pytest.approx(w)
         prev = thr
+
+
+def test_pseudo_label_split_matches_reference_parse_ann_info():
+    """(gt, ignore) split of stored pseudo labels == SemiCOCODataset._parse_ann_info (semicoco.py:184-291) on the same
+    files: default band before any threshold file exists, per-class thresholds (with unseen classes) afterwards."""
+    import json
+    import os
+    from dsl_amd.runner import split_pseudo_labels
+    d = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'pseudo_split.json')))
+    idx = {n: i for i, n in enumerate(d['names'])}
+    for mode in d['modes']:
+        thr = {idx[k]: v for k, v in mode['thres'].items()} if mode['thres'] else {}
+        for img, ref in zip(d['imgs'], mode['outs']):
+            gt, gl, ig = split_pseudo_labels(np.array(img['rects'], np.float64).reshape(-1, 4), [idx[t] for t in img['tags']],
+                                             img['scores'], thr, img_wh=tuple(d['wh']))
+            assert gt.tolist() == ref['bboxes'] and gl.tolist() == ref['labels'] and ig.tolist() == ref['ignore'], mode['mode']
