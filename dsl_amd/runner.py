@@ -292,6 +292,18 @@ def split_pseudo_labels(boxes, labels, scores, thres_by_class, default_thres=(0.
     return f(gt), torch.tensor(gl, dtype=torch.int64), f(ig)
 
 
+def parse_det_results(dets, labels, score_thr):
+    """unlabel_pred_hook.py:20-38 + the score sort of gen_save_json_dict (:40-57): keep detections with
+    score >= score_thr, integer-truncate the coordinates (int()), round the score to 6 decimals, highest score first.
+    dets [k, 5] (x1, y1, x2, y2, score), labels [k]."""
+    dets, labels = np.asarray(dets), np.asarray(labels)
+    keep = dets[:, 4] >= score_thr
+    b, l = dets[keep], labels[keep]
+    scores = np.array([round(float(v), 6) for v in b[:, 4]], dtype=np.float64)
+    order = np.argsort(-scores, kind='stable')
+    return dict(rects=np.trunc(b[order, :4]).astype(np.int64), tags=l[order].astype(np.int64), scores=scores[order])
+
+
 @HOOKS.register_module()
 class UnlabelPredHook(Hook):
     """On-GPU pseudo-label refresh.  Each call runs the (EMA) teacher on the given unlabeled images with the
@@ -315,11 +327,7 @@ class UnlabelPredHook(Hook):
         dets, labels, count = dets.cpu().numpy(), labels.cpu().numpy(), count.cpu().numpy()
         for i, name in enumerate(names):
             k = int(count[i])
-            b, l = dets[i, :k], labels[i, :k]
-            keep = b[:, 4] >= self.score_thr
-            b, l = b[keep], l[keep]
-            rects = np.trunc(b[:, :4]).astype(np.int64)           # int() truncation of the reference
-            self.bank[name] = dict(rects=rects, tags=l.astype(np.int64), scores=np.round(b[:, 4].astype(np.float64), 6))
+            self.bank[name] = parse_det_results(dets[i, :k], labels[i, :k], self.score_thr)
             if self.export_dir:
                 self._export(name)
         return self.bank

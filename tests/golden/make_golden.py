@@ -303,7 +303,35 @@ def gen_pseudo_split():
     print('wrote pseudo_split.json', sum(len(o['bboxes']) for o in modes[0]['outs']), sum(len(o['ignore']) for o in modes[0]['outs']))
 
 
+def gen_parse_dets():
+    """parse_det_results + the score sort of gen_save_json_dict (runner/hooks/unlabel_pred_hook.py:20-57), run from their
+    own source text on random per-class detection arrays (bbox2result layout)."""
+    import ast
+    import json
+    path = os.path.join(R.REF, 'mmdet/runner/hooks/unlabel_pred_hook.py')
+    tree = ast.parse(open(path).read())
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('parse_det_results', 'gen_save_json_dict')]
+    ns = {}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, 'exec'), ns)
+    rng = np.random.RandomState(17)
+    cases = []
+    for _ in range(4):
+        results = []
+        for c in range(6):
+            k = int(rng.poisson(2))
+            b = np.concatenate([rng.uniform(-3, 300, (k, 4)), rng.uniform(0.02, 0.99, (k, 1))], 1).astype(np.float32)
+            results.append(b)
+        out = ns['gen_save_json_dict'](dict(task_type='Det', infer_score_thre=0.1, result=results), None)['infer_results']
+        cases.append(dict(results=[r.tolist() for r in results],
+                          out=[dict(c=o['category_index'], score=o['score'], bbox=o['bbox']) for o in out]))
+    json.dump(dict(score_thr=0.1, cases=cases), open(os.path.join(HERE, 'parse_dets.json'), 'w'))
+    print('wrote parse_dets.json', [len(c['out']) for c in cases])
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['parse_dets']:
+        gen_parse_dets()
+        sys.exit(0)
     if sys.argv[1:] == ['adathres']:
         gen_adathres()
         sys.exit(0)

@@ -212,3 +212,19 @@ def test_pseudo_label_split_matches_reference_parse_ann_info():
             gt, gl, ig = split_pseudo_labels(np.array(img['rects'], np.float64).reshape(-1, 4), [idx[t] for t in img['tags']],
                                              img['scores'], thr, img_wh=tuple(d['wh']))
             assert gt.tolist() == ref['bboxes'] and gl.tolist() == ref['labels'] and ig.tolist() == ref['ignore'], mode['mode']
+
+
+def test_parse_det_results_matches_reference():
+    """Stored pseudo labels == parse_det_results + score sort (unlabel_pred_hook.py:20-57): threshold, int()
+    truncation, 6-decimal scores, highest score first."""
+    import json
+    import os
+    from dsl_amd.runner import parse_det_results
+    d = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'parse_dets.json')))
+    for case in d['cases']:
+        dets = np.concatenate([np.array(r, np.float32).reshape(-1, 5) for r in case['results']])
+        labels = np.concatenate([np.full(len(r), c) for c, r in enumerate(case['results'])])
+        got = parse_det_results(dets, labels, d['score_thr'])
+        assert got['scores'].tolist() == [o['score'] for o in case['out']]
+        assert got['tags'].tolist() == [o['c'] for o in case['out']]
+        assert got['rects'].tolist() == [o['bbox'] for o in case['out']]
