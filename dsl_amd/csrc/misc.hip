@@ -70,6 +70,7 @@ struct GnK {
 };
 
 constexpr int GN_PPB = 128;   // pixels per block
+constexpr int GN_TA = 1024;   // the two pure streaming (apply) passes
 constexpr int GN_T = 512;     // threads per block: 8 waves keep two waves per SIMD in flight on the ~1.4 blocks a CU gets
 
 // pass 1 of forward: sum / sumsq per (seg, img, group) -> red (pre-zeroed)
@@ -113,12 +114,12 @@ __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
 }
 
 // pass 2 of forward: y = relu((x-mean)*rstd*gamma+beta); also writes (mean, rstd) to stats
-__global__ __launch_bounds__(GN_T) void gn_apply_kernel(const GnK p) {
+__global__ __launch_bounds__(GN_TA) void gn_apply_kernel(const GnK p) {
   const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
   const int hw = p.h[seg] * p.w[seg];
   const int px0 = blockIdx.x * GN_PPB;
   if (px0 >= hw) return;
-  const int cpr = p.c / 8, ppi = GN_T / cpr;
+  const int cpr = p.c / 8, ppi = GN_TA / cpr;
   const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
   const int grp = chunk / p.cpg8;
   const float cnt = (float)hw * (float)(p.c / p.groups);
@@ -229,12 +230,12 @@ __global__ __launch_bounds__(GN_T) void gn_bwd_reduce_kernel(const GnK p) {
 }
 
 // backward pass 2: dx = rstd * (dz*gamma - (s1 + xhat*s2)/cnt)
-__global__ __launch_bounds__(GN_T) void gn_bwd_apply_kernel(const GnK p) {
+__global__ __launch_bounds__(GN_TA) void gn_bwd_apply_kernel(const GnK p) {
   const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
   const int hw = p.h[seg] * p.w[seg];
   const int px0 = blockIdx.x * GN_PPB;
   if (px0 >= hw) return;
-  const int cpr = p.c / 8, ppi = GN_T / cpr;
+  const int cpr = p.c / 8, ppi = GN_TA / cpr;
   const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
   const int grp = chunk / p.cpg8;
   const float* st = p.stats + ((long long)si * p.groups + grp) * 2;
@@ -391,7 +392,7 @@ extern "C" int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!d->prezeroed) hipMemsetAsync(d->red, 0, sizeof(float) * 2 * d->nseg * d->n * d->groups, st);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_T), 0, st, k);
-  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_T), 0, st, k);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_TA), 0, st, k);
   DSL_LAUNCH_CHECK("gn forward");
   return 0;
 }
@@ -413,7 +414,7 @@ extern "C" int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream) {
     hipMemsetAsync(d->dbeta, 0, sizeof(float) * d->c, st);
   }
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(GN_T), 0, st, k);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(GN_T), 0, st, k);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(GN_TA), 0, st, k);
   DSL_LAUNCH_CHECK("gn backward");
   return 0;
 }
