@@ -167,7 +167,7 @@ extern "C" int dsl_probe_tr16(const uint16_t* img, const int32_t* lane_off, uint
 }
 
 // ---- probe: XCC id of each workgroup + XCD-local (workgroup-scope, L2-resident) float atomics --------------
-// The XCD-aware workgroup mappings of the conv / wgrad kernels assume block b runs on XCD b % 8; this probe pins
+// The XCD-aware workgroup mappings of the conv / wgrad kernels assume blocks with equal b % 8 share an XCD (round-robin dispatch); this probe pins
 // that (HW_REG_XCC_ID) and that workgroup-scope global_atomic_add_f32 into per-XCD buffers is complete after the
 // kernel.
 __global__ void probe_xcc_kernel(int* xcc_of_block, float* acc /* [8][256] */) {

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_co = wave / WPX, wave_px = wave % WPX;
-  // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD owns a contiguous run of tiles in (cout tile
+  // XCD-aware tile order (workgroups are dealt round-robin to the XCDs: equal b % 8 = same XCD): every XCD owns a contiguous run of tiles in (cout tile
   // fastest, then pixel tile, then K split) order, so neighbouring pixel tiles - which share their halo rows - and
   // the cout tiles of one pixel range hit the same L2 instead of being fetched into up to three of them.
 #ifdef DSL_ABLATE_BUILD
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_co = wave / WCI, wave_ci = wave % WCI;
-  // XCD-aware work mapping (block b runs on XCD b % 8): the (cout tile, tap, cin tile) workgroups of one pixel
+  // XCD-aware work mapping (blocks are dealt round-robin to the XCDs: equal b % 8 = same XCD): the (cout tile, tap, cin tile) workgroups of one pixel
   // split are neighbours on one XCD, so its dY / X pixel range is fetched into that XCD's L2 once instead of
   // once per tap.  Placement only affects speed.
   const int tiles_per_member = p.gx * p.gy;
