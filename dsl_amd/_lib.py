@@ -51,7 +51,7 @@ class GnDesc(C.Structure):
                 ('h', I5), ('w', I5), ('eps', C.c_float),
                 ('x', C.c_void_p), ('y', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
                 ('stats', C.c_void_p), ('dy', C.c_void_p), ('dx', C.c_void_p), ('dgamma', C.c_void_p),
-                ('dbeta', C.c_void_p), ('red', C.c_void_p), ('prezeroed', C.c_int32)]
+                ('dbeta', C.c_void_p), ('dbias', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
 class FcosDesc(C.Structure):
@@ -99,6 +99,8 @@ lib.dsl_wgrad_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_wgrad_group_workspace_bytes'):
     lib.dsl_wgrad_group_workspace_bytes.restype = C.c_size_t
 lib.dsl_conv2d_workspace_bytes.restype = C.c_size_t
+if hasattr(lib, 'dsl_groupnorm_workspace_bytes'):
+    lib.dsl_groupnorm_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_detect_workspace_bytes'):
     lib.dsl_detect_workspace_bytes.restype = C.c_size_t
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -106,7 +108,7 @@ _SIGS = {
     'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_workspace_bytes': [_vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
     'dsl_wgrad_workspace_bytes': [_vp], 'dsl_wgrad_group_workspace_bytes': [_vp, _i], 'dsl_conv2d_wgrad_group': [_vp, _i, _vp],
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
-    'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp],
+    'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp], 'dsl_groupnorm_workspace_bytes': [_vp],
     'dsl_sum2x2': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], 'dsl_colsum': [_vp, _vp, _l, _i, _i, _vp],
     'dsl_fcos_points': [_vp, _vp, _vp], 'dsl_fcos_assign': [_vp, _vp], 'dsl_fcos_loss': [_vp, _vp],
     'dsl_sumsq': [_vp, _l, _vp, _vp],
@@ -114,7 +116,7 @@ _SIGS = {
     'dsl_ema_lerp': [_vp, _vp, _l, _f, _vp], 'dsl_cast_bf16': [_vp, _vp, _l, _vp],
     'dsl_pack_dgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_pack_dgrad_batched': [_vp, _i, _i, _vp],
     'dsl_detect_workspace_bytes': [_vp], 'dsl_fcos_detect': [_vp, _vp],
-    'dsl_run_ops': [_vp, _i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp],
+    'dsl_run_ops': [_vp, _i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
 }
 MISSING = []
 for _name, _args in _SIGS.items():

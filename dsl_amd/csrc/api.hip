@@ -1,5 +1,6 @@
 // libdsl_hip.so: error reporting, op-list executor, hardware probes.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -24,9 +25,28 @@ int g_evpos[16] = {};
 bool g_init[16] = {};
 hipEvent_t g_named[16][16] = {};        // DSL_OP_RECORD / DSL_OP_WAIT slots
 bool g_named_set[16][16] = {};
+// Side stream 1 carries the weight gradients.  DSL_SIDE_CUS=k (k < 32) confines it to k of the 32 CUs of every XCD
+// (hipExtStreamCreateWithCUMask; bit i of the mask = CU i/8 of XCD i%8, pinned by tests/test_kernels_gpu.py::
+// test_probe_cu_mask): its long-running 128 KB-LDS workgroups then cannot occupy the CUs the caller's latency-critical
+// kernel chain needs.  Streams 2, 3 (forward tower overlap) stay unrestricted.
+int side_cus() {
+  static const int k = [] { const char* e = getenv("DSL_SIDE_CUS"); return e ? atoi(e) : 0; }();
+  return k;
+}
 void side_init(int dev) {
   if (g_init[dev]) return;
-  for (int i = 0; i < kSide; ++i) hipStreamCreateWithFlags(&g_side[dev][i], hipStreamNonBlocking);
+  for (int i = 0; i < kSide; ++i) {
+    const int k = side_cus();
+    if (i == 0 && k > 0 && k < 32) {
+      uint32_t mask[8];
+      for (int w = 0; w < 8; ++w) mask[w] = 0;
+      for (int b = 0; b < 256; ++b)
+        if (b / 8 < k) mask[b >> 5] |= 1u << (b & 31);
+      if (hipExtStreamCreateWithCUMask(&g_side[dev][i], 8, mask) == hipSuccess) continue;
+      (void)hipGetLastError();
+    }
+    hipStreamCreateWithFlags(&g_side[dev][i], hipStreamNonBlocking);
+  }
   for (int i = 0; i < kEvRing; ++i) hipEventCreateWithFlags(&g_ev[dev][i], hipEventDisableTiming);
   for (int i = 0; i < 16; ++i) hipEventCreateWithFlags(&g_named[dev][i], hipEventDisableTiming);
   g_init[dev] = true;
@@ -175,6 +195,41 @@ __global__ void probe_xcc_kernel(int* xcc_of_block, float* acc /* [8][256] */) {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
   if (threadIdx.x == 0) xcc_of_block[blockIdx.x] = (int)x;
   __hip_atomic_fetch_add(acc + (x & 7) * 256 + threadIdx.x, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---- probe: which CUs a CU-masked stream runs on -------------------------------------------------------------------
+// every workgroup claims a whole CU's LDS for ~20 us and records (XCC id, HW_ID: SE/SH/CU fields)
+__global__ void probe_cu_kernel(int* out) {
+  extern __shared__ int lds[];
+  unsigned x, h;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 32)" : "=s"(h));
+  lds[threadIdx.x] = (int)h;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(20);      // 100 MHz constant clock: 20 us
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = (int)x;
+    out[2 * blockIdx.x + 1] = lds[0];
+  }
+}
+
+extern "C" int dsl_probe_cu_mask(const uint32_t* mask, int nwords, int32_t* out, int nblocks) {
+  hipStream_t st;
+  if (mask && nwords > 0) {
+    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask) != hipSuccess) {
+      dsl_set_error("dsl_probe_cu_mask: hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(hipGetLastError()));
+      return -2;
+    }
+  } else {
+    hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  }
+  const int lds = 160 * 1024;
+  hipFuncSetAttribute((const void*)probe_cu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(probe_cu_kernel, dim3(nblocks), dim3(64), lds, st, out);
+  hipError_t e = hipStreamSynchronize(st);
+  hipStreamDestroy(st);
+  DSL_CHECK(e == hipSuccess, "dsl_probe_cu_mask: %s", hipGetErrorString(e));
+  return 0;
 }
 
 extern "C" int dsl_probe_xcc(int32_t* xcc_of_block, float* acc, int nblocks, void* stream) {

@@ -953,6 +953,7 @@ struct WgK {
   int gx, gy, splits;       // v2: workgroup grid (cout tiles, column tiles) and split count for the XCD-aware 1-D launch
   int chunk;                // v2: consecutive work items (split-major) per XCD
   int group;                // v2: convolutions sharing this geometry in one launch (dsl_conv2d_wgrad_group)
+  int cyp;                  // v2: cy rounded up to the cout tile (partial-tile rows in the workspace); dY columns >= cy read as zero
   const uint16_t* dyv[DSL_MAX_GROUP];
   const uint16_t* xv[DSL_MAX_GROUP];
   long long krow;
@@ -1381,7 +1382,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
 #pragma unroll
       for (int i = 0; i < LY; ++i) {
         const int gp = kl * KS + yrow[i];
-        const gptr_t g = gp < totpx ? (gptr_t)(dy_p + (long long)gp * p.cy + co0 + ych[i]) : zero;
+        const gptr_t g = (gp < totpx && co0 + ych[i] < p.cy) ? (gptr_t)(dy_p + (long long)gp * p.cy + co0 + ych[i]) : zero;
         __builtin_amdgcn_global_load_lds(g, (lptr_t)(stage + (wave + NW * i) * 1024), 16, 0, 0);
       }
 #pragma unroll
@@ -1414,7 +1415,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int co = co0 + wave_co * (32 * CT) + ct * 32 + (j & 3) + 8 * (j >> 2) + 4 * fhalf;
-        p.ws[(((long long)sp * p.group + member) * p.cy + co) * p.krow + col] = acc[ct][it][j];
+        p.ws[(((long long)sp * p.group + member) * p.cyp + co) * p.krow + col] = acc[ct][it][j];
       }
     }
 }
@@ -1474,9 +1475,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, const RedK r, 
 namespace {
 // DMA-to-LDS tile configurations {BCO, BPX, workgroups per CU, ring depth}
 struct TileCfg { int bco, bpx, occ, nst, wpx; };     // wpx: pixel-waves of the pipelined kernel (epilogue staging = 32*wpx pixels)
-constexpr int kNumCfg = 6;
+constexpr int kNumCfg = 8;
 const TileCfg kCfgs[kNumCfg] = {{256, 192, 1, 2, 2}, {256, 128, 1, 3, 2}, {128, 256, 1, 3, 4}, {128, 128, 2, 2, 4}, {64, 256, 2, 2, 8},
-                                {128, 64, 2, 3, 2}};
+                                {128, 64, 2, 3, 2},
+                                // small tiles for the layers with few pixels (layer3/4: 8 400 / 2 100 pixels at N = 2): enough
+                                // workgroups to use every CU without split-K partials, several resident per CU
+                                {64, 64, 3, 3, 2}, {64, 128, 2, 3, 4}};
 
 // strided data-gradients gather with per-tap divisibility tests: only the v2 kernel's general address path does that
 inline bool conv_v2_only(const dsl_conv_desc* d) { return d->mode == 1 && d->stride > 1; }
@@ -1490,7 +1494,7 @@ inline bool conv_v2_only(const dsl_conv_desc* d) { return d->mode == 1 && d->str
 double conv_cost_us(int ci, long long px, int cd_pad, int ktiles, int sp, bool out_f32) {
   const TileCfg& c = kCfgs[ci];
   // per-config efficiency of the K loop (the 8-wave 128x128 tile keeps 2 waves per SIMD even alone on a CU)
-  static const double kEff[kNumCfg] = {1.0, 1.0, 1.0, 0.7, 0.95, 0.9};
+  static const double kEff[kNumCfg] = {1.0, 1.0, 1.0, 0.7, 0.95, 0.9, 1.3, 1.25};     // 6, 7: measured best on one shape of tools/bench_conv.py only
   const long long wgs = (long long)(cd_pad / c.bco) * ((px + c.bpx - 1) / c.bpx) * sp;
   const long long slots = 256LL * c.occ;
   const long long rounds = (wgs + slots - 1) / slots;
@@ -1525,7 +1529,7 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
     for (int c = 0; c < kNumCfg; ++c) {
       if (d->cd_pad % kCfgs[c].bco) continue;
       if (force >= 1 && force <= kNumCfg && force - 1 != c) continue;
-      if (c == 5 && conv_v2_only(d)) continue;       // the 128x64 tile exists for the pipelined kernel only
+      if (c >= 5 && conv_v2_only(d)) continue;       // the small tiles exist for the pipelined kernel only
       if (smallc && c != 4) continue;                // the 8-channel-source variant is instantiated for the 64x256 tile
       for (int sp = 1; sp <= 16; ++sp) {
         if (sp > 1 && smallc) break;
@@ -1538,7 +1542,7 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
     if (pick < 0 && force_split > 1) {               // forced split not feasible: ignore it
       for (int c = 0; c < kNumCfg; ++c) {
         if (d->cd_pad % kCfgs[c].bco || (force >= 1 && force <= kNumCfg && force - 1 != c)) continue;
-        if (c == 5 && conv_v2_only(d)) continue;
+        if (c >= 5 && conv_v2_only(d)) continue;
         const double t = conv_cost_us(c, px, d->cd_pad, ktiles, 1, out_f32);
         if (t < best) { best = t; pick = c; splits = 1; }
       }
@@ -1692,7 +1696,9 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
             LAUNCH3(64, 256, 1, 8, 2);
           }
           break;
-        default: LAUNCH3(128, 64, 2, 2, 3); break;
+        case 5: LAUNCH3(128, 64, 2, 2, 3); break;
+        case 6: LAUNCH3(64, 64, 1, 2, 3); break;
+        default: LAUNCH3(64, 128, 1, 4, 3); break;
       }
     }
 #undef LAUNCH2
@@ -1741,7 +1747,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
 static int wgrad_pick(const dsl_wgrad_desc* d) {
   const int force = d->splits < 0 ? -d->splits : 0;       // test hook: splits = -(cfg+1) forces a config
   if (force) return force - 1;
-  if (d->cy % 128) return 0;
+  if (d->cy % 128) return d->cs % 256 == 0 ? 3 : 4;      // cy = 64 (mod 128): the 128-cout tiles, upper half reads zeros
   if (d->cy % 256 == 0 && d->cs % 256 == 0) return 1;
   if (d->cy % 256 == 0) return 2;
   if (d->cs % 256 == 0) return 3;
@@ -1755,7 +1761,7 @@ static int wgrad_geometry(const dsl_wgrad_desc* d, int* ktiles, int* tiles, int*
   const int bcos[5] = {(d->cy % 128 == 0) ? 128 : 64, 256, 256, 128, 128};
   const int bcis[5] = {128, 256, 128, 256, 128};
   *bco = bcos[cfg];
-  *tiles = (d->cy / *bco) * (d->kh * d->kw * d->cs / bcis[cfg]);
+  *tiles = ((d->cy + *bco - 1) / *bco) * (d->kh * d->kw * d->cs / bcis[cfg]);
   return cfg;
 }
 
@@ -1772,7 +1778,12 @@ static int wgrad_splits_for(const dsl_wgrad_desc* d, int count) {
     // one full round, never a nearly-empty second one.  (Accumulating the split partials with XCD-local L2 float
     // atomics instead of writing them out was measured: 117 vs 85 us on the head shape - L2 atomics retire about
     // two lanes per clock per channel.)
-    splits = 256 * per_cu / tiles;
+    // DSL_WGRAD_SLOTS < 256 leaves CUs free: the weight gradients run on the side stream under the caller's chain of
+    // small convolutions, and a full round of 128 KB-LDS workgroups that live for 100-250 us would leave those
+    // kernels only the handful of CUs the round did not cover
+    // (measured, bench.py N = 2: 256 -> 305, 224 -> 306, 192 -> 309, 160 -> 313, 128 -> 310 img/s)
+    static const int slots = [] { const char* e = getenv("DSL_WGRAD_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 160; }();
+    splits = slots * per_cu / tiles;
   }
   static const int forced_splits = [] { const char* e = getenv("DSL_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();   // tuning knob
   if (forced_splits > 0 && cfg != 0) splits = forced_splits;
@@ -1784,15 +1795,21 @@ static int wgrad_splits_for(const dsl_wgrad_desc* d, int count) {
 
 extern "C" int dsl_wgrad_splits(const dsl_wgrad_desc* d) { return wgrad_splits_for(d, 1); }
 
+static size_t wgrad_cy_pad(const dsl_wgrad_desc* d) {       // rows of one partial tile set in the workspace
+  int ktiles, tiles, bco;
+  wgrad_geometry(d, &ktiles, &tiles, &bco);
+  return (size_t)(d->cy + bco - 1) / bco * bco;
+}
+
 extern "C" size_t dsl_wgrad_workspace_bytes(const dsl_wgrad_desc* d) {
   const int splits = d->splits > 0 ? d->splits : dsl_wgrad_splits(d);
-  return (size_t)splits * d->cy * (size_t)d->kh * d->kw * d->cs * sizeof(float);
+  return (size_t)splits * wgrad_cy_pad(d) * (size_t)d->kh * d->kw * d->cs * sizeof(float);
 }
 
 extern "C" size_t dsl_wgrad_group_workspace_bytes(const dsl_wgrad_desc* descs, int count) {
   if (!descs || count < 1) return 0;
   if (count == 1) return dsl_wgrad_workspace_bytes(descs);
-  return (size_t)wgrad_splits_for(descs, count) * count * descs->cy * (size_t)descs->kh * descs->kw * descs->cs * sizeof(float);
+  return (size_t)wgrad_splits_for(descs, count) * count * wgrad_cy_pad(descs) * (size_t)descs->kh * descs->kw * descs->cs * sizeof(float);
 }
 
 extern "C" int dsl_colsum(const void* x, float* out, long rows, int c, int ld, void* stream);
@@ -1833,7 +1850,8 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     return 0;
   }
   const int splits = count == 1 ? (d->splits > 0 ? d->splits : dsl_wgrad_splits(d)) : wgrad_splits_for(d, count);
-  const size_t need = (size_t)splits * count * d->cy * (size_t)d->kh * d->kw * d->cs * sizeof(float);
+  const int cyp = (int)wgrad_cy_pad(d);
+  const size_t need = (size_t)splits * count * cyp * (size_t)d->kh * d->kw * d->cs * sizeof(float);
   DSL_CHECK(d->workspace_bytes >= need, "dsl_conv2d_wgrad: workspace too small (%zu < %zu)", d->workspace_bytes, need);
   WgK k;
   memset(&k, 0, sizeof(k));
@@ -1859,6 +1877,7 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
   k.krow = (long long)d->kh * d->kw * d->cs;
   k.dy = (const uint16_t*)d->dy; k.x = (const uint16_t*)d->x; k.ws = (float*)d->workspace;
   k.group = count;
+  k.cyp = cyp;
   for (int g = 0; g < DSL_MAX_GROUP; ++g) {
     k.dyv[g] = (const uint16_t*)descs[g < count ? g : 0].dy;
     k.xv[g] = (const uint16_t*)descs[g < count ? g : 0].x;
@@ -1868,8 +1887,8 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
   if (cfg >= 1) {
     const int bcis[5] = {128, 256, 128, 256, 128};
     const int bci = bcis[cfg];
-    DSL_CHECK(d->cy % bco == 0 && d->cs % bci == 0, "dsl_conv2d_wgrad: tile config %d does not divide cy=%d / cs=%d", cfg, d->cy, d->cs);
-    k.gx = d->cy / bco;
+    DSL_CHECK(cyp % bco == 0 && d->cs % bci == 0, "dsl_conv2d_wgrad: tile config %d does not divide cy=%d / cs=%d", cfg, d->cy, d->cs);
+    k.gx = cyp / bco;
     k.gy = d->kh * d->kw * d->cs / bci;
     k.splits = splits;
 #ifdef DSL_ABLATE_BUILD
@@ -1925,7 +1944,7 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     r.db[g] = g < count ? descs[g].db : nullptr;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb, count), dim3(256), 0, st, (const float*)d->workspace, r, splits, count,
-                     d->cy, d->cd, k.krow);
+                     cyp, d->cd, k.krow);
   DSL_LAUNCH_CHECK("wgrad_reduce_kernel");
   for (int g = 0; g < count; ++g)
     if (descs[g].db) {       // db was cleared by the reduce kernel above

@@ -52,10 +52,17 @@ __global__ void maxpool_kernel(const uint16_t* __restrict__ x, uint16_t* __restr
 }
 
 // ---- GroupNorm(32) + ReLU ------------------------------------------------------------------------
+// Two passes each way over a level-major tensor, statistics per (level segment, image, group) in fp32.
+// Every reduction is two-level and in a FIXED order (no atomics): pass 1 writes one partial record per
+// 128-pixel block into the workspace, pass 2's prologue (and, for the per-channel sums of the backward, an
+// extra row of workgroups) adds the records up in block order - results are bit-identical run to run, and
+// nothing has to be zeroed beforehand.  (The round-1 kernels added block partials with float atomics: up to
+// 350 workgroups x 512 same-address L2 atomics made the reduction passes 2x slower than the streaming passes.)
 struct GnK {
   int nseg, n, c, groups, cpg8;   // cpg8 = 16-byte chunks per group (channels per group / 8)
   int h[DSL_MAX_SEG], w[DSL_MAX_SEG];
   long long off[DSL_MAX_SEG];    // pixel offset of segment start
+  int nblk;                      // workgroups per (segment, image) row of the grid = ceil(max hw / GN_PPB)
   float eps;
   const uint16_t* x;
   uint16_t* y;
@@ -66,14 +73,36 @@ struct GnK {
   uint16_t* dx;
   float* dgamma;
   float* dbeta;
-  float* red;
+  float* dbias;                  // optional: gradient of the bias of the convolution that produced x = sum_p dx
+  float* ws;                     // partial records [nseg*n][nblk][rec]; rec = 2*groups (fwd) or 3*c + 2*groups (bwd)
 };
 
 constexpr int GN_PPB = 128;   // pixels per block
 constexpr int GN_TA = 1024;   // the two pure streaming (apply) passes
 constexpr int GN_T = 512;     // threads per block: 8 waves keep two waves per SIMD in flight on the ~1.4 blocks a CU gets
 
-// pass 1 of forward: sum / sumsq per (seg, img, group) -> red (pre-zeroed)
+// Sum of V-float records over the nb blocks of one (segment, image), by all T threads of the workgroup, in a fixed
+// order: thread (q, v) adds blocks q, q+Q, ... (Q = T / V), then thread v adds the Q partial sums in order.
+// out[] is LDS (V floats); sh[] is LDS scratch (T floats).  Needs V <= T and T % V == 0.
+template <int T>
+__device__ __forceinline__ void gn_sum_records(const float* __restrict__ rec0, int nb, int stride, int V, float* sh,
+                                               float* out) {
+  const int Q = T / V;
+  const int v = threadIdx.x % V, q = threadIdx.x / V;
+  float a = 0.f;
+  if (q < Q)
+    for (int b = q; b < nb; b += Q) a += rec0[(long long)b * stride + v];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < V) {
+    float s = 0.f;
+    for (int k = 0; k < Q; ++k) s += sh[k * V + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// pass 1 of forward: sum / sumsq per (seg, img, group) of this block's pixels -> ws record
 __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
   __shared__ float sh[2][GN_T];
   const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
@@ -86,14 +115,28 @@ __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
   const uint16_t* base = p.x + (p.off[seg] + (long long)img * hw) * p.c;
   float s = 0.f, ss = 0.f;
   const int px1 = min(px0 + GN_PPB, hw);
-#pragma unroll 4
-  for (int px = px0 + prow; px < px1; px += ppi) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long long)px * p.c + chunk * 8);
+  if (px1 - px0 == GN_PPB && ppi * 8 == GN_PPB) {      // full block, C = 256: all 8 loads of the thread in flight at once
+    u32x4 v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float a = bflo(v[e]), b = bfhi(v[e]);
-      s += a + b;
-      ss += a * a + b * b;
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const u32x4*>(base + (long long)(px0 + prow + i * ppi) * p.c + chunk * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = bflo(v[i][e]), b = bfhi(v[i][e]);
+        s += a + b;
+        ss += a * a + b * b;
+      }
+  } else {
+#pragma unroll 4
+    for (int px = px0 + prow; px < px1; px += ppi) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long long)px * p.c + chunk * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = bflo(v[e]), b = bfhi(v[e]);
+        s += a + b;
+        ss += a * a + b * b;
+      }
     }
   }
   sh[0][threadIdx.x] = s;
@@ -107,25 +150,28 @@ __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
         a += sh[0][r * cpr + threadIdx.x * p.cpg8 + k];
         b += sh[1][r * cpr + threadIdx.x * p.cpg8 + k];
       }
-    float* dst = p.red + ((long long)si * p.groups + threadIdx.x) * 2;
-    atomicAdd(dst, a);
-    atomicAdd(dst + 1, b);
+    float* dst = p.ws + ((long long)si * p.nblk + blockIdx.x) * (2 * p.groups) + 2 * threadIdx.x;
+    dst[0] = a;
+    dst[1] = b;
   }
 }
 
 // pass 2 of forward: y = relu((x-mean)*rstd*gamma+beta); also writes (mean, rstd) to stats
 __global__ __launch_bounds__(GN_TA) void gn_apply_kernel(const GnK p) {
+  __shared__ float sh[GN_TA];
+  __shared__ float tot[512];
   const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
   const int hw = p.h[seg] * p.w[seg];
   const int px0 = blockIdx.x * GN_PPB;
   if (px0 >= hw) return;
+  const int nb = (hw + GN_PPB - 1) / GN_PPB;
+  gn_sum_records<GN_TA>(p.ws + (long long)si * p.nblk * (2 * p.groups), nb, 2 * p.groups, 2 * p.groups, sh, tot);
   const int cpr = p.c / 8, ppi = GN_TA / cpr;
   const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
   const int grp = chunk / p.cpg8;
   const float cnt = (float)hw * (float)(p.c / p.groups);
-  const float* rd = p.red + ((long long)si * p.groups + grp) * 2;
-  const float mean = rd[0] / cnt;
-  const float var = fmaxf(rd[1] / cnt - mean * mean, 0.f);
+  const float mean = tot[2 * grp] / cnt;
+  const float var = fmaxf(tot[2 * grp + 1] / cnt - mean * mean, 0.f);
   const float rstd = rsqrtf(var + p.eps);
   if (blockIdx.x == 0 && prow == 0 && (chunk % p.cpg8) == 0) {
     float* st = p.stats + ((long long)si * p.groups + grp) * 2;
@@ -155,10 +201,11 @@ __global__ __launch_bounds__(GN_TA) void gn_apply_kernel(const GnK p) {
   }
 }
 
-// backward pass 1: per (seg,img,group) s1 = sum dz*gamma, s2 = sum dz*gamma*xhat -> red;
-// per channel dgamma += sum dz*xhat, dbeta += sum dz   (dz = dy * [gamma*xhat+beta > 0])
+// backward pass 1, per block record [3c + 2*groups]: per channel dg = sum dz*xhat, db = sum dz, sx = sum xhat;
+// per group s1 = sum dz*gamma, s2 = sum dz*gamma*xhat       (dz = dy * [gamma*xhat+beta > 0])
+constexpr int GN_BW = 26;     // floats per thread in the block reduction (8 dg + 8 db + 8 sx + s1 + s2)
 __global__ __launch_bounds__(GN_T) void gn_bwd_reduce_kernel(const GnK p) {
-  __shared__ float sh[GN_T * 18];
+  __shared__ float sh[GN_T * GN_BW];
   const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
   const int hw = p.h[seg] * p.w[seg];
   const int px0 = blockIdx.x * GN_PPB;
@@ -168,13 +215,14 @@ __global__ __launch_bounds__(GN_T) void gn_bwd_reduce_kernel(const GnK p) {
   const int grp = chunk / p.cpg8;
   const float* st = p.stats + ((long long)si * p.groups + grp) * 2;
   const float mean = st[0], rstd = st[1];
-  float ga[8], be[8], dg[8], db[8];
+  float ga[8], be[8], dg[8], db[8], sx[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     ga[e] = p.gamma[chunk * 8 + e];
     be[e] = p.beta[chunk * 8 + e];
     dg[e] = 0.f;
     db[e] = 0.f;
+    sx[e] = 0.f;
   }
   float s1 = 0.f, s2 = 0.f;
   const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
@@ -192,57 +240,144 @@ __global__ __launch_bounds__(GN_T) void gn_bwd_reduce_kernel(const GnK p) {
       const float dz = (xh * ga[e] + be[e] > 0.f) ? gg : 0.f;
       dg[e] += dz * xh;
       db[e] += dz;
+      sx[e] += xh;
       s1 += dz * ga[e];
       s2 += dz * ga[e] * xh;
     }
   }
-  float* my = sh + threadIdx.x * 18;
+  float* my = sh + threadIdx.x * GN_BW;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     my[e] = dg[e];
     my[8 + e] = db[e];
+    my[16 + e] = sx[e];
   }
-  my[16] = s1;
-  my[17] = s2;
+  my[24] = s1;
+  my[25] = s2;
   __syncthreads();
+  float* rec = p.ws + ((long long)si * p.nblk + blockIdx.x) * (3 * p.c + 2 * p.groups);
   // channel sums: thread t < c handles channel t
   for (int ch = threadIdx.x; ch < p.c; ch += GN_T) {
     const int ck = ch / 8, e = ch % 8;
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, s = 0.f;
     for (int r = 0; r < ppi; ++r) {
-      a += sh[(r * cpr + ck) * 18 + e];
-      b += sh[(r * cpr + ck) * 18 + 8 + e];
+      const float* t = sh + (r * cpr + ck) * GN_BW;
+      a += t[e];
+      b += t[8 + e];
+      s += t[16 + e];
     }
-    atomicAdd(p.dgamma + ch, a);
-    atomicAdd(p.dbeta + ch, b);
+    rec[ch] = a;
+    rec[p.c + ch] = b;
+    rec[2 * p.c + ch] = s;
   }
   if (threadIdx.x < p.groups) {
     float a = 0.f, b = 0.f;
     for (int r = 0; r < ppi; ++r)
       for (int k = 0; k < p.cpg8; ++k) {
-        a += sh[(r * cpr + threadIdx.x * p.cpg8 + k) * 18 + 16];
-        b += sh[(r * cpr + threadIdx.x * p.cpg8 + k) * 18 + 17];
+        const float* t = sh + (r * cpr + threadIdx.x * p.cpg8 + k) * GN_BW;
+        a += t[24];
+        b += t[25];
       }
-    float* dst = p.red + ((long long)si * p.groups + threadIdx.x) * 2;
-    atomicAdd(dst, a);
-    atomicAdd(dst + 1, b);
+    rec[3 * p.c + 2 * threadIdx.x] = a;
+    rec[3 * p.c + 2 * threadIdx.x + 1] = b;
   }
 }
 
-// backward pass 2: dx = rstd * (dz*gamma - (s1 + xhat*s2)/cnt)
+// backward pass 2: dx = rstd * (dz*gamma - (s1 + xhat*s2)/cnt).
+// Grid row blockIdx.y == 0 is the parameter-gradient row (dispatched first, it overlaps the streaming rows): its
+// workgroups add the per-channel records of ALL (segment, image, block) up in a fixed order, GN_CW channels per pass:
+//   dgamma[c] = sum dg,  dbeta[c] = sum db,
+//   dbias[c]  = sum_p dx[p][c] = sum_si rstd_si * (gamma_c * DB_si[c] - hw_si * m1_si - m2_si * SX_si[c])
+// (the gradient of the bias of the convolution in front of the norm, from the records instead of one more pass
+// over dx).  Rows 1 .. nseg*n are the streaming rows.
+constexpr int GN_CW = 16;     // channels per pass of a parameter-gradient workgroup
 __global__ __launch_bounds__(GN_TA) void gn_bwd_apply_kernel(const GnK p) {
-  const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
+  __shared__ float sh[GN_TA * 3];
+  __shared__ float tot[1024];
+  const int S = p.nseg * p.n;
+  const int R = 3 * p.c + 2 * p.groups;
+  if (blockIdx.y == 0) {
+    constexpr int Q = GN_TA / GN_CW;       // 64 record lanes per channel
+    const int cl = threadIdx.x % GN_CW, q = threadIdx.x / GN_CW;
+    const int cpg = p.c / p.groups;
+    for (int c0 = blockIdx.x * GN_CW; c0 < p.c; c0 += gridDim.x * GN_CW) {
+      __syncthreads();
+      // phase 1: the (s1, s2) group sums of every (segment, image) for the (at most two) groups of this channel slice
+      const int g_lo = c0 / cpg;
+      const int NG = (min(c0 + GN_CW, p.c) - 1) / cpg - g_lo + 1;
+      const int NV = S * NG * 2, Q1 = GN_TA / NV;
+      {
+        const int v = threadIdx.x % NV, j = threadIdx.x / NV;
+        float a = 0.f;
+        if (j < Q1) {
+          const int si = v / (2 * NG), k = v - si * (2 * NG);
+          const int seg = si / p.n;
+          const int nb = (p.h[seg] * p.w[seg] + GN_PPB - 1) / GN_PPB;
+          const float* col = p.ws + (long long)si * p.nblk * R + 3 * p.c + 2 * g_lo + k;
+          for (int b = j; b < nb; b += Q1) a += col[(long long)b * R];
+        }
+        sh[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < NV) {
+          float t = 0.f;
+          for (int k = 0; k < Q1; ++k) t += sh[k * NV + threadIdx.x];
+          tot[threadIdx.x] = t;              // [si][group - g_lo][s1, s2]
+        }
+        __syncthreads();
+      }
+      // phase 2: the per-channel records
+      const int ch = c0 + cl;
+      const bool ok = ch < p.c;
+      const int gi = ok ? ch / cpg - g_lo : 0;
+      const float gam = ok ? p.gamma[ch] : 0.f;
+      float dg = 0.f, db = 0.f, dbi = 0.f;
+      for (int si = 0; si < S; ++si) {
+        const int seg = si / p.n;
+        const int hw = p.h[seg] * p.w[seg];
+        const int nb = (hw + GN_PPB - 1) / GN_PPB;
+        const float rstd = p.stats[((long long)si * p.groups + g_lo + gi) * 2 + 1];
+        const float m2 = tot[(si * NG + gi) * 2 + 1] / ((float)hw * (float)cpg);
+        if (ok)
+          for (int b = q; b < nb; b += Q) {
+            const float* rec = p.ws + ((long long)si * p.nblk + b) * R;
+            const float rdb = rec[p.c + ch];
+            dg += rec[ch];
+            db += rdb;
+            dbi += rstd * (gam * rdb - m2 * rec[2 * p.c + ch]);
+          }
+      }
+      sh[(0 * Q + q) * GN_CW + cl] = dg;
+      sh[(1 * Q + q) * GN_CW + cl] = db;
+      sh[(2 * Q + q) * GN_CW + cl] = dbi;
+      __syncthreads();
+      if (threadIdx.x < GN_CW && ok) {
+        float t[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 3; ++k)
+          for (int j = 0; j < Q; ++j) t[k] += sh[(k * Q + j) * GN_CW + cl];
+        for (int si = 0; si < S; ++si) {       // - rstd * hw * m1, m1 = s1 / (hw * cpg)
+          const float rstd = p.stats[((long long)si * p.groups + g_lo + gi) * 2 + 1];
+          t[2] -= rstd * tot[(si * NG + gi) * 2] / (float)cpg;
+        }
+        p.dgamma[ch] = t[0];
+        p.dbeta[ch] = t[1];
+        if (p.dbias) p.dbias[ch] = t[2];
+      }
+    }
+    return;
+  }
+  const int si = blockIdx.y - 1, seg = si / p.n, img = si - seg * p.n;
   const int hw = p.h[seg] * p.w[seg];
   const int px0 = blockIdx.x * GN_PPB;
   if (px0 >= hw) return;
+  const int nb = (hw + GN_PPB - 1) / GN_PPB;
+  gn_sum_records<GN_TA>(p.ws + (long long)si * p.nblk * R + 3 * p.c, nb, R, 2 * p.groups, sh, tot);
   const int cpr = p.c / 8, ppi = GN_TA / cpr;
   const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
   const int grp = chunk / p.cpg8;
   const float* st = p.stats + ((long long)si * p.groups + grp) * 2;
   const float mean = st[0], rstd = st[1];
   const float cnt = (float)hw * (float)(p.c / p.groups);
-  const float* rd = p.red + ((long long)si * p.groups + grp) * 2;
-  const float m1 = rd[0] / cnt, m2 = rd[1] / cnt;
+  const float m1 = tot[2 * grp] / cnt, m2 = tot[2 * grp + 1] / cnt;
   float ga[8], be[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -344,15 +479,31 @@ int fill_gn(const dsl_gn_desc* d, GnK& k, long long* total_px) {
   k.eps = d->eps;
   k.x = (const uint16_t*)d->x; k.y = (uint16_t*)d->y; k.gamma = d->gamma; k.beta = d->beta;
   k.stats = d->stats; k.dy = (const uint16_t*)d->dy; k.dx = (uint16_t*)d->dx;
-  k.dgamma = d->dgamma; k.dbeta = d->dbeta; k.red = d->red;
+  k.dgamma = d->dgamma; k.dbeta = d->dbeta; k.dbias = d->dbias; k.ws = (float*)d->workspace;
+  int maxhw = 0;
+  for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
+  k.nblk = (maxhw + GN_PPB - 1) / GN_PPB;
   return 0;
 }
 
+}  // namespace
+extern "C" size_t dsl_groupnorm_workspace_bytes(const dsl_gn_desc* d) {
+  if (!d || d->nseg < 1 || d->nseg > DSL_MAX_SEG) return 0;
+  int maxhw = 0;
+  for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
+  const size_t nblk = (maxhw + GN_PPB - 1) / GN_PPB;
+  return (size_t)d->nseg * d->n * nblk * (3 * (size_t)d->c + 2 * (size_t)d->groups) * sizeof(float);
+}
+namespace {
 int gn_check(const dsl_gn_desc* d, const char* who) {
   DSL_CHECK(d && d->nseg >= 1 && d->nseg <= DSL_MAX_SEG, "%s: bad descriptor", who);
   DSL_CHECK(d->c % 8 == 0 && d->c <= GN_T * 8 && GN_T % (d->c / 8) == 0, "%s: unsupported C=%d", who, d->c);
   DSL_CHECK(d->groups > 0 && d->c % d->groups == 0 && (d->c / d->groups) % 8 == 0 && d->groups <= 256,
             "%s: channels per group must be a multiple of 8 (C=%d groups=%d)", who, d->c, d->groups);
+  DSL_CHECK(GN_TA % (2 * d->groups) == 0, "%s: 2*groups=%d must divide %d", who, 2 * d->groups, GN_TA);
+  DSL_CHECK(d->nseg * d->n * 4 <= 1024, "%s: more than 256 (segment, image) pairs", who);
+  DSL_CHECK(d->workspace && d->workspace_bytes >= dsl_groupnorm_workspace_bytes(d), "%s: workspace too small (%zu < %zu)",
+            who, d->workspace_bytes, dsl_groupnorm_workspace_bytes(d));
   return 0;
 }
 
@@ -382,7 +533,7 @@ extern "C" int dsl_maxpool3x3s2(const void* x, void* y, int n, int h, int w, int
 
 extern "C" int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream) {
   if (gn_check(d, "dsl_groupnorm_relu_fwd")) return -1;
-  DSL_CHECK(d->x && d->y && d->gamma && d->beta && d->stats && d->red, "dsl_groupnorm_relu_fwd: null pointer");
+  DSL_CHECK(d->x && d->y && d->gamma && d->beta && d->stats, "dsl_groupnorm_relu_fwd: null pointer");
   GnK k;
   long long tot;
   fill_gn(d, k, &tot);
@@ -390,7 +541,6 @@ extern "C" int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream) {
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   dim3 grid((maxhw + GN_PPB - 1) / GN_PPB, d->nseg * d->n);
   hipStream_t st = (hipStream_t)stream;
-  if (!d->prezeroed) hipMemsetAsync(d->red, 0, sizeof(float) * 2 * d->nseg * d->n * d->groups, st);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_T), 0, st, k);
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_TA), 0, st, k);
   DSL_LAUNCH_CHECK("gn forward");
@@ -399,7 +549,7 @@ extern "C" int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream) {
 
 extern "C" int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream) {
   if (gn_check(d, "dsl_groupnorm_relu_bwd")) return -1;
-  DSL_CHECK(d->x && d->dy && d->dx && d->gamma && d->beta && d->stats && d->red && d->dgamma && d->dbeta,
+  DSL_CHECK(d->x && d->dy && d->dx && d->gamma && d->beta && d->stats && d->dgamma && d->dbeta,
             "dsl_groupnorm_relu_bwd: null pointer");
   GnK k;
   long long tot;
@@ -408,13 +558,9 @@ extern "C" int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream) {
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   dim3 grid((maxhw + GN_PPB - 1) / GN_PPB, d->nseg * d->n);
   hipStream_t st = (hipStream_t)stream;
-  if (!d->prezeroed) {
-    hipMemsetAsync(d->red, 0, sizeof(float) * 2 * d->nseg * d->n * d->groups, st);
-    hipMemsetAsync(d->dgamma, 0, sizeof(float) * d->c, st);
-    hipMemsetAsync(d->dbeta, 0, sizeof(float) * d->c, st);
-  }
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(GN_T), 0, st, k);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(GN_TA), 0, st, k);
+  dim3 grid2(grid.x, grid.y + 1);        // + the parameter-gradient row
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid2, dim3(GN_TA), 0, st, k);
   DSL_LAUNCH_CHECK("gn backward");
   return 0;
 }

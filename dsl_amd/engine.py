@@ -41,10 +41,11 @@ class OpList:
         self.arr = None
 
     def conv(self, d, side=False):
-        self._add(L.OP_CONV, d, i=(0, 0, 0, 0, 0, 0, 1 if side else 0))
+        """side: False/0 = the caller's stream, True/1..3 = that side stream of the library."""
+        self._add(L.OP_CONV, d, i=(0, 0, 0, 0, 0, 0, int(side)))
 
-    def fork(self):
-        self._add(L.OP_FORK)
+    def fork(self, side=1):
+        self._add(L.OP_FORK, i=(side,))
 
     def wgrad(self, d, side=False):
         """side=True: on the library's side stream, after a FORK (the weight gradient only depends on tensors
@@ -61,8 +62,8 @@ class OpList:
             self._add(L.OP_FORK)
         self._add(L.OP_WGRAD_GROUP, arr, i=(len(arr), 0, 0, 0, 0, 0, 1 if side else 0))
 
-    def join(self):
-        self._add(L.OP_JOIN)
+    def join(self, side=1):
+        self._add(L.OP_JOIN, i=(side,))
 
     def record(self, slot, stream=1):
         """Named event: everything queued so far on `stream` (1 = the side stream)."""
@@ -72,7 +73,7 @@ class OpList:
         self._add(L.OP_WAIT, i=(stream, slot))
 
     def gn_fwd(self, d, side=False):
-        self._add(L.OP_GN_FWD, d, i=(0, 0, 0, 0, 0, 0, 1 if side else 0))
+        self._add(L.OP_GN_FWD, d, i=(0, 0, 0, 0, 0, 0, int(side)))
 
     def gn_bwd(self, d):
         self._add(L.OP_GN_BWD, d)
@@ -126,12 +127,7 @@ class Plan:
         # split-K scratch shared by all convs of the plan (they run back to back on one stream); the library
         # lowers its split factor if a conv would need more than this
         self.conv_ws = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
-        # one pre-zeroed pool for every GroupNorm reduction buffer of the step (8 forward + 8 backward slices):
-        # a single memset at the start of the forward list replaces one memset per GN launch
-        self._gn_slice = 5 * N * 32 * 2
-        self.zero_pool = torch.zeros(16 * self._gn_slice, dtype=torch.float32, device=dev)
-        self._gn_next = 0
-        self.fwd.memset(self.zero_pool, self.zero_pool.numel() * 4)
+        self._gn_ws = {}          # GroupNorm block-record workspaces, one per stream that runs GroupNorm launches
         self._build_forward()
         if training:
             self.lossplan = FcosLossPlan(N, self.level_sizes, dev, max_gt=max_gt)
@@ -227,9 +223,11 @@ class Plan:
         self.tower = {}
         # the two towers are independent chains: the regression tower (+ its predictor) runs on the side stream
         self.conv_ws_side = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
-        f.fork()
+        FSIDE = 2 if os.environ.get('DSL_SIDE', '1') != '0' else 0      # side stream 1 carries the weight gradients (and may be CU-masked)
+        if FSIDE:
+            f.fork(FSIDE)
         for tower in ('cls_convs', 'reg_convs'):
-            side = tower == 'reg_convs'
+            side = FSIDE if tower == 'reg_convs' else 0
             xin = feats
             lays = []
             for i in range(4):
@@ -243,8 +241,7 @@ class Plan:
                 f.conv(cd_, side=side)
                 base = f'bbox_head.{tower}.{i}.gn'
                 gd = ops.gn_desc(pre, act, st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'), stats,
-                                 self._gn_red(), n=N, hw=ls)
-                gd.prezeroed = 1
+                                 self._gn_workspace('side' if side else 'main'), n=N, hw=ls)
                 f.gn_fwd(gd, side=side)
                 lays.append(dict(spec=spec, xin=xin, pre=pre, act=act, stats=stats, gn=base))
                 xin = act
@@ -256,18 +253,23 @@ class Plan:
                              flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.cls_b'), workspace=self.conv_ws))
         f.conv(ops.conv_desc(self.tower['reg_convs'][3]['act'], st.t16_ptr('head.regctr_w'), regctr, n=N, grid=ls,
                              src_hw=ls, dst_hw=ls, cs=256, cd=5, cd_pad=64, ldd=8, kh=3, kw=3, stride=1, pad=1,
-                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.regctr_b'), workspace=self.conv_ws_side), side=True)
-        f._add(L.OP_JOIN)
+                             flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.regctr_b'), workspace=self.conv_ws_side),
+               side=FSIDE)
+        if FSIDE:
+            f.join(FSIDE)
 
-    def _gn_red(self):
-        assert self._gn_next < 16
-        ptr = self.zero_pool.data_ptr() + self._gn_next * self._gn_slice * 4
-        self._gn_next += 1
-        return ptr
+    def _gn_workspace(self, key):
+        """Launches on one stream run one after the other and may share the block-record scratch."""
+        ws = self._gn_ws.get(key)
+        if ws is None:
+            nblk = (max(h * w for h, w in self.level_sizes) + 127) // 128
+            ws = torch.empty(5 * self.N * nblk * (3 * 256 + 64), dtype=torch.float32, device=self.dev)
+            self._gn_ws[key] = ws
+        return ws
 
     # ---------------------------------------------------------------------------------------------
     def _wgrad(self, ol, spec, dy, x, n, out_hw, in_hw, cy=None, cd=None, wregion=None, bregion=None, side=False,
-               emit=True):
+               emit=True, no_db=False):
         """emit=False: only build the descriptor (for a later grouped launch)."""
         st = self.store
         scale = st.bn_ptrs(spec.bn)[0] if (spec is not None and spec.bn) else None
@@ -275,7 +277,7 @@ class Plan:
         db = None
         if bregion is not None:
             db = st.t32_ptr(bregion, st.grad)
-        elif spec is not None and spec.bias:
+        elif spec is not None and spec.bias and not no_db:
             db = st.t32_ptr(spec.name + '.bias', st.grad)
         k = 3 if spec is None else spec.k
         d = ops.wgrad_desc(dy, x, st.t32_ptr(name, st.grad), n=n, grid=out_hw, src_hw=in_hw,
@@ -335,7 +337,7 @@ class Plan:
         lp = self.lossplan
         reg = st.train_regions
         M = self.M
-        SIDE = True
+        SIDE = os.environ.get('DSL_SIDE', '1') != '0'
         # tuning knobs (both measured: on is better): group the last segment's weight gradients too, although nothing
         # is left on the caller's stream to overlap their tail with ...
         GROUP_LAST = os.environ.get('DSL_GROUP_LAST', '1') != '0'
@@ -343,11 +345,6 @@ class Plan:
         g_feats = self.buf('g_feats', M, 256)
         # ================= segment 0: head + FPN =================
         ol = OpList()
-        # the 16 GN gamma/beta gradient vectors are contiguous in the flat gradient buffer: one memset
-        g0 = reg['bbox_head.cls_convs.0.gn.weight'][0]
-        g1 = reg['bbox_head.reg_convs.3.gn.bias'][0] + reg['bbox_head.reg_convs.3.gn.bias'][1]
-        assert g1 - g0 == 16 * 256
-        ol.memset(st.grad.data_ptr() + g0 * 4, (g1 - g0) * 4)
         for ti, tower in enumerate(('cls_convs', 'reg_convs')):
             lays = self.tower[tower]
             g_act = self.buf(f'g_{tower}_act3', M, 256)
@@ -364,12 +361,15 @@ class Plan:
                 lay = lays[i]
                 base = lay['gn']
                 g_pre = self.buf(f'g_{tower}_pre{i}', M, 256)
+                # the GroupNorm backward also yields the conv bias gradient (sum over pixels of g_pre) from its block
+                # records: the weight gradient below runs without its column-sum pass
                 gd = ops.gn_desc(lay['pre'], lay['act'], st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'),
-                                 lay['stats'], self._gn_red(), n=N, hw=ls, dy=g_act, dx=g_pre,
-                                 dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad))
-                gd.prezeroed = 1
+                                 lay['stats'], self._gn_workspace('main'), n=N, hw=ls, dy=g_act, dx=g_pre,
+                                 dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad),
+                                 dbias=st.t32_ptr(lay['spec'].name + '.bias', st.grad))
                 ol.gn_bwd(gd)
-                tower_group.append(self._wgrad(ol, lay['spec'], g_pre, lay['xin'], N, ls, ls, side=SIDE, emit=not GROUP))
+                tower_group.append(self._wgrad(ol, lay['spec'], g_pre, lay['xin'], N, ls, ls, side=SIDE, emit=not GROUP,
+                                               no_db=True))
                 if i > 0:
                     g_act = self.buf(f'g_{tower}_act{i - 1}', M, 256)
                     ol.conv(self._dgrad(lay['spec'].name, g_pre, g_act, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
@@ -377,7 +377,7 @@ class Plan:
                     ol.conv(self._dgrad(lay['spec'].name, g_pre, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1,
                                         pad=1, addend=g_feats if ti == 1 else None))
             if GROUP:
-                self._wgrad_group(ol, tower_group)
+                self._wgrad_group(ol, tower_group, side=SIDE)
         # ---- FPN backward ----
         cv = st.convs
         fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
@@ -469,7 +469,7 @@ class Plan:
                 tail_main = (li == 1) and os.environ.get('DSL_TAIL_MAIN', '1') != '0'
                 for grp_descs in (g3, g2, g1):
                     # last segment: the caller's stream has nothing left to do, it takes the last group itself
-                    self._wgrad_group(ol, grp_descs, side=not (tail_main and grp_descs is g1),
+                    self._wgrad_group(ol, grp_descs, side=SIDE and not (tail_main and grp_descs is g1),
                                       ws_name='wg_ws_main' if (tail_main and grp_descs is g1) else 'wg_ws')
             seg = 4 - li                      # 1, 2, 3
             ol.record(seg)
@@ -497,14 +497,15 @@ class Engine:
         self.plans = {}         # insertion-ordered: least recently used first
 
     def plan(self, store, N, H, W, training=True):
-        key = (id(store), N, H, W, training)
+        if store.dirty:
+            store.refresh()           # in place where the packs exist; a re-allocation bumps store.generation
+        key = (id(store), getattr(store, 'generation', 0), N, H, W, training)
         p = self.plans.pop(key, None)
         if p is None:
-            while len(self.plans) >= self.MAX_PLANS:
+            stale = [k for k in self.plans if k[0] == id(store) and k[1] != key[1]]
+            while stale or len(self.plans) >= self.MAX_PLANS:
                 torch.cuda.synchronize()                    # the evicted plan's buffers may still be in use on a stream
-                self.plans.pop(next(iter(self.plans)))
+                self.plans.pop(stale.pop() if stale else next(iter(self.plans)))
             p = Plan(store, N, H, W, training)
         self.plans[key] = p
-        if store.dirty:
-            store.refresh()
         return p

@@ -105,16 +105,23 @@ def conv2d_wgrad(*a, **k):
     return d
 
 
-def gn_desc(x, y, gamma, beta, stats, red, *, n, hw, c=256, groups=32, eps=1e-5, dy=None, dx=None,
-            dgamma=None, dbeta=None):
+def gn_desc(x, y, gamma, beta, stats, workspace=None, *, n, hw, c=256, groups=32, eps=1e-5, dy=None, dx=None,
+            dgamma=None, dbeta=None, dbias=None):
+    """workspace: uint8/float tensor of >= dsl_groupnorm_workspace_bytes (allocated here when None); calls that may
+    run concurrently (different streams) need different workspaces."""
     d = L.GnDesc()
     d.nseg, d.n, d.c, d.groups = len(hw), n, c, groups
     d.h, d.w = _segs(hw)
     d.eps = eps
-    d.x, d.y, d.gamma, d.beta, d.stats, d.red = (L.ptr(t) for t in (x, y, gamma, beta, stats, red))
-    d.prezeroed = 0
-    d.dy, d.dx, d.dgamma, d.dbeta = (L.ptr(t) for t in (dy, dx, dgamma, dbeta))
-    d._keep = (x, y, gamma, beta, stats, red, dy, dx, dgamma, dbeta)
+    d.x, d.y, d.gamma, d.beta, d.stats = (L.ptr(t) for t in (x, y, gamma, beta, stats))
+    d.dy, d.dx, d.dgamma, d.dbeta, d.dbias = (L.ptr(t) for t in (dy, dx, dgamma, dbeta, dbias))
+    need = lib.dsl_groupnorm_workspace_bytes(C.byref(d))
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device='cuda')
+    nbytes = workspace.numel() * workspace.element_size()
+    assert nbytes >= need, (nbytes, need)
+    d.workspace, d.workspace_bytes = L.ptr(workspace), nbytes
+    d._keep = (x, y, gamma, beta, stats, workspace, dy, dx, dgamma, dbeta, dbias)
     return d
 
 

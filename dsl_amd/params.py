@@ -238,14 +238,20 @@ class ParamStore:
             bis.append(b - m * sc)
             self.bn_off[s.bn] = off
             off += s.cout
-        self.bn_scale = torch.cat(scs).contiguous()
-        self.bn_bias = torch.cat(bis).contiguous()
-        self._pack_tab = None        # holds pointers into bn_scale
-        self.frozen16 = self.frozen.bfloat16()
-        w = self.fview('backbone.conv1.weight')           # [64][7][7][3] -> [64][448], k = tap*8 + c
         wp = torch.zeros(64, 7 * 64, device=dev)
+        w = self.fview('backbone.conv1.weight')           # [64][7][7][3] -> [64][448], k = tap*8 + c
         wp[:, :392] = torch.cat([w, torch.zeros(64, 7, 7, 5, device=dev)], -1).reshape(64, 392)
-        self.stem16 = wp.bfloat16()
+        # Execution plans bake the device addresses of these four tensors into their kernel descriptors: refresh IN
+        # PLACE whenever the buffers already exist on this device (load_state_dict into a model that has already run)
+        for name, val in (('bn_scale', torch.cat(scs)), ('bn_bias', torch.cat(bis)), ('frozen16', self.frozen.bfloat16()),
+                          ('stem16', wp.bfloat16())):
+            cur = getattr(self, name, None)
+            if cur is not None and cur.device == val.device and cur.shape == val.shape:
+                cur.copy_(val)
+            else:
+                setattr(self, name, val.contiguous())
+                self._pack_tab = None        # holds pointers into bn_scale
+                self.generation = getattr(self, 'generation', 0) + 1    # plans built against older buffers are stale
 
     def refresh_train_packs(self, stream_ptr=None):
         """bf16 forward pack (= cast of the flat buffer) and dgrad packs.  Called after load_state_dict;

@@ -272,8 +272,9 @@ def adaptive_thresholds(scores_by_class, prev_thres=None, ranges=(0.3, 0.35), ga
     return thres, weights
 
 
-def split_pseudo_labels(boxes, labels, scores, thres_by_class, default_thres=(0.1, 0.4), img_wh=None):
-    """datasets/semicoco.py:184-291: score in [default_lo, thr_c) -> gt_bboxes_ignore, otherwise -> gt box."""
+def split_pseudo_labels(boxes, labels, scores, thres_by_class, default_thres=(0.1, 0.3), img_wh=None):
+    """datasets/semicoco.py:184-291: score in [default_lo, thr_c) -> gt_bboxes_ignore, otherwise -> gt box; classes
+    without a threshold of their own use the dataset's default band [0.1, 0.3) (semicoco.py:56, semivoc.py:43)."""
     gt, gl, ig = [], [], []
     for b, l, s in zip(boxes, labels, scores):
         x1, y1, x2, y2 = (float(v) for v in b)

@@ -121,7 +121,9 @@ int dsl_pack_image(const float* img_nchw, void* out_nhwc8, int n, int h, int w, 
 int dsl_maxpool3x3s2(const void* x, void* y, int n, int h, int w, int c, void* stream);
 
 /* GroupNorm(32 groups, eps) + ReLU over level-major NHWC bf16 (mmcv ConvModule norm+act as used at
- * anchor_free_head.py:104-133).  stats = [nseg*n*groups][2] fp32 (mean, rstd), written by fwd. */
+ * anchor_free_head.py:104-133).  stats = [nseg*n*groups][2] fp32 (mean, rstd), written by fwd.
+ * Both directions are two passes with two-level, fixed-order reductions through `workspace` (block records,
+ * no atomics, nothing to pre-zero): results are bit-identical from run to run. */
 typedef struct dsl_gn_desc {
   int32_t nseg, n, c, groups;
   int32_t h[DSL_MAX_SEG], w[DSL_MAX_SEG];
@@ -136,9 +138,11 @@ typedef struct dsl_gn_desc {
   void* dx;               /* bf16 grad wrt x */
   float* dgamma;          /* fp32 [c], overwritten */
   float* dbeta;           /* fp32 [c], overwritten */
-  float* red;             /* fp32 scratch [nseg*n*groups][2] */
-  int32_t prezeroed;      /* 1: caller already zeroed red (and dgamma/dbeta for bwd): skip the memsets */
+  float* dbias;           /* fp32 [c] or NULL: sum over pixels of dx = gradient of the bias of the conv that made x */
+  void* workspace;        /* >= dsl_groupnorm_workspace_bytes(d); private to this call until it completes */
+  size_t workspace_bytes;
 } dsl_gn_desc;
+size_t dsl_groupnorm_workspace_bytes(const dsl_gn_desc* d);
 int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream);
 int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream);
 
@@ -283,6 +287,9 @@ int dsl_probe_tr16(const uint16_t* lds_image /* 4096 u16 */, const int32_t* lane
 /* xcc_of_block[b] = HW_REG_XCC_ID of workgroup b; every workgroup adds 1.0 to acc[xcc][0..255] (8 x 256 floats,
  * zeroed by the caller) with workgroup-scope atomics */
 int dsl_probe_xcc(int32_t* xcc_of_block, float* acc, int nblocks, void* stream);
+/* Runs nblocks one-per-CU workgroups on a temporary stream created with the given CU mask (NULL: unrestricted) and
+ * returns per workgroup out[2b] = XCC id, out[2b+1] = HW_ID register (SE/SH/CU fields); synchronous. */
+int dsl_probe_cu_mask(const uint32_t* mask, int nwords, int32_t* out /* [nblocks][2] */, int nblocks);
 
 #ifdef __cplusplus
 }

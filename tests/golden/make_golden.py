@@ -272,6 +272,10 @@ def gen_pseudo_split():
     ns = dict(os=os, json=json, np=np)
     exec(compile(ast.Module(body=[fn], type_ignores=[]), path, 'exec'), ns)
     parse = ns['_parse_ann_info']
+    # the class's own default band: the literal assigned to self.default_thres in SemiCOCODataset.__init__ (semicoco.py:56)
+    init = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == '__init__'][0]
+    default_thres = [ast.literal_eval(n.value) for n in ast.walk(init) if isinstance(n, ast.Assign)
+                     and isinstance(n.targets[0], ast.Attribute) and n.targets[0].attr == 'default_thres'][0]
     rng = np.random.RandomState(13)
     names = [f'cls{i}' for i in range(8)]
     cat2id = {n: i for i, n in enumerate(names)}
@@ -293,13 +297,14 @@ def gen_pseudo_split():
     for mode in ('no_file', 'file'):
         if mode == 'file':
             json.dump(dict(thres=thres), open(thres_file, 'w'))
-        self = types.SimpleNamespace(ann_path=tmp, thres=thres_file, default_thres=[0.1, 0.4], labelmapper=dict(cat2id=cat2id))
+        self = types.SimpleNamespace(ann_path=tmp, thres=thres_file, default_thres=default_thres, labelmapper=dict(cat2id=cat2id))
         outs = []
         for k in range(12):
             a = parse(self, dict(filename=f'im{k}.jpg', width=W, height=H), None)
             outs.append(dict(bboxes=a['bboxes'].tolist(), labels=a['labels'].tolist(), ignore=a['bboxes_ignore'].tolist()))
         modes.append(dict(mode=mode, thres=thres if mode == 'file' else None, outs=outs))
-    json.dump(dict(names=names, wh=[W, H], imgs=imgs, modes=modes), open(os.path.join(HERE, 'pseudo_split.json'), 'w'))
+    json.dump(dict(names=names, wh=[W, H], imgs=imgs, modes=modes, default_thres=default_thres),
+              open(os.path.join(HERE, 'pseudo_split.json'), 'w'))
     print('wrote pseudo_split.json', sum(len(o['bboxes']) for o in modes[0]['outs']), sum(len(o['ignore']) for o in modes[0]['outs']))
 
 

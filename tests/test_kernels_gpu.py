@@ -76,6 +76,25 @@ def test_probe_xcc_local_atomics(K):
     print('blocks per XCD', counts.tolist(), 'block->xcc head', x[:16].tolist())
 
 
+@pytest.mark.gpu
+def test_probe_cu_mask(K):
+    """hipExtStreamCreateWithCUMask on MI355X: bit i of the 256-bit mask = CU i // 8 of XCD i % 8 (what the DSL_SIDE_CUS
+    experiment knob of api.hip relies on): the first 96 bits give 12 CUs in every XCD."""
+    import ctypes as C
+    L, _ = K
+    nb = 1024
+    out = torch.zeros(nb, 2, dtype=torch.int32, device='cuda')
+    mask = (C.c_uint32 * 8)()
+    for b in range(96):
+        mask[b >> 5] |= 1 << (b & 31)
+    L.check(L.lib.dsl_probe_cu_mask(mask, 8, L.ptr(out), nb))
+    o = out.cpu()
+    xcc, hw = o[:, 0], o[:, 1]
+    ids = {(int(x), int(h) & 0x7f00) for x, h in zip(xcc.tolist(), hw.tolist())}      # (XCD, SE | SH | CU fields of HW_ID)
+    per = torch.bincount(torch.tensor([i[0] for i in ids]), minlength=8)
+    assert len(ids) == 96 and per.tolist() == [12] * 8, (len(ids), per.tolist())
+
+
 # ------------------------------------------------------------------------------------------------
 def test_probe_tr16(K):
     """Documents the ds_read_b64_tr_b16 semantics the weight-gradient kernel relies on:
@@ -107,7 +126,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 15, 4 + (3 << 4), 5 + (2 << 4), 6 + (5 << 4), 0 + (16 << 4)])
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 4 + (3 << 4), 5 + (2 << 4), 6 + (5 << 4), 7 + (2 << 4), 0 + (16 << 4)])
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_forward(K, case, force):
     """force: 0 = library's own tile choice, 1..5 = v2 (DMA-to-LDS) tile configs, 15 = v1 kernel."""
@@ -115,7 +134,7 @@ def test_conv_forward(K, case, force):
     _, N, Ci, Co, H, W, k, s, p = case
     ws = torch.empty(64 << 20, dtype=torch.uint8, device='cuda') if force >> 4 else None
     force = (force & 15) | ((force >> 4) & 15) << 4         # bits 8-11 tile config, bits 12-15 forced split-K (16 -> auto)
-    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128}.get(force & 15)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64}.get(force & 15)
     if bco and ((Co + 63) // 64 * 64) % bco:
         pytest.skip('tile does not divide Cout')
     g = torch.Generator().manual_seed(hash(case[0]) % 1000)
@@ -203,13 +222,13 @@ DGRAD_CASES = [('3x3_s1', 2, 128, 64, 11, 13, 3, 1, 1), ('3x3_s2', 1, 128, 128, 
                ('1x1_s1', 2, 256, 128, 7, 9, 1, 1, 0), ('3x3_s1_pad80', 1, 256, 80, 9, 9, 3, 1, 1)]
 
 
-@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 15])
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 15])
 @pytest.mark.parametrize('case', DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
 def test_conv_dgrad_transposed(K, case, force):
     """mode 1 gather == autograd input-gradient; epilogue (acc + addend) * (mask > 0)."""
     L, ops = K
     _, N, Ci, Co, H, W, k, s, p = case
-    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128}.get(force)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64}.get(force)
     if bco and Ci % bco:
         pytest.skip('tile does not divide Cin')
     g = torch.Generator().manual_seed(len(case[0]))
@@ -265,7 +284,7 @@ def test_wgrad(K, case, cfg):
     L, ops = K
     _, N, Ci, Co, H, W, k, s, p = case
     need = {1: (256, 256), 2: (256, 128), 3: (128, 256), 4: (128, 128)}.get(cfg)
-    if need and (Co % need[0] or Ci % need[1]):
+    if need and ((Co % need[0] and not (need[0] == 128 and Co % 64 == 0)) or Ci % need[1]):   # 128-cout tiles take cy = 64 (mod 128): zero upper half
         pytest.skip('tile does not divide the channels')
     g = torch.Generator().manual_seed(7 + len(case[0]))
     x = rnd(N, Ci, H, W, g=g)
@@ -386,24 +405,32 @@ def test_groupnorm_relu_fwd_bwd(K):
     x_d = _multiseg([x.detach() for x in xs])
     y_d = torch.empty(P, Cc, dtype=torch.bfloat16, device='cuda')
     stats = torch.empty(5 * N * 32, 2, device='cuda')
-    red = torch.empty(5 * N * 32, 2, device='cuda')
     ga, be = gamma.detach().cuda(), beta.detach().cuda()
-    d = ops.gn_desc(x_d, y_d, ga, be, stats, red, n=N, hw=sizes)
+    d = ops.gn_desc(x_d, y_d, ga, be, stats, n=N, hw=sizes)
     L.check(L.lib.dsl_groupnorm_relu_fwd(C.byref(d), L.stream_ptr()))
     sync()
     ref_y = torch.cat([y.detach().permute(0, 2, 3, 1).reshape(-1, Cc) for y in ys])
     assert torch.allclose(y_d.float().cpu(), ref_y, rtol=1e-2, atol=1e-2)
     dy_d = _multiseg(dys)
     dx_d = torch.empty_like(y_d)
-    dgam, dbet = torch.empty(Cc, device='cuda'), torch.empty(Cc, device='cuda')
-    d = ops.gn_desc(x_d, y_d, ga, be, stats, red, n=N, hw=sizes, dy=dy_d, dx=dx_d, dgamma=dgam, dbeta=dbet)
+    dgam, dbet, dbias = (torch.full((Cc,), float('nan'), device='cuda') for _ in range(3))      # overwritten, never accumulated
+    d = ops.gn_desc(x_d, y_d, ga, be, stats, n=N, hw=sizes, dy=dy_d, dx=dx_d, dgamma=dgam, dbeta=dbet, dbias=dbias)
     L.check(L.lib.dsl_groupnorm_relu_bwd(C.byref(d), L.stream_ptr()))
     sync()
+    first = [t.clone() for t in (dx_d, dgam, dbet, dbias, y_d)]
+    L.check(L.lib.dsl_groupnorm_relu_fwd(C.byref(d), L.stream_ptr()))
+    L.check(L.lib.dsl_groupnorm_relu_bwd(C.byref(d), L.stream_ptr()))
+    sync()
+    for a, b in zip(first, (dx_d, dgam, dbet, dbias, y_d)):          # fixed-order reductions: bit-identical reruns
+        assert torch.equal(a, b)
     ref_dx = torch.cat([x.grad.permute(0, 2, 3, 1).reshape(-1, Cc) for x in xs])
     got = dx_d.float().cpu()
     assert torch.allclose(got, ref_dx, rtol=2e-2, atol=2e-2 * float(ref_dx.abs().max())), (got - ref_dx).abs().max()
     assert torch.allclose(dgam.cpu(), gamma.grad, rtol=1e-2, atol=1e-2 * float(gamma.grad.abs().max()))
     assert torch.allclose(dbet.cpu(), beta.grad, rtol=1e-2, atol=1e-2 * float(beta.grad.abs().max()))
+    # bias gradient of the conv in front of the norm = column sum of dx (here of the fp32 reference dx)
+    ref_db = ref_dx.sum(0)
+    assert torch.allclose(dbias.cpu(), ref_db, rtol=1e-2, atol=1e-2 * float(ref_db.abs().max()) + 1e-3), (dbias.cpu() - ref_db).abs().max()
 
 
 def test_maxpool_sum2x2_colsum(K):
