@@ -82,10 +82,62 @@ __device__ void radix_select_block(const float* keys, int P, int k, unsigned* hi
   need_out = need;
 }
 
-// one block per (image, level): indices of the top nms_pre keys (all of them when the level is smaller)
+// Ordered stream compaction by one workgroup: element i of [0, P) is taken when take(i) says so, taken elements get
+// consecutive output slots IN INDEX ORDER (no atomics: results do not depend on wave arrival order).  Among the
+// elements for which tie(i) holds only the first `need` (lowest indices) are taken - the deterministic version of
+// "any `need` of the equal keys", and the choice torch.topk makes on the CPU path of the reference.
+// Two passes over wave-contiguous segments: count (ballot + popcount), workgroup scan of the 16 wave totals, write.
+template <typename Take, typename Tie, typename Emit>
+__device__ void ordered_compact(int P, unsigned need, unsigned* s_wave /* >= 2 * 16 + 2 */, Take take, Tie tie, Emit emit,
+                                unsigned* total_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int seg = ((P + nw - 1) / nw + 63) / 64 * 64;          // elements per wave, multiple of 64
+  const int lo = wave * seg, hi = min(P, lo + seg);
+  unsigned ntake = 0, ntie = 0;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const bool in = i < hi;
+    ntake += __popcll(__ballot(in && take(i)));
+    ntie += __popcll(__ballot(in && tie(i)));
+  }
+  if (lane == 0) {
+    s_wave[wave] = ntake;
+    s_wave[16 + wave] = ntie;
+  }
+  __syncthreads();
+  // ties taken from the waves in front of this one, and the output slots they (and their sure takes) use
+  unsigned tie_before = 0, out_before = 0;
+  for (int w = 0; w < wave; ++w) {
+    const unsigned t = s_wave[16 + w];
+    const unsigned used = tie_before < need ? min(t, need - tie_before) : 0u;
+    out_before += s_wave[w] + used;
+    tie_before += t;
+  }
+  unsigned out = out_before, tr = tie_before;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const bool in = i < hi;
+    const bool tk = in && take(i), ti = in && tie(i);
+    const unsigned long long bt = __ballot(ti);
+    const unsigned my_tr = tr + (unsigned)__popcll(bt & lt);
+    const bool sel = tk || (ti && my_tr < need);
+    const unsigned long long bs = __ballot(sel);
+    if (sel) emit(i, out + (unsigned)__popcll(bs & lt));
+    out += (unsigned)__popcll(bs);
+    tr += (unsigned)__popcll(bt);
+  }
+  if (total_out) {
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) *total_out = out;       // the last wave's running offset = the total
+    __syncthreads();
+  }
+}
+
+// one block per (image, level): indices of the top nms_pre keys (all of them when the level is smaller), in index order
 __global__ __launch_bounds__(1024) void det_select_kernel(const DetK p) {
   __shared__ unsigned hist[2048];
-  __shared__ unsigned s_tmp[2], s_cnt, s_tie;
+  __shared__ unsigned s_tmp[2], s_wave[34], s_total;
   const int lvl = blockIdx.x, img = blockIdx.y;
   const int P = p.h[lvl] * p.w[lvl];
   const int base = p.mstart[lvl] + img * P;
@@ -99,23 +151,12 @@ __global__ __launch_bounds__(1024) void det_select_kernel(const DetK p) {
   }
   unsigned prefix, need;
   radix_select_block(p.keys + base, P, k, hist, s_tmp, prefix, need);
-  if (threadIdx.x == 0) {
-    s_cnt = 0;
-    s_tie = 0;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    const float f = p.keys[base + i];
-    const unsigned u = f > 0.f ? __float_as_uint(f) : 0u;
-    if (u > prefix) {
-      sel[atomicAdd(&s_cnt, 1u)] = i;
-    } else if (u == prefix) {
-      const unsigned t = atomicAdd(&s_tie, 1u);
-      if (t < need) sel[atomicAdd(&s_cnt, 1u)] = i;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) *cnt = (int)s_cnt;
+  const float* keys = p.keys + base;
+  auto bits = [&](int i) { const float f = keys[i]; return f > 0.f ? __float_as_uint(f) : 0u; };
+  ordered_compact(
+      P, need, s_wave, [&](int i) { return bits(i) > prefix; }, [&](int i) { return bits(i) == prefix; },
+      [&](int i, unsigned slot) { sel[slot] = i; }, &s_total);
+  if (threadIdx.x == 0) *cnt = (int)s_total;
 }
 
 // dense final scores of every (selected location, class) pair: score*centerness if score > score_thr
@@ -137,36 +178,28 @@ __global__ void det_pairscore_kernel(const DetK p) {
   p.pairscore[((long long)img * p.nlvl + lvl) * p.nms_pre * p.num_classes + t] = out;
 }
 
-// one block per image: keep the CAND_CAP best pairs (all of them when fewer are valid), decode their boxes
+// one block per image: keep the CAND_CAP best pairs (all of them when fewer are valid), decode their boxes; candidate
+// slots are assigned in (level, slot, class) index order (ordered_compact), so the score-tie order of the NMS below -
+// and with it the whole result - is reproducible
 __global__ __launch_bounds__(1024) void det_compact_kernel(const DetK p) {
   __shared__ unsigned hist[2048];
-  __shared__ unsigned s_tmp[2], s_cnt, s_tie, s_valid;
+  __shared__ unsigned s_tmp[2], s_valid, s_wave[34], s_total;
   const int img = blockIdx.x;
   const int per_img = p.nlvl * p.nms_pre * p.num_classes;
   const float* ps = p.pairscore + (long long)img * per_img;
-  if (threadIdx.x == 0) {
-    s_valid = 0;
-    s_cnt = 0;
-    s_tie = 0;
-  }
+  if (threadIdx.x == 0) s_valid = 0;
   __syncthreads();
   unsigned local = 0;
   for (int i = threadIdx.x; i < per_img; i += blockDim.x) local += ps[i] > 0.f ? 1u : 0u;
-  atomicAdd(&s_valid, local);
+  atomicAdd(&s_valid, local);          // integer count: order-independent
   __syncthreads();
   const unsigned nvalid = s_valid;
   unsigned prefix = 0, need = 0;
   const bool all = nvalid <= (unsigned)CAND_CAP;
   if (!all) radix_select_block(ps, per_img, CAND_CAP, hist, s_tmp, prefix, need);
-  for (int i = threadIdx.x; i < per_img; i += blockDim.x) {
+  auto emit = [&](int i, unsigned out) {
+    if (out >= (unsigned)CAND_CAP) return;
     const float f = ps[i];
-    if (!(f > 0.f)) continue;
-    const unsigned u = __float_as_uint(f);
-    bool take = all || u > prefix;
-    if (!take && u == prefix) take = atomicAdd(&s_tie, 1u) < need;
-    if (!take) continue;
-    const int out = (int)atomicAdd(&s_cnt, 1u);
-    if (out >= CAND_CAP) continue;
     const int c = i % p.num_classes;
     const int slot = (i / p.num_classes) % p.nms_pre;
     const int lvl = i / (p.num_classes * p.nms_pre);
@@ -195,9 +228,12 @@ __global__ __launch_bounds__(1024) void det_compact_kernel(const DetK p) {
     cb[0] = b[0]; cb[1] = b[1]; cb[2] = b[2]; cb[3] = b[3];
     p.cscore[(long long)img * CAND_CAP + out] = f;
     p.clabel[(long long)img * CAND_CAP + out] = c;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) p.ccount[img] = min((int)s_cnt, CAND_CAP);
+  };
+  ordered_compact(
+      per_img, all ? 0u : need, s_wave,
+      [&](int i) { const float f = ps[i]; return f > 0.f && (all || __float_as_uint(f) > prefix); },
+      [&](int i) { const float f = ps[i]; return !all && f > 0.f && __float_as_uint(f) == prefix; }, emit, &s_total);
+  if (threadIdx.x == 0) p.ccount[img] = min((int)s_total, CAND_CAP);
 }
 
 __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr) {
@@ -284,6 +320,85 @@ __global__ __launch_bounds__(NMS_THREADS) void det_nms_kernel(const DetK p) {
   if (threadIdx.x == 0) p.det_count[img] = s_nkept;
 }
 
+// ---- pseudo-label fuse step of the refresh (unlabel_pred_hook.py:84-171 with fuse_history=False) ------------------
+// One block per image over its <= max_per_img detections: keep score >= parse_thr, truncate the coordinates toward
+// zero (int(), parse_det_results :27), round the score to 6 decimals (:35), then per class (ascending, classes
+// 0 .. num_classes-1) mmcv.ops.nms(boxes, scores, iou_threshold, score_threshold): candidates with score > nms_thr in
+// descending score order (ties: earlier detection first), greedy, suppress IoU > iou_thr (offset 0).
+struct FuseK {
+  int n, maxk, num_classes;
+  float parse_thr, iou_thr, nms_thr;
+  const float* dets; const long long* labels; const int* count;
+  float* out_boxes; float* out_scores; long long* out_labels; int* out_count;
+};
+
+constexpr int FUSE_T = 256, FUSE_MAX = 1024;
+__global__ __launch_bounds__(FUSE_T) void pseudo_fuse_kernel(const FuseK p) {
+  __shared__ float bx[FUSE_MAX][4];
+  __shared__ float sc[FUSE_MAX];
+  __shared__ int lb[FUSE_MAX];          // -1: dropped
+  __shared__ int order[FUSE_MAX];       // candidate index at each rank of (label asc, score desc, index asc)
+  __shared__ int kept[FUSE_MAX];
+  __shared__ int s_nk, s_flag, s_ncand, s_cls0;
+  const int img = blockIdx.x;
+  const int k = min(p.count[img], min(p.maxk, FUSE_MAX));
+  for (int i = threadIdx.x; i < k; i += FUSE_T) {
+    const float* d = p.dets + ((long long)img * p.maxk + i) * 5;
+    const float s = d[4];
+    const int l = (int)p.labels[(long long)img * p.maxk + i];
+    const float rs = (float)(nearbyint((double)s * 1e6) / 1e6);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bx[i][e] = (float)(int)d[e];
+    sc[i] = rs;
+    lb[i] = (s >= p.parse_thr && l >= 0 && l < p.num_classes && rs > p.nms_thr) ? l : -1;
+  }
+  if (threadIdx.x == 0) {
+    s_nk = 0;
+    s_ncand = 0;
+  }
+  __syncthreads();
+  // rank by counting (k <= 1024): dropped entries go last
+  for (int i = threadIdx.x; i < k; i += FUSE_T) {
+    int r = 0;
+    const int li = lb[i] < 0 ? 0x7fffffff : lb[i];
+    for (int j = 0; j < k; ++j) {
+      const int lj = lb[j] < 0 ? 0x7fffffff : lb[j];
+      const bool before = lj < li || (lj == li && (sc[j] > sc[i] || (sc[j] == sc[i] && j < i)));
+      r += before ? 1 : 0;
+    }
+    order[r] = i;
+    if (lb[i] >= 0) atomicAdd(&s_ncand, 1);
+  }
+  __syncthreads();
+  const int nc = s_ncand;
+  for (int r = 0; r < nc; ++r) {
+    const int ci = order[r];
+    const int nk = s_nk;
+    if (threadIdx.x == 0) {
+      s_flag = 0;
+      if (r == 0 || lb[order[r - 1]] != lb[ci]) s_cls0 = nk;      // first kept slot of this class
+    }
+    __syncthreads();
+    for (int t = s_cls0 + threadIdx.x; t < nk; t += FUSE_T)
+      if (iou_gt(bx[kept[t]], bx[ci], p.iou_thr)) s_flag = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && !s_flag) {
+      kept[nk] = ci;
+      s_nk = nk + 1;
+    }
+    __syncthreads();
+  }
+  const int nk = s_nk;
+  for (int t = threadIdx.x; t < nk; t += FUSE_T) {
+    const int ci = kept[t];
+    float* ob = p.out_boxes + ((long long)img * p.maxk + t) * 4;
+    ob[0] = bx[ci][0]; ob[1] = bx[ci][1]; ob[2] = bx[ci][2]; ob[3] = bx[ci][3];
+    p.out_scores[(long long)img * p.maxk + t] = sc[ci];
+    p.out_labels[(long long)img * p.maxk + t] = lb[ci];
+  }
+  if (threadIdx.x == 0) p.out_count[img] = nk;
+}
+
 size_t ws_layout(const dsl_det_desc* d, size_t off[8]) {
   long long M = 0;
   for (int l = 0; l < d->nlvl; ++l) M += (long long)d->n * d->h[l] * d->w[l];
@@ -353,5 +468,20 @@ extern "C" int dsl_fcos_detect(const dsl_det_desc* d, void* stream) {
   }
   hipLaunchKernelGGL(det_nms_kernel, dim3(d->n), dim3(NMS_THREADS), lds, st, k);
   DSL_LAUNCH_CHECK("dsl_fcos_detect");
+  return 0;
+}
+
+extern "C" int dsl_pseudo_label_fuse(const float* dets, const int64_t* labels, const int32_t* count, int n, int max_per_img,
+                                     int num_classes, float parse_thr, float iou_thr, float nms_thr, float* out_boxes,
+                                     float* out_scores, int64_t* out_labels, int32_t* out_count, void* stream) {
+  DSL_CHECK(dets && labels && count && out_boxes && out_scores && out_labels && out_count, "dsl_pseudo_label_fuse: null pointer");
+  DSL_CHECK(n >= 1 && max_per_img >= 1 && max_per_img <= FUSE_MAX, "dsl_pseudo_label_fuse: max_per_img must be in 1..%d", FUSE_MAX);
+  FuseK k;
+  k.n = n; k.maxk = max_per_img; k.num_classes = num_classes;
+  k.parse_thr = parse_thr; k.iou_thr = iou_thr; k.nms_thr = nms_thr;
+  k.dets = dets; k.labels = (const long long*)labels; k.count = count;
+  k.out_boxes = out_boxes; k.out_scores = out_scores; k.out_labels = (long long*)out_labels; k.out_count = out_count;
+  hipLaunchKernelGGL(pseudo_fuse_kernel, dim3(n), dim3(FUSE_T), 0, (hipStream_t)stream, k);
+  DSL_LAUNCH_CHECK("pseudo_fuse_kernel");
   return 0;
 }

@@ -22,6 +22,63 @@ from .params import ParamStore
 from .registry import BACKBONES, DETECTORS, HEADS, LOSSES, NECKS, build_backbone, build_head, build_loss, build_neck
 
 
+# mmcv's model-zoo aliases used by configs/fcos_semi (mmcv/model_zoo/open_mmlab.json, mmcv 1.3.10): the file a
+# torch.hub download would leave in the checkpoint cache
+_ZOO_FILES = {'open-mmlab://detectron2/resnet50_caffe': 'resnet50_msra-5891d200.pth'}
+
+
+def resolve_checkpoint(uri):
+    """Local file for a `checkpoint=` value: a path, or a model-zoo alias looked up in $DSL_PRETRAINED_DIR and the torch
+    hub cache (there is no network on the training boxes: the file has to be there already).  None when not found."""
+    import os
+    if os.path.exists(uri):
+        return uri
+    name = _ZOO_FILES.get(uri, os.path.basename(uri))
+    for d in (os.environ.get('DSL_PRETRAINED_DIR'), os.path.join(torch.hub.get_dir(), 'checkpoints'),
+              os.path.expanduser('~/.cache/torch/checkpoints')):
+        if d and os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return None
+
+
+def load_backbone_checkpoint(det, uri, strict=False):
+    """Backbone-only checkpoint (keys un-prefixed: conv1.weight, layer1.0.bn1.running_mean, ...; optional
+    'state_dict' wrapper and 'module.' / 'backbone.' prefixes as mmcv's load_checkpoint strips them) into the flat
+    store.  A checkpoint that cannot be found is NOT silently ignored: with a frozen stem / layer1 / BatchNorms the
+    model would train on random frozen features."""
+    import warnings
+    path = resolve_checkpoint(uri)
+    if path is None:
+        warnings.warn(f'dsl_amd: pretrained backbone checkpoint {uri!r} not found (looked in $DSL_PRETRAINED_DIR and the '
+                      'torch hub cache; no network here): the FROZEN stem/layer1/BatchNorm tensors keep their random '
+                      'reference-style initialisation', RuntimeWarning, stacklevel=2)
+        return False
+    ck = torch.load(path, map_location='cpu')
+    sd = ck.get('state_dict', ck.get('model', ck)) if isinstance(ck, dict) else ck
+    views = det.store.named_views()
+    out, unexpected = {}, []
+    for k, v in sd.items():
+        if not isinstance(v, torch.Tensor):
+            v = torch.as_tensor(v)
+        for pre in ('module.', 'backbone.'):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        kk = 'backbone.' + k
+        if kk in views and tuple(views[kk].shape) == tuple(v.shape):
+            out[kk] = v
+        else:
+            unexpected.append(k)
+    missing = [k for k in views if k.startswith('backbone.') and k not in out and not k.endswith('num_batches_tracked')]
+    if strict and (missing or unexpected):
+        raise KeyError(f'backbone checkpoint mismatch: missing {missing[:5]}, unexpected {unexpected[:5]}')
+    if not out:
+        raise KeyError(f'{path}: no key of this checkpoint matches the backbone (first keys: {list(sd)[:5]})')
+    full = {k: v for k, v in views.items()}
+    full.update(out)
+    det.store.load_named(full, strict=False)
+    return True
+
+
 def _expect(cond, msg):
     if not cond:
         raise NotImplementedError('dsl_amd hot path: ' + msg)
@@ -39,6 +96,9 @@ class ResNet(nn.Module):
                 'frozen_stages=1, norm_eval=True, BN requires_grad=False (configs/fcos_semi/r50_caffe_*.py:4-15)')
         _expect(not kw.get('dcn') and not kw.get('plugins') and not kw.get('with_cp', False), 'no DCN/plugins/checkpointing')
         self.init_cfg = init_cfg
+        self.pretrained_checkpoint = pretrained
+        if isinstance(init_cfg, dict) and init_cfg.get('type') == 'Pretrained':
+            self.pretrained_checkpoint = init_cfg['checkpoint']
 
 
 @BACKBONES.register_module()
@@ -184,7 +244,13 @@ class FCOS(nn.Module):
 
     # ---- nn.Module surface redirected to the flat store ------------------------------------------
     def init_weights(self):
+        """tools/train.py:162,171 calls this on student and teacher: reference-style random init, then the backbone's
+        `init_cfg=dict(type='Pretrained', checkpoint=...)` / `pretrained=` checkpoint (mmcv BaseModule.init_weights ->
+        load_checkpoint(strict=False) on the backbone, resnet.py:372-382 / resnet_rla.py:369-377)."""
         self.store.init_reference_style(0)
+        ck = getattr(self.backbone, 'pretrained_checkpoint', None)
+        if ck:
+            load_backbone_checkpoint(self, ck)
 
     def _apply(self, fn, recurse=True):
         probe = fn(torch.zeros(1, device=self.store.device))

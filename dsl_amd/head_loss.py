@@ -41,11 +41,14 @@ class FcosLossPlan:
         self.gt_off = torch.zeros(n + 1, dtype=torch.int32, device=dev)
         self.ig_boxes = torch.zeros(max_gt, 4, dtype=torch.float32, device=dev)
         self.ig_off = torch.zeros(n + 1, dtype=torch.int32, device=dev)
-        # pinned staging: pageable H2D copies would block the host until the stream drains (one stall per step)
+        # pinned staging: pageable H2D copies would block the host until the stream drains (one stall per step).
+        # A ring of slots, each guarded by an event recorded behind its async copies: the host may run several steps
+        # ahead of the GPU (lazy_log, no per-step sync) and must not rewrite a slot whose copy has not executed yet.
         pin = torch.cuda.is_available()
-        self._h_boxes = torch.zeros(2, max_gt, 4, dtype=torch.float32, pin_memory=pin)
-        self._h_labels = torch.zeros(max_gt, dtype=torch.int64, pin_memory=pin)
-        self._h_off = torch.zeros(2, n + 1, dtype=torch.int32, pin_memory=pin)
+        self._slots = [dict(boxes=torch.zeros(2, max_gt, 4, dtype=torch.float32, pin_memory=pin),
+                            labels=torch.zeros(max_gt, dtype=torch.int64, pin_memory=pin),
+                            off=torch.zeros(2, n + 1, dtype=torch.int32, pin_memory=pin), ev=None) for _ in range(4)]
+        self._slot_i = 0
         self.desc = ops.fcos_desc(n=n, sizes=self.sizes, strides=strides, ranges=ranges, radius=radius,
                                   num_classes=num_classes)
         ops.set_ptrs(self.desc, gt_boxes=self.gt_boxes, gt_labels=self.gt_labels, gt_off=self.gt_off,
@@ -59,35 +62,50 @@ class FcosLossPlan:
     # -- ground truth upload (host lists -> one pinned staging copy) --------------------------------
     def set_targets(self, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
         assert len(gt_bboxes) == self.n == len(gt_labels)
+        slot = self._slots[self._slot_i]
+        self._slot_i = (self._slot_i + 1) % len(self._slots)
+        if slot['ev'] is not None:
+            slot['ev'].synchronize()          # the copies issued from this slot len(_slots) steps ago have executed
 
-        def stage(boxes, slot, labels=None):
-            tot = 0
-            self._h_off[slot, 0] = 0
-            for i, b in enumerate(boxes):
-                k = int(b.shape[0])
-                assert tot + k <= self.max_gt, f'more than {self.max_gt} boxes in one batch'
-                if k:
-                    self._h_boxes[slot, tot:tot + k].copy_(b.reshape(-1, 4))
-                    if labels is not None:
-                        self._h_labels[tot:tot + k].copy_(labels[i].reshape(-1))
-                tot += k
-                self._h_off[slot, i + 1] = tot
+        def stage(boxes, which, dev_boxes, labels=None):
+            """Offsets go through the pinned slot (shapes are host data); box/label payloads that already live on the
+            GPU are concatenated there (no D2H round trip), host payloads go through the slot."""
+            off, counts = slot['off'], [int(b.shape[0]) for b in boxes]
+            tot = sum(counts)
+            assert tot <= self.max_gt, f'more than {self.max_gt} boxes in one batch'
+            off[which, 0] = 0
+            for i, k in enumerate(counts):
+                off[which, i + 1] = off[which, i] + k
+            on_dev = tot > 0 and all(b.is_cuda for b, k in zip(boxes, counts) if k)
+            if tot and on_dev:
+                dev_boxes[:tot].copy_(torch.cat([b.reshape(-1, 4) for b, k in zip(boxes, counts) if k]).float())
+                if labels is not None:
+                    self.gt_labels[:tot].copy_(torch.cat([l.reshape(-1) for l, k in zip(labels, counts) if k]).long())
+            elif tot:
+                pos = 0
+                for i, (b, k) in enumerate(zip(boxes, counts)):
+                    if k:
+                        slot['boxes'][which, pos:pos + k].copy_(b.reshape(-1, 4))
+                        if labels is not None:
+                            slot['labels'][pos:pos + k].copy_(labels[i].reshape(-1))
+                    pos += k
+                dev_boxes[:tot].copy_(slot['boxes'][which, :tot], non_blocking=True)
+                if labels is not None:
+                    self.gt_labels[:tot].copy_(slot['labels'][:tot], non_blocking=True)
             return tot
 
-        tot = stage(gt_bboxes, 0, gt_labels)
-        if tot:
-            self.gt_boxes[:tot].copy_(self._h_boxes[0, :tot], non_blocking=True)
-            self.gt_labels[:tot].copy_(self._h_labels[:tot], non_blocking=True)
-        self.gt_off.copy_(self._h_off[0], non_blocking=True)
+        stage(gt_bboxes, 0, self.gt_boxes, gt_labels)
+        self.gt_off.copy_(slot['off'][0], non_blocking=True)
         if gt_bboxes_ignore is not None:
             assert len(gt_bboxes_ignore) == self.n
-            tot = stage(gt_bboxes_ignore, 1)
-            if tot:
-                self.ig_boxes[:tot].copy_(self._h_boxes[1, :tot], non_blocking=True)
-            self.ig_off.copy_(self._h_off[1], non_blocking=True)
+            stage(gt_bboxes_ignore, 1, self.ig_boxes)
+            self.ig_off.copy_(slot['off'][1], non_blocking=True)
             ops.set_ptrs(self.desc, ig_boxes=self.ig_boxes, ig_off=self.ig_off)
         else:
             ops.set_ptrs(self.desc, ig_boxes=None, ig_off=None)
+        if self.gt_off.is_cuda:
+            slot['ev'] = torch.cuda.Event()
+            slot['ev'].record()
 
     def configure(self, loss_weight=1.0, soft_weight=0.0, grad_scale=1.0, inv_world=1.0):
         d = self.desc

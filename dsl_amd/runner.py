@@ -252,106 +252,183 @@ class DistSamplerSeedHook_semi(Hook):
 # ------------------------------------------------------------------------------------------------
 # pseudo labels
 # ------------------------------------------------------------------------------------------------
-def adaptive_thresholds(scores_by_class, prev_thres=None, ranges=(0.3, 0.35), gamma1=0.05, gamma2=0.6, base=0.3):
-    """unlabel_pred_hook.py:295-367: from the per-class lists of pseudo-label scores, count / accumulate those
-    above the previous class threshold (0.3 the first time), then
-      thres_c  = clip((cum_c / (avg / n_cls)) ** gamma1 * base, ranges)
-      weight_c = (avg / n_cls / cum_c) ** gamma2."""
-    dis, cum = {}, {}
-    for c, sc in scores_by_class.items():
-        sc = np.asarray(sc, dtype=np.float64)
-        thr = 0.3 if prev_thres is None else prev_thres.get(c)
-        sel = sc if thr is None else sc[sc >= thr]
-        if len(sel):
-            dis[c], cum[c] = len(sel), float(sel.sum())
-    if not dis:
-        return {}, {}
-    avg = sum(dis.values())
-    weights = {c: (avg / len(dis) / cum[c]) ** gamma2 for c in dis}
-    thres = {c: max(min((cum[c] / (avg / len(dis))) ** gamma1 * base, ranges[1]), ranges[0]) for c in dis}
-    return thres, weights
-
-
-def split_pseudo_labels(boxes, labels, scores, thres_by_class, default_thres=(0.1, 0.3), img_wh=None):
-    """datasets/semicoco.py:184-291: score in [default_lo, thr_c) -> gt_bboxes_ignore, otherwise -> gt box; classes
-    without a threshold of their own use the dataset's default band [0.1, 0.3) (semicoco.py:56, semivoc.py:43)."""
-    gt, gl, ig = [], [], []
-    for b, l, s in zip(boxes, labels, scores):
-        x1, y1, x2, y2 = (float(v) for v in b)
-        if img_wh is not None:
-            if max(0, min(x2, img_wh[0]) - max(x1, 0)) * max(0, min(y2, img_wh[1]) - max(y1, 0)) == 0:
-                continue
-        if x2 - x1 < 1 or y2 - y1 < 1:
-            continue
-        hi = thres_by_class.get(int(l), default_thres[1])
-        if default_thres[0] <= s < hi:
-            ig.append([x1, y1, x2, y2])
-        else:
-            gt.append([x1, y1, x2, y2])
-            gl.append(int(l))
-    f = lambda a: torch.tensor(a, dtype=torch.float32).reshape(-1, 4)
-    return f(gt), torch.tensor(gl, dtype=torch.int64), f(ig)
-
-
-def parse_det_results(dets, labels, score_thr):
-    """unlabel_pred_hook.py:20-38 + the score sort of gen_save_json_dict (:40-57): keep detections with
-    score >= score_thr, integer-truncate the coordinates (int()), round the score to 6 decimals, highest score first.
-    dets [k, 5] (x1, y1, x2, y2, score), labels [k]."""
-    dets, labels = np.asarray(dets), np.asarray(labels)
-    keep = dets[:, 4] >= score_thr
-    b, l = dets[keep], labels[keep]
-    scores = np.array([round(float(v), 6) for v in b[:, 4]], dtype=np.float64)
-    order = np.argsort(-scores, kind='stable')
-    return dict(rects=np.trunc(b[order, :4]).astype(np.int64), tags=l[order].astype(np.int64), scores=scores[order])
+from .pseudo import (PseudoLabelBank, adaptive_thresholds, fuse_host, parse_det_results,  # noqa: E402,F401
+                     split_pseudo_labels)
 
 
 @HOOKS.register_module()
 class UnlabelPredHook(Hook):
-    """On-GPU pseudo-label refresh.  Each call runs the (EMA) teacher on the given unlabeled images with the
-    HIP sweep, keeps detections with score >= infer_score_thre with integer-truncated coordinates
-    (parse_det_results :20-38) in an in-memory bank keyed by image name, and optionally exports the
-    reference's per-image JSON {imageName,targetNum,rects,tags,masks,scores}."""
+    """On-GPU, self-scheduling pseudo-label refresh (unlabel_pred_hook.py:370-562).
 
-    def __init__(self, infer_score_thre=0.1, use_ema=True, start_point=8, export_dir=None, class_names=None,
-                 eval_checkpoint_config=None, **kw):
-        self.score_thr, self.use_ema, self.start_point = infer_score_thre, use_ema, start_point
-        self.export_dir, self.class_names = export_dir, class_names
-        self.bank = {}
-        self.thres, self.class_weights = None, None
-        self.cfg = kw
+    Constructed as the reference does it (apis/train.py:193-196): `UnlabelPredHook(cfg.data.unlabel_pred, cfg, 'Det',
+    interval_mode=..., interval=...)`; the dict's keys may also be given as keyword arguments.  Keys read:
+    infer_score_thre, first_score_thre, use_ema, start_point, preload, fuse_history / first_fuse, eval_config['iou'],
+    category_info_path (dict or file with id2cat / cat2id), ada_thres_weight_settings, anno_root_path (only with
+    export=True: the reference's JSON files are then written there as well).
 
-    def refresh(self, runner, imgs, img_metas, names):
-        from .sweep import detect_device
-        det = runner._det(runner.model)
-        teacher = runner._det(runner.ema_model) if (self.use_ema and runner.ema_flag) else det
-        dets, labels, count = detect_device(det, imgs, img_metas, rescale=True, store=teacher.store)
-        dets, labels, count = dets.cpu().numpy(), labels.cpu().numpy(), count.cpu().numpy()
-        for i, name in enumerate(names):
-            k = int(count[i])
-            self.bank[name] = parse_det_results(dets[i, :k], labels[i, :k], self.score_thr)
-            if self.export_dir:
-                self._export(name)
-        return self.bank
+    Schedule (mirrors :446-469): in iteration mode the hook wakes up once `runner.iter + 1 >= start_point *
+    iters_per_epoch + 1` and `(runner.iter + 1 - start_point) % interval == 0`; the first time it sweeps EVERY
+    unlabeled image (sharded over the ranks, :281), afterwards it refreshes the unlabeled image(s) this rank will
+    consume `lookahead` iterations after the next one - the loader says which (`loader.unlabeled.upcoming`), where the
+    reference guesses it from the sampler order and the DataLoader prefetch depth (`preload`).  Epoch mode sweeps
+    everything every `interval` epochs from `start_point` on.  At every epoch end the class thresholds / weights are
+    recomputed (adathres, :295-367,448).
 
-    def _export(self, name):
-        e = self.bank[name]
-        os.makedirs(self.export_dir, exist_ok=True)
-        tags = [self.class_names[t] if self.class_names else int(t) for t in e['tags']]
-        with open(os.path.join(self.export_dir, os.path.basename(name) + '.json'), 'w') as f:
-            json.dump(dict(imageName=name, targetNum=len(tags), rects=e['rects'].tolist(), tags=tags,
-                           masks=[[] for _ in tags], scores=e['scores'].tolist()), f)
+    One refresh = teacher forward on the image's test view -> dsl_fcos_detect (top-k, decode, class-aware NMS, top 100)
+    -> dsl_pseudo_label_fuse (score >= infer_score_thre, int() truncation, 6-decimal scores, second per-class NMS at
+    eval_config['iou'][0] with score_threshold 0.1, :20-57,150-166) -> PseudoLabelBank; nothing leaves the GPU until the
+    loader asks the bank for that image's annotations."""
 
-    def update_thresholds(self):
-        by_c = {}
-        for e in self.bank.values():
-            for t, s in zip(e['tags'], e['scores']):
-                by_c.setdefault(int(t), []).append(float(s))
-        self.thres, self.class_weights = adaptive_thresholds(by_c, self.thres)
-        return self.thres
+    def __init__(self, kwargs=None, config=None, task_type='Det', interval_mode=None, interval=None, bank=None,
+                 source=None, export=False, **kw):
+        k = dict(kwargs or {})
+        k.update(kw)
+        assert task_type == 'Det'
+        self.cfg, self.config = k, config
+        self.infer_score_thre = float(k.get('infer_score_thre', 0.1))
+        self.first_score_thre = k.get('first_score_thre', None)
+        if self.first_score_thre is None and config is not None:
+            self.first_score_thre = config.get('infer_score_thre', 0.1) if hasattr(config, 'get') else 0.1
+        self.use_ema = bool(k.get('use_ema', True))
+        self.start_point = int(k.get('start_point', 0))
+        self.fuse = bool(k.get('fuse_history', False))
+        if self.fuse:
+            raise NotImplementedError('fuse_history=True (NMS against the previous labels) is not built; configs/fcos_semi use False')
+        self.first_ignore = not k.get('first_fuse', True)
+        self.iou = float((k.get('eval_config') or {}).get('iou', [0.6])[0])
+        ec = k.get('eval_checkpoint_config') or {}
+        self.interval_mode = interval_mode or ec.get('mode', 'epoch')
+        self.interval = int(interval if interval is not None else ec.get('interval', 1))
+        self.preload_num = int(k.get('preload', 10))
+        cat = k.get('category_info_path')
+        if isinstance(cat, str):
+            cat = json.load(open(cat))
+        self.id2cat = dict(cat['id2cat']) if cat else None
+        # save_results2file loops `for i in range(0, len(id2cat) - 1)` (:152): every class id but the last entry of the
+        # category file (COCO files list the 80 classes + background)
+        self.num_classes = (len(self.id2cat) - 1) if self.id2cat else int(k.get('num_classes', 80))
+        names = [self.id2cat[str(i)] for i in range(self.num_classes)] if self.id2cat else k.get('class_names')
+        ada = None
+        if config is not None:
+            data = config.get('data', {}) if hasattr(config, 'get') else {}
+            ada = (data.get('unlabel_train') or {}).get('thres') if data else None
+        # adathres runs when the unlabeled dataset's `thres` is a (file) name (:427-435)
+        self.adathres_compute = bool(isinstance(ada, str) or k.get('adathres', False) or (config is None and (bank is None or bank.mode == 'ada')))
+        self.bank = bank if bank is not None else PseudoLabelBank(
+            num_classes=self.num_classes, class_names=names, thres=(ada if ada is not None else 'adathres.json'),
+            ada_settings=k.get('ada_thres_weight_settings'))
+        self.source = source
+        self.export_dir = k.get('anno_root_path') if export else k.get('export_dir')
+        self.iter_fuse_flag = False
+        self.n_refreshed = 0
+        self._buf = {}
 
-    def targets_for(self, name, img_wh=None):
-        e = self.bank[name]
-        return split_pseudo_labels(e['rects'], e['tags'], e['scores'], self.thres or {}, img_wh=img_wh)
+    # -- schedule (:439-469) ------------------------------------------------------------------------------
+    def every_n_epochs_with_startpoint(self, runner, n, start):
+        if runner.epoch + 1 < start:
+            return False
+        return (runner.epoch + 1 - start) % n == 0 if n > 0 else False
+
+    def every_n_iters_with_startpoint(self, runner, n, start):
+        if runner.iter + 1 < start:
+            return False
+        return (runner.iter + 1 - start) % n == 0 if n > 0 else False
+
+    def _source(self, runner):
+        src = self.source or getattr(getattr(runner, 'data_loader', None), 'unlabeled', None)
+        if src is None:
+            raise RuntimeError('UnlabelPredHook: the data loader exposes no `.unlabeled` source (dsl_amd/data.py)')
+        return src
 
     def after_train_epoch(self, runner):
-        self.update_thresholds()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.bank_all_gather()            # the ranks' per-iteration refreshes of the epoch (a shared directory in the reference)
+        if self.adathres_compute:
+            self.update_thresholds()
+        if self.interval_mode == 'epoch' and runner.epoch + 1 >= self.start_point:
+            if self.every_n_epochs_with_startpoint(runner, self.interval, self.start_point):
+                self.refresh_all(runner)
+
+    def after_train_iter(self, runner):
+        if self.interval_mode != 'iteration' or runner.iter + 1 < self.start_point * runner.iter_tol_epoch + 1:
+            return
+        if not self.every_n_iters_with_startpoint(runner, self.interval, self.start_point):
+            return
+        if not self.iter_fuse_flag:          # the first fuse is the same as the epoch manner (:461-463)
+            self.refresh_all(runner)
+            self.iter_fuse_flag = True
+            return
+        src = self._source(runner)
+        depth = getattr(src, 'prefetch_depth', None)
+        names = src.upcoming(self.preload_num if depth is None else depth)
+        if names:
+            self.refresh_names(runner, names)
+
+    # -- refresh ---------------------------------------------------------------------------------------
+    def _thr(self):
+        if self.first_score_thre is not None:     # the first sweep may use its own threshold (:487-492)
+            t, self.first_score_thre = float(self.first_score_thre), None
+            return t
+        return self.infer_score_thre
+
+    def refresh_all(self, runner):
+        import torch.distributed as dist
+        src = self._source(runner)
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+        thr = self._thr()
+        self.refresh_names(runner, src.names[rank::world], thr=thr)
+        if world > 1:
+            self.bank_all_gather()
+        if self.first_ignore:
+            self.first_ignore = False
+
+    def refresh_names(self, runner, names, thr=None):
+        src = self._source(runner)
+        thr = self._thr() if thr is None else thr
+        for name in names:
+            img, meta = src.test_view(name)
+            self.refresh(runner, img, [meta], [name], thr=thr)
+
+    def refresh(self, runner, imgs, img_metas, names, thr=None):
+        """Teacher sweep of `imgs` ([n,3,H,W], already normalised / padded) -> fused pseudo labels into the bank."""
+        from .sweep import detect_device
+        det = runner._det(runner.model)
+        teacher = runner._det(runner.ema_model) if (self.use_ema and runner.ema_flag and runner.ema_model is not None) else det
+        thr = self.infer_score_thre if thr is None else thr
+        dets, labels, count = detect_device(det, imgs, img_metas, rescale=True, store=teacher.store)
+        n, maxk = dets.shape[0], dets.shape[1]
+        # fresh output buffers per call: the bank reads them lazily (a ring would need the events below to bound reuse)
+        ob = torch.empty(n, maxk, 4, device=dets.device)
+        osc = torch.empty(n, maxk, device=dets.device)
+        ol = torch.empty(n, maxk, dtype=torch.int64, device=dets.device)
+        oc = torch.empty(n, dtype=torch.int32, device=dets.device)
+        L.check(L.lib.dsl_pseudo_label_fuse(L.ptr(dets), L.ptr(labels), L.ptr(count), n, maxk, self.num_classes, float(thr),
+                                            float(self.iou), 0.1, L.ptr(ob), L.ptr(osc), L.ptr(ol), L.ptr(oc), L.stream_ptr()),
+                'dsl_pseudo_label_fuse')
+        ev = torch.cuda.Event()
+        ev.record()
+        for i, name in enumerate(names):
+            self.bank.put_device(name, ob, osc, ol, oc, i, ev, stamp=runner.iter + 1)
+            if self.export_dir:
+                self.bank.export_json(name, self.export_dir)
+        self.n_refreshed += len(names)
+        return self.bank
+
+    def bank_all_gather(self):
+        """Every rank ends up with every rank's new records (the reference's ranks share them through the file system)."""
+        import torch.distributed as dist
+        mine = {n: self.bank[n] for n in self.bank.names()}
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, mine)
+        for d in out:
+            self.bank.merge(d)
+
+    def update_thresholds(self):
+        return self.bank.update_thresholds()
+
+    thres = property(lambda self: self.bank.thres)
+    class_weights = property(lambda self: self.bank.class_weights)
+
+    def targets_for(self, name, img_wh=None):
+        return self.bank.ann_info(name, img_wh=img_wh)

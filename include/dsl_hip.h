@@ -244,6 +244,15 @@ typedef struct dsl_det_desc {
 size_t dsl_detect_workspace_bytes(const dsl_det_desc* d);
 int dsl_fcos_detect(const dsl_det_desc* d, void* stream);
 
+/* The label-file step of the pseudo-label refresh (runner/hooks/unlabel_pred_hook.py:20-57,84-171 with
+ * fuse_history=False) on the detections of dsl_fcos_detect, per image: keep score >= parse_thr, int()-truncate the
+ * coordinates, round the score to 6 decimals, then per class 0..num_classes-1 mmcv.ops.nms(iou_thr, score_threshold =
+ * nms_thr) on the truncated boxes.  Outputs are ordered class-ascending, score-descending:
+ * out_boxes [n][max_per_img][4], out_scores [n][max_per_img], out_labels [n][max_per_img], out_count [n]. */
+int dsl_pseudo_label_fuse(const float* dets, const int64_t* labels, const int32_t* count, int n, int max_per_img,
+                          int num_classes, float parse_thr, float iou_thr, float nms_thr, float* out_boxes,
+                          float* out_scores, int64_t* out_labels, int32_t* out_count, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Op-list executor: run a prebuilt sequence of the ops above with one call (keeps the per-step
  * host cost of ~400 launches out of Python).

@@ -333,9 +333,83 @@ def gen_parse_dets():
     print('wrote parse_dets.json', [len(c['out']) for c in cases])
 
 
+def gen_fuse():
+    """The label-file step of the refresh, save_results2file (runner/hooks/unlabel_pred_hook.py:84-171, fuse=False), run
+    from its own source text on synthetic detector outputs; mmcv.ops.nms (not in the tree) is the documented mmcv 1.3.10
+    behaviour restated here: keep scores > score_threshold, sort descending, greedy, suppress IoU > iou_threshold."""
+    import ast
+    import json
+    import tempfile
+    path = os.path.join(R.REF, 'mmdet/runner/hooks/unlabel_pred_hook.py')
+    tree = ast.parse(open(path).read())
+    want = ('parse_det_results', 'gen_save_json_dict', 'create_dir', 'save_results2file')
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+
+    def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
+        valid = np.nonzero(scores > np.float32(score_threshold))[0]
+        b, sc = boxes[valid], scores[valid]
+        order = np.argsort(-sc, kind='stable')
+        keep = []
+        for i in order:
+            ok = True
+            for j in keep:
+                w = max(np.float32(0), min(b[i, 2], b[j, 2]) - max(b[i, 0], b[j, 0]))
+                h = max(np.float32(0), min(b[i, 3], b[j, 3]) - max(b[i, 1], b[j, 1]))
+                inter = np.float32(w * h)
+                union = np.float32((b[i, 2] - b[i, 0]) * (b[i, 3] - b[i, 1]) + (b[j, 2] - b[j, 0]) * (b[j, 3] - b[j, 1]) - inter)
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    if np.float32(inter / union) > np.float32(iou_threshold):
+                        ok = False
+                        break
+            if ok:
+                keep.append(i)
+        keep = np.array(keep, dtype=np.int64)
+        return np.concatenate([b[keep], sc[keep, None]], 1).reshape(-1, 5), valid[keep]
+
+    ns = dict(os=os, json=json, np=np, nms=nms)
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, 'exec'), ns)
+    C_ = 6
+    names = [f'cls{i}' for i in range(C_)] + ['background']
+    id2cat = {str(i): n for i, n in enumerate(names)}
+    cat2id = {n: i for i, n in enumerate(names)}
+    rng = np.random.RandomState(23)
+    cases = []
+    for case in range(5):
+        tmp = tempfile.mkdtemp()
+        root = os.path.join(tmp, 'images')
+        os.makedirs(root)
+        k = int(rng.randint(5, 60))
+        # clusters of overlapping boxes so that the second NMS has work to do; fractional coordinates, scores around
+        # both thresholds
+        ctr = rng.uniform(20, 300, (max(1, k // 4), 2))
+        which = rng.randint(0, len(ctr), k)
+        wh = rng.uniform(8, 90, (k, 2))
+        c = ctr[which] + rng.normal(0, 6, (k, 2))
+        boxes = np.concatenate([c - wh / 2, c + wh / 2], 1)
+        scores = np.sort(rng.uniform(0.03, 0.99, k))[::-1]
+        scores[rng.randint(0, k)] = 0.1           # exactly at infer_score_thre: kept by parse (>=), dropped by nms (>)
+        scores = np.sort(scores)[::-1]
+        dets = np.concatenate([boxes, scores[:, None]], 1).astype(np.float32)
+        labels = rng.randint(0, C_, k)
+        result = [dets[labels == i] for i in range(C_)]          # bbox2result (core/bbox/transforms.py:99-116)
+        json.dump(dict(imageName='a.jpg', targetNum=0, rects=[], tags=[], masks=[], scores=[]),
+                  open(os.path.join(tmp, 'a.jpg.json'), 'w'))
+        iou = [0.6, 0.5, 0.3, 0.6, 0.45][case]
+        ns['save_results2file'](result, os.path.join(root, 'a.jpg'), 400, 400, 'json', 'iteration_1.pth', 0.1, id2cat, cat2id,
+                                root, tmp, 'Det', anno_root_path=tmp, iou=iou, fuse=False, first_ignore=True)
+        out = json.load(open(os.path.join(tmp, 'a.jpg.json')))
+        cases.append(dict(dets=dets.tolist(), labels=labels.tolist(), iou=iou, rects=out['rects'],
+                          tags=[cat2id[t] for t in out['tags']], scores=out['scores'], targetNum=out['targetNum']))
+    json.dump(dict(infer_score_thre=0.1, nms_score_thr=0.1, id2cat=id2cat, cases=cases), open(os.path.join(HERE, 'fuse.json'), 'w'))
+    print('wrote fuse.json', [(len(c['dets']), c['targetNum']) for c in cases])
+
+
 if __name__ == '__main__':
     if sys.argv[1:] == ['parse_dets']:
         gen_parse_dets()
+        sys.exit(0)
+    if sys.argv[1:] == ['fuse']:
+        gen_fuse()
         sys.exit(0)
     if sys.argv[1:] == ['adathres']:
         gen_adathres()

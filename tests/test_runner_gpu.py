@@ -88,25 +88,124 @@ def test_semi_supervised_iterations(tmp_path):
     # bf16 forward pack of the teacher follows its master weights after EMA
     ts = teacher.store
     assert torch.equal(ts.train16.float(), ts.train.bfloat16().float())
-    # a15: teacher sweep -> pseudo-label bank -> thresholds -> (gt, ignore) split, JSON export in the reference's layout
-    hook = UnlabelPredHook(infer_score_thre=0.0, use_ema=True, export_dir=str(tmp_path))
+    # a15: teacher sweep -> fused pseudo labels in the bank, JSON export in the reference's layout
+    from dsl_amd.pseudo import fuse_host
+    from dsl_amd.sweep import detect_device
+    hook = UnlabelPredHook(infer_score_thre=0.0, use_ema=True, export_dir=str(tmp_path), adathres=True)
     names = ['im_a.jpg', 'im_b.jpg']
     bank = hook.refresh(runner, batches[1]['img'], batches[1]['img_metas'], names)
-    assert set(bank) == set(names)
-    for n in names:
+    assert set(bank.names()) == set(names)
+    dets, labels, count = detect_device(student, batches[1]['img'], batches[1]['img_metas'], rescale=True, store=teacher.store)
+    dets, labels, count = dets.cpu().numpy(), labels.cpu().numpy(), count.cpu().numpy()
+    for i, n in enumerate(names):
         e = bank[n]
-        assert e['rects'].dtype == np.int64 and e['rects'].shape[1] == 4 and len(e['tags']) == len(e['scores']) == len(e['rects'])
+        assert e['rects'].shape[1] == 4 and len(e['tags']) == len(e['scores']) == len(e['rects'])
+        # the fuse kernel == the host restatement (pinned to the reference's save_results2file) on the same detections
+        ref = fuse_host(dets[i, :count[i]], labels[i, :count[i]], 0.0, hook.iou, 0.1, num_classes=80)
+        assert e['rects'].tolist() == ref['rects'].tolist() and e['tags'].tolist() == ref['tags'].tolist()
+        assert np.array_equal(e['scores'].astype(np.float32), ref['scores'])
         j = json.load(open(os.path.join(str(tmp_path), n + '.json')))
         assert set(j) == {'imageName', 'targetNum', 'rects', 'tags', 'masks', 'scores'} and j['targetNum'] == len(e['tags'])
-    # the same detections as the oracle's get_bboxes on the teacher's weights
+    # the same detections as the oracle's get_bboxes on the teacher's weights (bf16 network vs fp32: loose; the exact
+    # comparison of the post-processing on identical logits is tests/test_sweep_gpu.py)
     tsd = {k: v.clone().cpu() for k, v in teacher.state_dict().items()}
     with torch.no_grad():
         cls, reg, ctr = O.extract_and_head(tsd, batches[1]['img'].cpu(), O.Quant(True), training=False)[:3]
     m = batches[1]['img_metas'][0]
-    dets = O.get_bboxes(cls, reg, ctr, [m['img_shape']] * 2, [[1.0, 1.0, 1.0, 1.0]] * 2)
+    odets = O.get_bboxes(cls, reg, ctr, [m['img_shape']] * 2, [[1.0, 1.0, 1.0, 1.0]] * 2)
     for i, n in enumerate(names):
-        n_ref = len(dets[i][0])
-        assert abs(n_ref - len(bank[n]['tags'])) <= max(2, n_ref // 10), (n_ref, len(bank[n]['tags']))
+        n_ref = len(odets[i][0])
+        assert abs(n_ref - int(count[i])) <= max(2, n_ref // 10), (n_ref, int(count[i]))
     hook.update_thresholds()
     gt, gl, ig = hook.targets_for(names[0], img_wh=(190, 128))
     assert gt.shape[1] == 4 and ig.shape[1] == 4 and len(gl) == len(gt)
+
+
+def test_fuse_kernel_vs_reference_golden():
+    """dsl_pseudo_label_fuse == the reference's save_results2file output (tests/golden/fuse.json), exactly."""
+    from dsl_amd import _lib as L
+    d = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'fuse.json')))
+    C_ = len(d['id2cat']) - 1
+    maxk = 100
+    for c in d['cases']:
+        k = len(c['dets'])
+        dets = torch.zeros(1, maxk, 5)
+        dets[0, :k] = torch.tensor(c['dets'])
+        labels = torch.zeros(1, maxk, dtype=torch.int64)
+        labels[0, :k] = torch.tensor(c['labels'])
+        dets, labels = dets.cuda(), labels.cuda()
+        count = torch.tensor([k], dtype=torch.int32, device='cuda')
+        ob, osc = torch.empty(1, maxk, 4, device='cuda'), torch.empty(1, maxk, device='cuda')
+        ol, oc = torch.empty(1, maxk, dtype=torch.int64, device='cuda'), torch.empty(1, dtype=torch.int32, device='cuda')
+        L.check(L.lib.dsl_pseudo_label_fuse(L.ptr(dets), L.ptr(labels), L.ptr(count), 1, maxk, C_, d['infer_score_thre'],
+                                            c['iou'], d['nms_score_thr'], L.ptr(ob), L.ptr(osc), L.ptr(ol), L.ptr(oc),
+                                            L.stream_ptr()))
+        torch.cuda.synchronize()
+        n = int(oc[0])
+        assert n == c['targetNum']
+        assert ob[0, :n].cpu().tolist() == c['rects'] and ol[0, :n].cpu().tolist() == c['tags']
+        assert osc[0, :n].cpu().numpy().tolist() == np.array(c['scores'], np.float32).tolist()
+
+
+def test_self_scheduled_refresh_feeds_the_next_batch():
+    """The loop of configs/fcos_semi/RLA_*.py end to end with nothing hand-wired per iteration: the hook wakes itself up
+    (iteration mode from start_point on), sweeps every unlabeled image the first time, then refreshes the image the loader
+    hands out next; the loader builds that image's gt / ignore boxes from the bank; thresholds follow at the epoch end."""
+    from dsl_amd.data import SyntheticSemiLoader
+    from dsl_amd.optim import FlatSGD
+    from dsl_amd.pseudo import PseudoLabelBank
+    from dsl_amd.runner import EMAOWNHook, OptimizerHook, SemiEpochBasedRunner, UnlabelPredHook
+    head = dict(loss_weight=3.0, soft_weight=1.0, soft_warm_up=0)
+    student, teacher = build(**head), build(**head)
+    for m in (student, teacher):                     # confident detections from the synthetic weights
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd['bbox_head.conv_cls.bias'].fill_(0.0)
+        m.load_state_dict(sd)
+    opt = FlatSGD(student, lr=0.001, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
+                  grad_clip=dict(max_norm=35, norm_type=2))
+    bank = PseudoLabelBank(num_classes=80, thres='adathres.json')
+    loader = SyntheticSemiLoader(bank, n_labeled=3, n_unlabeled=4, iters_per_epoch=4, H=128, W=192, W_img=190, img_std=30.0)
+    runner = SemiEpochBasedRunner(student, optimizer=opt, max_epochs=2, ema_model=teacher, scale_invariant=True)
+    runner.register_hook(OptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)), priority=30)
+    runner.register_hook(EMAOWNHook(interval=1, mode='iteration', ratio=0.99, start_point=1), priority=40)
+    hook = UnlabelPredHook(dict(infer_score_thre=0.1, first_score_thre=0.1, use_ema=True, start_point=1, preload=6,
+                                first_fuse=False, fuse_history=False, eval_config=dict(iou=[0.6]),
+                                eval_checkpoint_config=dict(interval=1, mode='iteration')),
+                           None, 'Det', interval_mode='iteration', interval=1, bank=bank)
+    runner.register_hook(hook, priority=50)
+    seen = []
+
+    class Spy:
+        priority = 20
+
+        def __getattr__(self, name):
+            return lambda r: None
+
+        def after_train_iter(self, r):      # runs before the refresh hook: what the batch of this iteration carried
+            seen.append((r.iter, len(bank), hook.n_refreshed))
+    runner.register_hook(Spy(), priority=20)
+    batches = []
+    orig_next = SyntheticSemiLoader.__next__
+
+    def spy_next(self):
+        b = orig_next(self)
+        batches.append((b['img_metas'][1]['filename'], b['gt_bboxes'][1].clone(), b['gt_bboxes_ignore'][1].clone()))
+        return b
+    SyntheticSemiLoader.__next__ = spy_next
+    try:
+        runner.run([loader], max_epochs=2)
+    finally:
+        SyntheticSemiLoader.__next__ = orig_next
+    torch.cuda.synchronize()
+    assert runner.iter == 8
+    # epoch 0: nothing refreshed, unlabeled images carry no boxes; first firing after iteration 4 (iter + 1 >= 1*4 + 1): all 4
+    assert all(n == 0 for _, _, n in seen[:5]) and seen[5][2] == 4 and len(bank) == 4
+    assert all(len(b[1]) == 0 and len(b[2]) == 0 for b in batches[:5])
+    # from then on one refresh per iteration (none after the last iteration of the epoch), and every batch's unlabeled
+    # image carries exactly the bank's current annotations
+    assert hook.n_refreshed == 4 + 2
+    assert bank.thres is not None                       # adathres ran at the epoch ends
+    later = batches[5:]
+    assert len(later) == 3 and sum(len(b[1]) + len(b[2]) for b in later) > 0
+    for name, gt, ig in later:
+        assert name in bank
