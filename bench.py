@@ -21,6 +21,7 @@ import torch.distributed as dist
 
 GFLOP_PER_IMAGE_STEP = 1185.8      # SURVEY.md §8d / BASELINE.md: fwd 419.55 + bwd 766.23 GFLOP per 800x1344 image
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0              # HBM3E spec (same guide; ~6.3 TB/s achievable)
 DOMINANT = 'conv_pipe_kernel<128, 128, 2, 4, 2>'    # the kernel class 0 of dsl_prof_* brackets (largest share of the step)
 
 
@@ -67,9 +68,10 @@ def synth_batch(rank, n_img=2, H=800, W=1344, device='cuda'):
     return dict(img=img.to(device), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
 
 
-def cpu_baseline(batch, seed=0):
+def cpu_baseline(batch, seed=0, warmup=1, steps=2):
     """The CPU restatement of the SAME step (oracle/fcos_oracle.py, fp32 torch on the host cores), timed on a
-    bounded sample: one full N=2 step at 800x1344 (forward + loss + autograd backward + SGD)."""
+    bounded sample: `warmup` untimed + `steps` timed full N=2 steps at 800x1344 (forward + loss + autograd backward +
+    SGD), same weights and batch every step."""
     from oracle import fcos_oracle as O
     from dsl_amd.params import ParamStore
     torch.manual_seed(seed)
@@ -77,14 +79,74 @@ def cpu_baseline(batch, seed=0):
     sd = {k: v.clone() for k, v in store.named_views().items()}
     img = batch['img'].cpu()
     cores = torch.get_num_threads()
-    t0 = time.perf_counter()
-    losses, grads, _ = O.train_step(sd, img, batch['gt_bboxes'], batch['gt_labels'], None)
     tk = O.trainable_keys(sd)
-    O.sgd_step({k: sd[k] for k in tk}, grads, {}, first_step=True)
-    dt = time.perf_counter() - t0
+    times, losses = [], None
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        losses, grads, _ = O.train_step(sd, img, batch['gt_bboxes'], batch['gt_labels'], None)
+        O.sgd_step({k: sd[k] for k in tk}, grads, {}, first_step=True)
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
     n = img.shape[0]
+    dt = sum(times) / len(times)
     return dict(value=n / dt, unit='imgs/s', cores=cores, kind='port',
-                sample=f'1 training step, {n} x (3,800,1344) fp32, torch CPU {cores} threads, {dt:.1f} s'), losses
+                sample=f'{steps} training steps after {warmup} warm-up, {n} x (3,800,1344) fp32, torch CPU {cores} threads, '
+                       + ', '.join(f'{t:.1f}' for t in times) + ' s'), losses
+
+
+def dsl_iteration_timing(steps=10, warm=4):
+    """BASELINE.json configs[2] beside the headline line: the semi-supervised iteration - labeled + unlabeled image and the
+    half-scale copy (N = 3 through the student), ignore boxes, loss_weight 3, sisoft, clip, SGD, EMA teacher update every
+    iteration - without and with the teacher's pseudo-label refresh of the upcoming unlabeled image (self-scheduled
+    UnlabelPredHook, iteration mode)."""
+    from dsl_amd.data import SyntheticSemiLoader
+    from dsl_amd.optim import FlatSGD
+    from dsl_amd.pseudo import PseudoLabelBank
+    from dsl_amd.registry import build_detector
+    from dsl_amd.runner import EMAOWNHook, OptimizerHook, SemiEpochBasedRunner, UnlabelPredHook
+    out = {}
+    for refresh in (False, True):
+        student, teacher = build_detector(model_cfg(dsl=True)).cuda(), build_detector(model_cfg(dsl=True)).cuda()
+        student.lazy_log = True
+        student.eager_backward = True
+        opt = FlatSGD(student, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
+                      grad_clip=dict(max_norm=35, norm_type=2))
+        bank = PseudoLabelBank(num_classes=80, thres='adathres.json')
+        n_it = warm + steps
+        loader = SyntheticSemiLoader(bank, n_labeled=4, n_unlabeled=4, iters_per_epoch=n_it, H=800, W=1344, W_img=1333)
+        runner = SemiEpochBasedRunner(student, optimizer=opt, max_epochs=1, ema_model=teacher, scale_invariant=True)
+        runner.register_hook(OptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)), priority=40)
+        runner.register_hook(EMAOWNHook(interval=1, mode='iteration', ratio=0.99, start_point=0), priority=45)
+        if refresh:
+            hook = UnlabelPredHook(dict(infer_score_thre=0.1, use_ema=True, start_point=0, eval_config=dict(iou=[0.6]),
+                                        eval_checkpoint_config=dict(interval=1, mode='iteration')), None, 'Det',
+                                   interval_mode='iteration', interval=1, bank=bank)
+            hook.iter_fuse_flag = True          # steady state: the initial full sweep is not part of an iteration's cost
+            runner.register_hook(hook, priority=50)
+        marks = {}
+
+        class Clock:
+            priority = 90
+
+            def __getattr__(self, name):
+                return lambda r: None
+
+            def after_train_iter(self, r):
+                if r.iter + 1 == warm:
+                    torch.cuda.synchronize()
+                    marks['t0'] = time.perf_counter()
+        runner.register_hook(Clock(), priority=90)
+        runner.run([loader], max_epochs=1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - marks['t0']) / steps
+        out['ms_per_iter_with_teacher_refresh' if refresh else 'ms_per_iter'] = round(dt * 1e3, 3)
+        del student, teacher, runner, opt, loader
+        torch.cuda.empty_cache()
+    out['imgs_per_iter'] = 2
+    out['note'] = ('N = 3 student step (labeled + unlabeled + half-scale copy, ignore boxes, loss_weight 3, sisoft, clip 35) + SGD + '
+                   'EMA teacher every iteration; refresh = teacher sweep + fuse of the next unlabeled image every iteration; '
+                   'images resident in HBM, the loader reads the refreshed labels back from the GPU before each batch')
+    return out
 
 
 def main():
@@ -94,6 +156,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--imgs-per-gpu', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-dsl', action='store_true', help='skip the extra.dsl_iteration timing (configs[2]) after the timed region')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket the conv kernels with HIP events')
     ap.add_argument('--prof-light', action='store_true', help='bracket only the dominant kernel class in the instrumented pass')
     args = ap.parse_args()
@@ -185,25 +248,39 @@ def main():
         launches = (C.c_int64 * NC)()
         ms = (C.c_double * NC)()
         fl = (C.c_double * NC)()
-        L.lib.dsl_prof_read(launches, ms, fl)
+        by = (C.c_double * NC)()
+        L.lib.dsl_prof_read2(launches, ms, fl, by)
 
         def cls(i):
             return dict(achieved=round(fl[i] / (ms[i] * 1e-3) / 1e12, 1) if launches[i] else None,
                         avg_launch_us=round(ms[i] * 1e3 / max(launches[i], 1), 2), launches_per_step=launches[i] // args.steps,
-                        ms_per_step=round(ms[i] / args.steps, 3))
+                        ms_per_step=round(ms[i] / args.steps, 3),
+                        algorithmic_mb_per_launch=round(by[i] / max(launches[i], 1) / 1e6, 2))
         if launches[0]:
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel=DOMINANT + ' (forward + data-gradient implicit GEMM, 8-wave 128x128 tile: the '
-                        'backbone / predictor convolutions; largest share of the step)',
-                        achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(ach / PEAK_BF16_TFLOPS, 4),
+            gbs = by[0] / (ms[0] * 1e-3) / 1e9
+            intensity = fl[0] / by[0]
+            # the roof that binds this class: below the ridge of 2500 TFLOP/s / 8 TB/s = 312 FLOP per algorithmic byte it is HBM
+            hbm = intensity < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            roof = dict(bound='hbm' if hbm else 'mfma', kernel=DOMINANT + ' (forward + data-gradient implicit GEMM, 8-wave 128x128 '
+                        'tile: the backbone / predictor convolutions; largest share of the step)',
+                        achieved=round(gbs if hbm else ach, 1), peak=PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS,
+                        unit='GB/s' if hbm else 'TFLOP/s', frac=round(gbs / PEAK_HBM_GBS if hbm else ach / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, traffic_source=traffic_src, measured='HIP event pairs on the launch stream, second pass '
                         'of the same %d steps (%.3f ms/step while instrumented)' % (args.steps, dt_prof / args.steps * 1e3),
                         launches_per_step=launches[0] // args.steps,
                         avg_launch_us=round(ms[0] * 1e3 / launches[0], 2),
                         algorithmic_gflop_per_launch=round(fl[0] / launches[0] / 1e9, 3),
+                        algorithmic_bytes_per_launch=round(by[0] / launches[0]),
+                        flop_per_algorithmic_byte=round(intensity, 1),
+                        mfma_tflops=round(ach, 1), mfma_frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                        hbm_gbs_algorithmic=round(gbs, 1), hbm_frac_algorithmic=round(gbs / PEAK_HBM_GBS, 4),
                         head_tile_256x192=cls(1), other_conv_kernels=cls(2), wgrad_kernels=cls(3),
                         whole_step_frac=round(value / world * GFLOP_PER_IMAGE_STEP / 1e3 / PEAK_BF16_TFLOPS, 4))
-    cpu = None
+    cpu = extra = None
+    if rank == 0 and world == 1 and not args.no_dsl:
+        del opt
+        extra = dict(dsl_iteration=dsl_iteration_timing())
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, _ = cpu_baseline(batch)
     if rank == 0:
@@ -215,7 +292,7 @@ def main():
                                    f'{args.imgs_per_gpu} x (3,800,1344) per GPU, synthetic COCO-shaped boxes, '
                                    'random-init weights', 'global_batch': args.imgs_per_gpu * world,
                        'parallelism': f'dp{world}', 'optimizer': 'SGD momentum 0.9 wd 1e-4'},
-            'roofline': roof, 'cpu_baseline': cpu, 'final_losses': log}))
+            'roofline': roof, 'cpu_baseline': cpu, 'extra': extra, 'final_losses': log}))
     if world > 1:
         dist.destroy_process_group()
 

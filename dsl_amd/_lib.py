@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
                 ('mode', C.c_int32), ('os', C.c_int32), ('flags', C.c_int32),
                 ('src', C.c_void_p), ('wgt', C.c_void_p), ('dst', C.c_void_p),
                 ('scale', C.c_void_p), ('bias', C.c_void_p), ('addend', C.c_void_p), ('mask', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('cs_real', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -117,7 +117,7 @@ _SIGS = {
     'dsl_pack_dgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_pack_dgrad_batched': [_vp, _i, _i, _vp],
     'dsl_detect_workspace_bytes': [_vp], 'dsl_fcos_detect': [_vp, _vp],
     'dsl_pseudo_label_fuse': [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
-    'dsl_run_ops': [_vp, _i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
+    'dsl_run_ops': [_vp, _i, _vp], 'dsl_stream_wait_slot': [_i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_prof_read2': [_vp, _vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
 }
 MISSING = []
 for _name, _args in _SIGS.items():

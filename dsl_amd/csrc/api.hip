@@ -120,9 +120,21 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
   return 0;
 }
 
+// Make `stream` wait for named event slot `slot` (recorded by a DSL_OP_RECORD of an earlier dsl_run_ops call): the
+// communication stream of the data-parallel wrapper waits for "the weight gradients of backward segment s are done"
+// without involving the caller's compute stream.  No-op (returns 1) when the slot was never recorded.
+extern "C" int dsl_stream_wait_slot(int slot, void* stream) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  DSL_CHECK(dev >= 0 && dev < 16 && slot >= 0 && slot < 16, "dsl_stream_wait_slot: bad device %d / slot %d", dev, slot);
+  if (!g_init[dev] || !g_named_set[dev][slot]) return 1;
+  DSL_CHECK(hipStreamWaitEvent((hipStream_t)stream, g_named[dev][slot], 0) == hipSuccess, "dsl_stream_wait_slot: hipStreamWaitEvent failed");
+  return 0;
+}
+
 // ---- live kernel timing ----------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
 constexpr int kMaxRec = 1 << 15;
 int g_prof_on = 0;       // 0 off, 1 = only class 0 (the dominant kernel), 2 = every class
 ProfRec* g_rec = nullptr;
@@ -131,7 +143,7 @@ int g_nrec = 0, g_nevents = 0;
 
 bool dsl_prof_active() { return g_prof_on != 0; }
 
-int dsl_prof_begin(int cls, double flops, hipStream_t st) {
+int dsl_prof_begin(int cls, double flops, hipStream_t st, double bytes) {
   if (!g_prof_on || g_nrec >= kMaxRec) return -1;
   if (g_prof_on == 1 && cls != 0) return -1;
   if (!g_rec) g_rec = (ProfRec*)calloc(kMaxRec, sizeof(ProfRec));
@@ -142,6 +154,7 @@ int dsl_prof_begin(int cls, double flops, hipStream_t st) {
   }
   g_rec[g_nrec].cls = cls;
   g_rec[g_nrec].flops = flops;
+  g_rec[g_nrec].bytes = bytes;
   hipEventRecord(g_rec[g_nrec].a, st);
   return g_nrec++;
 }
@@ -158,17 +171,21 @@ extern "C" int dsl_prof_reset(void) {
   g_nrec = 0;
   return 0;
 }
-extern "C" int dsl_prof_read(int64_t* launches, double* ms, double* flops) {
-  for (int c = 0; c < DSL_PROF_CLASSES; ++c) { launches[c] = 0; ms[c] = 0; flops[c] = 0; }
+extern "C" int dsl_prof_read2(int64_t* launches, double* ms, double* flops, double* bytes) {
+  for (int c = 0; c < DSL_PROF_CLASSES; ++c) { launches[c] = 0; ms[c] = 0; flops[c] = 0; if (bytes) bytes[c] = 0; }
   for (int i = 0; i < g_nrec; ++i) {
     hipEventSynchronize(g_rec[i].b);
     float t = 0.f;
     hipEventElapsedTime(&t, g_rec[i].a, g_rec[i].b);
     const int c = g_rec[i].cls;
-    if (c >= 0 && c < DSL_PROF_CLASSES) { launches[c]++; ms[c] += t; flops[c] += g_rec[i].flops; }
+    if (c >= 0 && c < DSL_PROF_CLASSES) {
+      launches[c]++; ms[c] += t; flops[c] += g_rec[i].flops;
+      if (bytes) bytes[c] += g_rec[i].bytes;
+    }
   }
   return 0;
 }
+extern "C" int dsl_prof_read(int64_t* launches, double* ms, double* flops) { return dsl_prof_read2(launches, ms, flops, nullptr); }
 
 // ---- probe: semantics of ds_read_b64_tr_b16 (used by tests/test_probe_gpu.py) -------------------
 __global__ void probe_tr16_kernel(const uint16_t* img, const int* lane_off, uint16_t* out) {

@@ -18,7 +18,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 void dsl_set_error(const char* fmt, ...);
 bool dsl_prof_active();
-int dsl_prof_begin(int cls, double flops, hipStream_t st);
+int dsl_prof_begin(int cls, double flops, hipStream_t st, double bytes = 0.0);
 void dsl_prof_end(int id, hipStream_t st);
 #define DSL_CHECK(cond, ...)          \
   do {                                \

@@ -1552,6 +1552,27 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
   *splits_out = splits;
 }
 
+// algorithmic work of one launch: real channels (3 for the NHWC8 image, cs_real for padded gradient rows), every tensor
+// read / written once
+double conv_real_cin(const dsl_conv_desc* d) {
+  return (d->flags & DSL_CONV_SMALL_C) ? 3.0 : (double)(d->cs_real > 0 ? d->cs_real : d->cs);
+}
+double conv_algo_flops(const dsl_conv_desc* d, long long px) {
+  return 2.0 * px * (double)d->cd * d->kh * d->kw * conv_real_cin(d);
+}
+double conv_algo_bytes(const dsl_conv_desc* d, long long px) {
+  double src_px = 0, dst_px = 0;
+  for (int s = 0; s < d->nseg; ++s) {
+    src_px += (double)d->n * d->sh[s] * d->sw[s];
+    dst_px += (double)d->n * d->dh[s] * d->dw[s];
+  }
+  double b = src_px * conv_real_cin(d) * 2.0 + (double)d->cd * d->kh * d->kw * conv_real_cin(d) * 2.0 +
+             dst_px * d->cd * ((d->flags & DSL_CONV_OUT_F32) ? 4.0 : 2.0);
+  if (d->addend) b += dst_px * d->cd * 2.0;
+  if (d->mask) b += dst_px * d->cd * 2.0;
+  return b;
+}
+
 long long conv_pixels(const dsl_conv_desc* d) {
   long long px = 0;
   for (int s = 0; s < d->nseg; ++s) px += (long long)d->n * d->gh[s] * d->gw[s];
@@ -1652,7 +1673,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
       if (stg > lds) lds = stg;
     }
     int prof = -1;
-    if (dsl_prof_active()) prof = dsl_prof_begin(pick == 3 ? 0 : (pick == 0 ? 1 : 2), 2.0 * px * (double)d->cd * d->kh * d->kw * (smallc ? 3.0 : (double)d->cs), st);
+    if (dsl_prof_active()) prof = dsl_prof_begin(pick == 3 ? 0 : (pick == 0 ? 1 : 2), conv_algo_flops(d, px), st, conv_algo_bytes(d, px));
 #define LAUNCH2(A, B, C_, D, S_)                                                                               \
   do {                                                                                                        \
     static bool attr_set = false;                                                                             \
@@ -1727,10 +1748,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     hipLaunchKernelGGL((conv_gemm_kernel<BCO_, SC_>), grid, dim3(256), lds, st, k);               \
   } while (0)
   int prof = -1;
-  if (dsl_prof_active()) {
-    const double cin_real = smallc ? 3.0 : (double)d->cs;
-    prof = dsl_prof_begin(2, 2.0 * px * (double)d->cd * d->kh * d->kw * cin_real, st);
-  }
+  if (dsl_prof_active()) prof = dsl_prof_begin(2, conv_algo_flops(d, px), st, conv_algo_bytes(d, px));
   if (bco == 128) {
     if (smallc) LAUNCH(128, true); else LAUNCH(128, false);
   } else {
@@ -1883,7 +1901,11 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     k.xv[g] = (const uint16_t*)descs[g < count ? g : 0].x;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int prof = dsl_prof_active() ? dsl_prof_begin(3, 2.0 * count * px * (double)d->cd * d->kh * d->kw * d->cs, st) : -1;
+  // weight gradient: dY and X read once, dW written once (fp32)
+  const int prof = dsl_prof_active()
+                       ? dsl_prof_begin(3, 2.0 * count * px * (double)d->cd * d->kh * d->kw * d->cs, st,
+                                        count * ((double)px * d->cd * 2.0 + (double)xo * d->cs * 2.0 + (double)d->cd * d->kh * d->kw * d->cs * 4.0))
+                       : -1;
   if (cfg >= 1) {
     const int bcis[5] = {128, 256, 128, 256, 128};
     const int bci = bcis[cfg];

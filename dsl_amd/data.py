@@ -47,15 +47,19 @@ class SyntheticUnlabeled:
         return [self.names[l._order(l._epoch)[pos % l.n_unlabeled]]]
 
     def image(self, name):
-        i = self.names.index(name)
-        g = torch.Generator().manual_seed(7919 * (i + 1) + self._l.seed)
-        return (torch.randn(3, self._l.H, self._l.W, generator=g) * self._l.img_std).bfloat16().float()
+        """Deterministic per name; generated once and kept on the loader's device (the loop then does no host-side image work)."""
+        c = self._l._cache
+        if name not in c:
+            i = self.names.index(name)
+            g = torch.Generator().manual_seed(7919 * (i + 1) + self._l.seed)
+            c[name] = (torch.randn(3, self._l.H, self._l.W, generator=g) * self._l.img_std).bfloat16().float().to(self._l.device)
+        return c[name]
 
     def test_view(self, name):
         l = self._l
         meta = dict(filename=name, ori_filename=name, ori_shape=(l.H, l.W_img, 3), img_shape=(l.H, l.W_img, 3),
                     pad_shape=(l.H, l.W, 3), scale_factor=np.ones(4, dtype=np.float32), flip=False)
-        return self.image(name)[None].to(l.device), meta
+        return self.image(name)[None], meta
 
 
 class SyntheticSemiLoader:
@@ -69,6 +73,7 @@ class SyntheticSemiLoader:
         self.seed, self.device, self.img_std, self.rank = seed + 1000 * rank, device, img_std, rank
         self._len = iters_per_epoch or max(n_labeled, n_unlabeled)
         self._epoch, self._pos = 0, 0
+        self._cache = {}
         self.unlabeled = SyntheticUnlabeled(self)
         rng = np.random.RandomState(2024 + self.seed)
         self._gt = []
@@ -96,14 +101,16 @@ class SyntheticSemiLoader:
         i = self._pos
         li = (self._epoch * self._len + i) % self.n_labeled
         uname = self.unlabeled.upcoming(0)[0]
-        g = torch.Generator().manual_seed(104729 * (li + 1) + self.seed)
-        img_l = (torch.randn(3, self.H, self.W, generator=g) * self.img_std).bfloat16().float()
-        img = torch.stack([img_l, self.unlabeled.image(uname)]).to(self.device)
+        lname = f'labeled_{li:05d}.jpg'
+        if lname not in self._cache:
+            g = torch.Generator().manual_seed(104729 * (li + 1) + self.seed)
+            self._cache[lname] = (torch.randn(3, self.H, self.W, generator=g) * self.img_std).bfloat16().float().to(self.device)
+        img = torch.stack([self._cache[lname], self.unlabeled.image(uname)])
         ugt, ugl, uig = self.bank.ann_info(uname, img_wh=(self.W_img, self.H))
         gtb, gtl = self._gt[li]
         metas = [dict(filename=n, ori_filename=n, ori_shape=(self.H, self.W_img, 3), img_shape=(self.H, self.W_img, 3),
                       pad_shape=(self.H, self.W, 3), scale_factor=np.ones(4, dtype=np.float32), flip=False)
-                 for n in (f'labeled_{li:05d}.jpg', uname)]
+                 for n in (lname, uname)]
         self._pos += 1
         return dict(img=img, img_metas=metas, gt_bboxes=[gtb, ugt], gt_labels=[gtl, ugl],
                     gt_bboxes_ignore=[torch.zeros(0, 4), uig])

@@ -14,9 +14,13 @@ off-GPU raises.
 """
 from collections import OrderedDict
 
+import ctypes
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+C_void = ctypes.c_void_p
 
 from .params import ParamStore
 from .registry import BACKBONES, DETECTORS, HEADS, LOSSES, NECKS, build_backbone, build_head, build_loss, build_neck
@@ -241,6 +245,7 @@ class FCOS(nn.Module):
         # once per train_step, as mmcv's OptimizerHook does.
         self.eager_backward = False
         self._pending = []
+        self._comm_stream = None
 
     # ---- nn.Module surface redirected to the flat store ------------------------------------------
     def init_weights(self):
@@ -339,14 +344,31 @@ class FCOS(nn.Module):
         return losses
 
     def _run_backward(self, plan):
-        """Hand-written backward; gradient buckets are all-reduced as each segment's kernels are queued
-        (bulk RCCL traffic overlaps the remaining backward, as torch DDP does at mmdet/apis/train.py:92-96)."""
+        """Hand-written backward.  Data parallel: gradient bucket s (head+FPN, layer4, layer3, layer2) is all-reduced as
+        soon as the side stream has finished its weight gradients - the communication stream waits for the named event
+        the segment recorded (dsl_stream_wait_slot), not for the caller's stream, which is already running the next
+        segment's data-gradient chain - so the bulk RCCL traffic overlaps the remaining backward (what torch DDP's bucket
+        hooks do at mmdet/apis/train.py:92-96); only the last, smallest bucket (layer2, 5 MB) is exposed."""
         self._pending = []
-        for ol, ready in plan.bwd_segments:
+        ddp = self.world_size > 1
+        on_gpu = self.store.grad.is_cuda
+        if ddp and on_gpu and self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        for ol, info in plan.bwd_segments:
             ol.run()
-            if self.world_size > 1:
-                for lo, hi in ready:        # buckets whose gradients are complete once this list has run
-                    self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
+            if not ddp:
+                continue
+            lo, hi = info['bucket']
+            if not on_gpu:            # host tensors (the gloo unit test of the bucket order): nothing to order against
+                self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
+                continue
+            from . import _lib as L
+            cs = self._comm_stream
+            L.check(min(L.lib.dsl_stream_wait_slot(info['slot'], C_void(cs.cuda_stream)), 0), 'dsl_stream_wait_slot')
+            if info['main']:
+                cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
         self._rebind_grads()
 
     def wait_grads(self):

@@ -122,7 +122,7 @@ class Plan:
         self.fwd = OpList()
         self.loss_ops = OpList()
         self.assign_ops = OpList()
-        self.bwd_segments = []          # [(OpList, (grad_lo, grad_hi))] in execution order
+        self.bwd_segments = []          # [(OpList, dict(bucket=(lo, hi), slot=event slot, main=bool))] in execution order
         self.img = torch.zeros(N, 3, H, W, dtype=torch.float32, device=dev)
         # split-K scratch shared by all convs of the plan (they run back to back on one stream); the library
         # lowers its split factor if a conv would need more than this
@@ -320,13 +320,13 @@ class Plan:
         return ws
 
     def _dgrad(self, name, dy, dst, n, dy_hw, dst_hw, *, cs, cd, k, stride, pad, os=1, addend=None, mask=None,
-               mask_first=False, mask_last=False):
+               mask_first=False, mask_last=False, cs_real=0):
         st = self.store
         f = (L.CONV_MASK_FIRST if mask_first else 0) | (L.CONV_MASK_LAST if mask_last else 0)
         grid = dy_hw if os > 1 else dst_hw
         return ops.conv_desc(dy, st.wT_ptr(name), dst, n=n, grid=grid, src_hw=dy_hw, dst_hw=dst_hw, cs=cs, cd=cd,
                              cd_pad=cd, ldd=cd, kh=k, kw=k, stride=stride, pad=pad, mode=1, os=os, flags=f,
-                             addend=addend, lda=cd, mask=mask, ldm=cd, workspace=self.conv_ws)
+                             addend=addend, lda=cd, mask=mask, ldm=cd, workspace=self.conv_ws, cs_real=cs_real)
 
     def _build_backward(self):
         """Backward op lists.  The data-gradient chain runs on the caller's stream; every weight gradient is
@@ -351,11 +351,11 @@ class Plan:
             if tower == 'cls_convs':
                 self._wgrad(ol, None, lp.g_cls, lays[3]['act'], N, ls, ls, cy=128, cd=80, wregion='head.cls_w',
                             bregion='head.cls_b', side=SIDE)
-                ol.conv(self._dgrad('head.cls', lp.g_cls, g_act, N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1))
+                ol.conv(self._dgrad('head.cls', lp.g_cls, g_act, N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1, cs_real=80))
             else:
                 self._wgrad(ol, None, lp.g_rc, lays[3]['act'], N, ls, ls, cy=64, cd=5, wregion='head.regctr_w',
                             bregion='head.regctr_b', side=SIDE)
-                ol.conv(self._dgrad('head.regctr', lp.g_rc, g_act, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1))
+                ol.conv(self._dgrad('head.regctr', lp.g_rc, g_act, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1, cs_real=5))
             tower_group = []
             for i in (3, 2, 1, 0):
                 lay = lays[i]
@@ -422,10 +422,11 @@ class Plan:
                                 mask=cfeat, mask_first=True))
         buckets = st.grad_buckets()
         # no JOIN here: this segment's weight gradients keep running on the side stream under the next segment's
-        # data-gradient chain; slot s marks "side-stream work of segment s queued", the NEXT segment ends by waiting
-        # for it, after which bucket s is complete and its all-reduce may start
+        # data-gradient chain.  Named event slot s marks "side-stream work of segment s queued": once it has fired, gradient
+        # bucket s is complete - the data-parallel wrapper's communication stream waits for exactly that
+        # (dsl_stream_wait_slot) and starts the bucket's all-reduce, independent of the caller's stream.
         ol.record(0)
-        self.bwd_segments.append((ol, []))
+        self.bwd_segments.append((ol, dict(bucket=buckets[0], slot=0, main=False)))
         # ================= backbone: layer4, layer3, layer2 =================
         blocks_by_stage = {li: [b for b in self.blocks if b['stage'] == li] for li in (1, 2, 3)}
         for li in (3, 2, 1):
@@ -473,12 +474,10 @@ class Plan:
                                       ws_name='wg_ws_main' if (tail_main and grp_descs is g1) else 'wg_ws')
             seg = 4 - li                      # 1, 2, 3
             ol.record(seg)
-            ol.wait(seg - 1)                  # previous segment's weight gradients done -> its bucket is complete
-            ready = [buckets[seg - 1]]
             if li == 1:                       # last segment: everything must be complete when the list returns
                 ol.join()
-                ready.append(buckets[seg])
-            self.bwd_segments.append((ol, ready))
+            # main=True: part of this bucket's gradients was computed on the caller's stream (the last group above)
+            self.bwd_segments.append((ol, dict(bucket=buckets[seg], slot=seg, main=(li == 1))))
 
     # ---------------------------------------------------------------------------------------------
     def forward(self, img=None):

@@ -16,7 +16,7 @@ def _segs(shapes):
 
 def conv_desc(src, wgt, dst, *, n, grid, src_hw, dst_hw, cs, cd, cd_pad, ldd, kh, kw, stride=1, pad=0,
               mode=0, os=1, flags=0, scale=None, bias=None, addend=None, lda=0, add_hw=None, mask=None,
-              ldm=0, workspace=None):
+              ldm=0, workspace=None, cs_real=0):
     """grid/src_hw/dst_hw/add_hw: list of (h, w) per level segment."""
     d = L.ConvDesc()
     d.nseg, d.n = len(grid), n
@@ -27,6 +27,7 @@ def conv_desc(src, wgt, dst, *, n, grid, src_hw, dst_hw, cs, cd, cd_pad, ldd, kh
         d.ah, d.aw = _segs(add_hw)
     d.cs, d.cd, d.cd_pad, d.ldd, d.lda, d.ldm = cs, cd, cd_pad, ldd, lda, ldm
     d.kh, d.kw, d.stride, d.pad, d.mode, d.os, d.flags = kh, kw, stride, pad, mode, os, flags
+    d.cs_real = cs_real
     d.src, d.wgt, d.dst = L.ptr(src), L.ptr(wgt), L.ptr(dst)
     d.scale, d.bias, d.addend, d.mask = L.ptr(scale), L.ptr(bias), L.ptr(addend), L.ptr(mask)
     if workspace is not None:

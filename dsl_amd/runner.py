@@ -82,7 +82,12 @@ class SemiEpochBasedRunner:
     def _det(self, m):
         return m.module if hasattr(m, 'module') else m
 
+    PRIORITIES = dict(HIGHEST=0, VERY_HIGH=10, HIGH=30, ABOVE_NORMAL=40, NORMAL=50, BELOW_NORMAL=60, LOW=70, VERY_LOW=90,
+                      LOWEST=100)         # mmcv/runner/priority.py
+
     def register_hook(self, hook, priority=50):
+        if isinstance(priority, str):
+            priority = self.PRIORITIES[priority.upper()]
         hook.priority = priority
         i = len(self._hooks)
         while i > 0 and self._hooks[i - 1].priority > priority:
@@ -92,6 +97,63 @@ class SemiEpochBasedRunner:
     def call_hook(self, name):
         for h in self._hooks:
             getattr(h, name)(self)
+
+    # -- config-driven hook registration (semi_epoch_based_runner.py:460-509, mmcv BaseRunner.register_*_hook) ----
+    def register_training_hooks(self, lr_config, optimizer_config=None, ema_config=None, checkpoint_config=None,
+                                log_config=None, momentum_config=None, timer_config=None, custom_hooks_config=None):
+        if lr_config is not None:
+            if isinstance(lr_config, dict):
+                c = dict(lr_config)
+                policy = c.pop('policy')
+                assert policy == 'step', f'lr policy {policy!r}: only the step policy of configs/fcos_semi is built'
+                hook = StepLrUpdaterHook(**c)
+            else:
+                hook = lr_config
+            self.register_hook(hook, priority='VERY_HIGH')
+        assert momentum_config is None, 'momentum schedules are not used by configs/fcos_semi'
+        if optimizer_config is not None:
+            hook = OptimizerHook(**optimizer_config) if isinstance(optimizer_config, dict) else optimizer_config
+            self.register_hook(hook, priority='ABOVE_NORMAL')
+        if ema_config is not None:
+            if isinstance(ema_config, dict):
+                c = dict(ema_config)
+                c.setdefault('type', 'EMAOWNHook')
+                hook = HOOKS.build(c)
+            else:
+                hook = ema_config
+            self.register_hook(hook, priority=45)
+        if checkpoint_config is not None:
+            hook = CheckpointHook(**checkpoint_config) if isinstance(checkpoint_config, dict) else checkpoint_config
+            self.register_hook(hook, priority='NORMAL')
+        if log_config is not None:
+            interval = log_config.get('interval', 10)
+            for info in log_config.get('hooks', []):
+                c = dict(info)
+                if c['type'] not in HOOKS:
+                    raise KeyError(f"logger hook {c['type']} is not available")
+                c.setdefault('interval', interval)
+                self.register_hook(HOOKS.build(c), priority='VERY_LOW')
+        for c in custom_hooks_config or []:
+            c = dict(c)
+            prio = c.pop('priority', 'NORMAL')
+            self.register_hook(HOOKS.build(c), priority=prio)
+
+    def current_lr(self):
+        return [g['lr'] for g in self.optimizer.param_groups]
+
+    def resume(self, checkpoint, resume_optimizer=True, map_location='cpu'):
+        """mmcv BaseRunner.resume: weights (student and teacher, :350-366), epoch / iter counters, optimizer state."""
+        ck = self.load_checkpoint(checkpoint, map_location=map_location)
+        self._epoch = ck['meta']['epoch']
+        self._iter = ck['meta']['iter']
+        if 'optimizer' in ck and resume_optimizer and self.optimizer is not None:
+            self.optimizer.load_state_dict(ck['optimizer'])
+        ema = checkpoint + '_ema'
+        if self.ema_model is not None and os.path.exists(ema):
+            self._det(self.ema_model).load_state_dict(torch.load(ema, map_location=map_location)['state_dict'], strict=False)
+            self.ema_flag = True
+        if self.logger:
+            self.logger.info('resumed epoch %d, iter %d', self.epoch, self.iter)
 
     def run_iter(self, data_batch, train_mode=True, **kw):
         m = self.model if train_mode else (self.ema_model if self.ema_flag else self.model)
@@ -154,16 +216,32 @@ class SemiEpochBasedRunner:
             L.check(L.lib.dsl_cast_bf16(L.ptr(t.train), L.ptr(t.train16), t.n_train, L.stream_ptr()), 'dsl_cast_bf16')
         self.ema_flag = True
 
-    def save_checkpoint(self, out_dir, filename_tmpl='epoch_{}.pth', meta=None):
-        """:411-458: student to <file>, teacher to <file>_ema."""
+    def save_checkpoint(self, out_dir, filename_tmpl='epoch_{}.pth', save_optimizer=True, meta=None, create_symlink=True):
+        """:411-458: student (+ optimizer state) to <file>, teacher to <file>_ema once it exists (ema_flag), latest.pth."""
         os.makedirs(out_dir, exist_ok=True)
-        fn = os.path.join(out_dir, filename_tmpl.format(self.epoch + 1))
-        meta = dict(meta or {}, epoch=self.epoch + 1, iter=self.iter)
-        sd = {k: v.detach().cpu().clone() for k, v in self._det(self.model).state_dict().items()}
-        torch.save(dict(meta=meta, state_dict=sd), fn)
-        if self.ema_model is not None:
+        meta = dict(meta or {})
+        if self.meta is not None:
+            meta.update(self.meta)
+        meta.update(epoch=self.epoch + 1, iter=self.iter)
+        filename = filename_tmpl.format(self.epoch + 1)
+        fn = os.path.join(out_dir, filename)
+        ck = dict(meta=meta, state_dict={k: v.detach().cpu().clone() for k, v in self._det(self.model).state_dict().items()})
+        if save_optimizer and self.optimizer is not None:
+            osd = self.optimizer.state_dict()
+            ck['optimizer'] = {k: (v.detach().cpu().clone() if isinstance(v, torch.Tensor) else v) for k, v in osd.items()}
+        torch.save(ck, fn)
+        if self.ema_flag and self.ema_model is not None:
             sd = {k: v.detach().cpu().clone() for k, v in self._det(self.ema_model).state_dict().items()}
             torch.save(dict(meta=meta, state_dict=sd), fn + '_ema')
+        if create_symlink:
+            dst = os.path.join(out_dir, 'latest.pth')
+            if os.path.lexists(dst):
+                os.remove(dst)
+            try:
+                os.symlink(filename, dst)
+            except OSError:
+                import shutil
+                shutil.copy(fn, dst)
         return fn
 
     def load_checkpoint(self, filename, map_location='cpu', strict=False):
@@ -237,8 +315,71 @@ class EMAOWNHook(Hook):
 
 
 @HOOKS.register_module()
+class CheckpointHook(Hook):
+    """mmcv CheckpointHook (by_epoch): runner.save_checkpoint every `interval` epochs into work_dir, rank 0 only."""
+
+    def __init__(self, interval=-1, by_epoch=True, save_optimizer=True, out_dir=None, max_keep_ckpts=-1, **kw):
+        self.interval, self.by_epoch, self.save_optimizer, self.out_dir = interval, by_epoch, save_optimizer, out_dir
+
+    def _rank0(self):
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+    def after_train_epoch(self, runner):
+        if not self.by_epoch or not self.every_n_epochs(runner, self.interval):
+            return
+        out = self.out_dir or runner.work_dir
+        if out and self._rank0():
+            runner.save_checkpoint(out, save_optimizer=self.save_optimizer)
+
+
+@HOOKS.register_module()
+class TextLoggerHook(Hook):
+    """mmcv TextLoggerHook, reduced: every `interval` iterations one line with epoch / iter / lr and the log vars
+    averaged over the interval (the only host read of the step's device scalars), also appended to
+    <work_dir>/<timestamp>.log.json."""
+
+    def __init__(self, interval=10, by_epoch=True, **kw):
+        self.interval, self.by_epoch = interval, by_epoch
+
+    def after_train_iter(self, runner):
+        if not self.every_n_iters(runner, self.interval):
+            return
+        buf = runner.log_buffer[-self.interval:]
+        if not buf:
+            return
+        keys = list(buf[0][0].keys())
+        avg = {k: float(sum(float(lv[k]) * n for lv, n in buf) / sum(n for _, n in buf)) for k in keys}
+        rec = dict(mode='train', epoch=runner.epoch + 1, iter=runner.inner_iter + 1, lr=runner.current_lr()[0], **avg)
+        if runner.logger:
+            runner.logger.info('Epoch [%d][%d/%d]\tlr: %.3e, %s', rec['epoch'], rec['iter'], len(runner.data_loader),
+                               rec['lr'], ', '.join(f'{k}: {v:.4f}' for k, v in avg.items()))
+        if runner.work_dir:
+            os.makedirs(runner.work_dir, exist_ok=True)
+            with open(os.path.join(runner.work_dir, f"{getattr(runner, 'timestamp', None) or 'train'}.log.json"), 'a') as f:
+                f.write(json.dumps(rec) + '\n')
+        runner.log_buffer = []
+
+
+@HOOKS.register_module()
 class NumClassCheckHook(Hook):
-    pass
+    """mmdet/datasets/utils.py:115-160: the head's num_classes must equal len(dataset.CLASSES)."""
+
+    def before_train_epoch(self, runner):
+        loader = getattr(runner, 'data_loader', None)
+        ds = getattr(loader, 'dataset', loader)
+        classes = getattr(ds, 'CLASSES', None)
+        if classes is None:
+            if runner.logger:
+                runner.logger.warning('Please set `CLASSES` in the %s and check if it is consistent with the `num_classes` '
+                                      'of head', ds.__class__.__name__)
+            return
+        assert type(classes) is not str, f'`CLASSES` in {ds.__class__.__name__} should be a tuple of str.'
+        head = runner._det(runner.model).bbox_head
+        assert head.num_classes == len(classes), (
+            f'The `num_classes` ({head.num_classes}) in {head.__class__.__name__} of '
+            f'{runner._det(runner.model).__class__.__name__} does not matches the length of `CLASSES` {len(classes)}) in '
+            f'{ds.__class__.__name__}')
 
 
 @HOOKS.register_module()
@@ -247,6 +388,8 @@ class DistSamplerSeedHook_semi(Hook):
         loader = getattr(runner, 'data_loader', None)
         if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
             loader.sampler.set_epoch(runner.epoch)
+        elif hasattr(loader, 'set_epoch'):
+            loader.set_epoch(runner.epoch)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -72,6 +72,9 @@ typedef struct dsl_conv_desc {
   const void* mask;                                  /* bf16 or NULL */
   void* workspace;                                   /* optional fp32 scratch for split-K (small-M, large-K convs) */
   size_t workspace_bytes;                            /* NULL/0: never split */
+  int32_t cs_real;                                   /* 0 = cs; else the source's real channel count when cs is padded (the
+                                                      * 80- / 5-channel predictor gradients stored 128 / 64 wide): only the
+                                                      * algorithmic FLOP / byte counts of dsl_prof_* use it */
 } dsl_conv_desc;
 
 /* bytes of split-K scratch this conv would like (0 if it will not split); any smaller buffer is legal */
@@ -274,6 +277,10 @@ typedef struct dsl_op {
   int64_t l[2];
 } dsl_op;
 int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream);
+/* `stream` waits for named event slot `slot` (a DSL_OP_RECORD of an earlier dsl_run_ops): lets a communication stream
+ * start a gradient bucket's all-reduce when the side stream has finished that bucket's weight gradients, whatever the
+ * caller's compute stream is doing.  Returns 1 (and does nothing) if the slot was never recorded. */
+int dsl_stream_wait_slot(int slot, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Live kernel timing with HIP events (bench.py roofline): when enabled, each launch of the MFMA
@@ -289,6 +296,8 @@ int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream);
 int dsl_prof_enable(int on);
 int dsl_prof_reset(void);
 int dsl_prof_read(int64_t* launches, double* ms, double* flops);
+/* the same plus the algorithmic HBM bytes of the bracketed launches (tensors read + written once, real channels) */
+int dsl_prof_read2(int64_t* launches, double* ms, double* flops, double* bytes);
 
 /* hardware probes used by the tests */
 int dsl_probe_tr16(const uint16_t* lds_image /* 4096 u16 */, const int32_t* lane_off /* 64 u16-offsets */,

@@ -53,11 +53,36 @@ class _RoundFwd(torch.autograd.Function):
         return g
 
 
-class Quant:
-    def __init__(self, emulate_bf16=False):
-        self.on = emulate_bf16
+class _JitterRound(torch.autograd.Function):
+    """x*(1 + eps*n), n ~ N(0,1), both ways, followed (rnd) by the bf16 round trip: a DIFFERENT realisation of the same
+    storage rounding - what another fp32 summation order in front of the store does (an fp32-ulp-sized change flips the
+    bf16 rounding of the ~1 % of values that sit next to a rounding boundary).  Without rnd it is the bare fp32-level
+    perturbation: the sensitivity probe of tests/golden/make_trajectory.py."""
 
-    def act(self, x):      # activation stored in HBM as bf16, its gradient too
+    @staticmethod
+    def forward(ctx, x, eps, gen, rnd):
+        ctx.eps, ctx.gen, ctx.rnd = eps, gen, rnd
+        y = x * (1 + eps * torch.randn(x.shape, generator=gen))
+        return y.bfloat16().float() if rnd else y
+
+    @staticmethod
+    def backward(ctx, g):
+        y = g * (1 + ctx.eps * torch.randn(g.shape, generator=ctx.gen))
+        return (y.bfloat16().float() if ctx.rnd else y), None, None, None
+
+
+class Quant:
+    def __init__(self, emulate_bf16=False, jitter=0.0, seed=0, fp32_grad_tags=()):
+        self.on = emulate_bf16
+        self.jitter = jitter
+        self.gen = torch.Generator().manual_seed(seed) if jitter else None
+        self.fp32_grad_tags = set(fp32_grad_tags)      # storage points whose GRADIENT tensor is kept in fp32
+
+    def act(self, x, tag=None):      # activation stored in HBM as bf16, its gradient too
+        if self.on and tag in self.fp32_grad_tags:
+            return _RoundFwd.apply(x)
+        if self.jitter:
+            return _JitterRound.apply(x, self.jitter, self.gen, self.on)
         return _RoundBoth.apply(x) if self.on else x
 
     def wt(self, w):       # bf16 packed weight copy; gradient stays fp32 (wgrad writes fp32)
@@ -240,14 +265,14 @@ def head_forward(sd, feats, q, training=True):
         for i in range(4):
             cf = F.conv2d(cf, q.wt(sd[f'bbox_head.cls_convs.{i}.conv.weight']),
                           sd[f'bbox_head.cls_convs.{i}.conv.bias'], 1, 1)
-            cf = q.act(cf)      # the HIP path stores the pre-GN conv output as bf16
+            cf = q.act(cf, 'tower_pre')      # the HIP path stores the pre-GN conv output as bf16
             cf = q.act(F.relu(F.group_norm(cf, 32, sd[f'bbox_head.cls_convs.{i}.gn.weight'],
-                                           sd[f'bbox_head.cls_convs.{i}.gn.bias'], 1e-5)))
+                                           sd[f'bbox_head.cls_convs.{i}.gn.bias'], 1e-5)), 'tower_act')
             rf = F.conv2d(rf, q.wt(sd[f'bbox_head.reg_convs.{i}.conv.weight']),
                           sd[f'bbox_head.reg_convs.{i}.conv.bias'], 1, 1)
-            rf = q.act(rf)
+            rf = q.act(rf, 'tower_pre')
             rf = q.act(F.relu(F.group_norm(rf, 32, sd[f'bbox_head.reg_convs.{i}.gn.weight'],
-                                           sd[f'bbox_head.reg_convs.{i}.gn.bias'], 1e-5)))
+                                           sd[f'bbox_head.reg_convs.{i}.gn.bias'], 1e-5)), 'tower_act')
         cls = F.conv2d(cf, q.wt(sd['bbox_head.conv_cls.weight']), sd['bbox_head.conv_cls.bias'], 1, 1)
         reg = F.conv2d(rf, q.wt(sd['bbox_head.conv_reg.weight']), sd['bbox_head.conv_reg.bias'], 1, 1)
         ctr = F.conv2d(rf, q.wt(sd['bbox_head.conv_centerness.weight']),
@@ -500,8 +525,8 @@ def append_half_scale(img, gt_bboxes, gt_labels, gt_bboxes_ignore):
 # whole step: forward + loss + backward   (detectors/single_stage.py:56-84, base.py:175-243)
 # ----------------------------------------------------------------------------------------------
 def train_step(sd, img, gt_bboxes, gt_labels, gt_bboxes_ignore=None, emulate_bf16=False,
-               want_grads=True, debug=None, **loss_kw):
-    q = Quant(emulate_bf16)
+               want_grads=True, debug=None, quant=None, **loss_kw):
+    q = quant if quant is not None else Quant(emulate_bf16)
     tk = trainable_keys(sd)
     p = {k: (v.detach().clone().requires_grad_(k in tk) if v.is_floating_point() else v)
          for k, v in sd.items()}

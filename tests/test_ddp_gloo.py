@@ -43,11 +43,12 @@ def _worker(rank, world, port, q):
         # bucketed all-reduce in backward order
         det.store.grad.copy_(torch.arange(det.store.n_train, dtype=torch.float32) % 7 + rank)
 
+        # the engine's schedule: segment s queues the weight gradients of bucket s on the side stream and records named
+        # event s; the bucket's all-reduce is issued behind that event
+        _b = det.store.grad_buckets()
+
         class Plan:
-            # the engine's schedule: a bucket becomes complete one segment late (its weight gradients finish on the
-            # side stream under the next segment), the last segment releases the last two
-            _b = det.store.grad_buckets()
-            bwd_segments = [(_NoOps(), []), (_NoOps(), [_b[0]]), (_NoOps(), [_b[1]]), (_NoOps(), [_b[2], _b[3]])]
+            bwd_segments = [(_NoOps(), dict(bucket=b, slot=i, main=(i == 3))) for i, b in enumerate(_b)]
         det._run_backward(Plan)
         assert len(det._pending) == 4
         det.wait_grads()

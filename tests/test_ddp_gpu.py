@@ -111,3 +111,27 @@ def test_ddp_step_equals_big_batch(eager, tmp_path):
         assert rel_l2(g_ddp[o:o + n], g_big[o:o + n]) < 2e-2, (name, rel_l2(g_ddp[o:o + n], g_big[o:o + n]))
     for k, v in out['log_vars'].items():
         assert logs[0][k] == pytest.approx(float(v), rel=2e-3), (k, logs[0][k], float(v))
+
+
+def test_bench_two_rank_dry_run():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU), here with both ranks on the
+    one GPU of the box and gloo collectives (DSL_BENCH_ONE_GPU / DSL_DIST_BACKEND test hooks): the multi-rank path of the
+    benchmark - rank-local batches, bucketed all-reduce behind the named events, max-over-ranks timing, ONE JSON line
+    from rank 0 with whole-job throughput - runs end to end before an 8-GPU node ever sees it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSL_BENCH_ONE_GPU='1', DSL_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--no-prof']
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['warmup'] == 1 and j['scaling'] == 'weak'
+    assert j['config']['global_batch'] == 4 and j['config']['parallelism'] == 'dp2'
+    assert j['value'] == pytest.approx(4 * 3 / (j['ms_per_step'] * 3e-3), rel=1e-3) and j['value'] > 0
+    assert j['cpu_baseline'] is None and np.isfinite(j['final_losses']['loss'])

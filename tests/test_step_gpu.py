@@ -176,6 +176,46 @@ def test_full_size_losses_and_assignment_vs_oracle():
     assert torch.equal(plan.lossplan.labels.cpu(), raux['labels'])
 
 
+def test_full_size_dsl_iteration_vs_oracle():
+    """BASELINE.json configs[2] at its real size: the semi-supervised batch 3 x (3, 800, 1344) - labeled image, unlabeled
+    image with ignore boxes, its half-scale copy built by append_half_scale - with loss_weight 3, the sisoft term at full
+    weight: the four losses within 1e-3 relative of the fp32 CPU oracle and bit-identical assignment (gt and ignore
+    passes) on all 67 200 locations."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from dsl_amd.runner import append_half_scale
+    from oracle import fcos_oracle as O
+    kw = dict(loss_weight=3.0, soft_weight=1.0)
+    model = build(soft_warm_up=0, **kw)
+    model.bbox_head.cur_iter = 1                      # past the warm-up window
+    b = bench.synth_batch(0, 2)
+    rng = np.random.RandomState(77)
+    ig = [torch.zeros(0, 4), T(bench.synth_boxes(rng, 3))]        # K ~ Poisson(3) ignore boxes on the unlabeled image (SURVEY 8d)
+    # the three-image batch is built once, on the CPU, by the oracle's restatement of semi_epoch_based_runner.py:186-204
+    # (the device version is compared with it in tests/test_boundary_cpu.py) and handed to both sides
+    oimg, ogb, ogl, ogi = O.append_half_scale(b['img'].cpu(), b['gt_bboxes'], b['gt_labels'], ig)
+    _, _, _, _, metas = append_half_scale(b['img'][:, :, :8, :8].cpu(), b['gt_bboxes'], b['gt_labels'], ig, b['img_metas'])
+    assert oimg.shape[0] == 3 and len(metas) == 3
+    losses = model.forward_train(oimg.cuda(), metas, ogb, ogl, ogi)
+    torch.cuda.synchronize()
+    assert set(losses) == {'loss_cls', 'loss_bbox', 'loss_centerness', 'loss_sisoft'}
+    l32, _, aux = O.train_step(O.synth_state_dict(0), oimg, ogb, ogl, ogi, emulate_bf16=False, want_grads=False,
+                               soft_scale=1.0, **kw)
+    for k, v in losses.items():
+        assert float(v.detach()) == pytest.approx(l32[k], rel=1e-3), (k, float(v.detach()), l32[k])
+    plan = [p for p in model._engine.plans.values() if p.N == 3][0]
+    with torch.no_grad():
+        _, raux = O.fcos_loss([t.detach() for t in aux['cls']], [t.detach() for t in aux['reg']],
+                              [t.detach() for t in aux['ctr']], ogb, ogl, ogi, return_aux=True, soft_scale=1.0, **kw)
+    assert plan.lossplan.assign_idx.numel() == 3 * 22400
+    assert torch.equal(plan.lossplan.assign_idx.cpu().long(), raux['assign_idx'])
+    assert torch.equal(plan.lossplan.labels.cpu(), raux['labels'])
+    if 'cls_weight' in raux:
+        assert torch.equal(plan.lossplan.cls_weight.cpu(), raux['cls_weight'].float())
+
+
 def test_plan_cache_is_bounded_and_reuses_shapes():
     """Multi-scale training visits many padded shapes: plans are cached per shape, least recently used evicted."""
     model = build()
