@@ -68,7 +68,8 @@ class FcosDesc(C.Structure):
                 ('scales', C.c_void_p), ('norm', C.c_void_p),
                 ('g_cls', C.c_void_p), ('ld_gcls', C.c_int32), ('g_rc', C.c_void_p), ('ld_grc', C.c_int32),
                 ('g_scales', C.c_void_p), ('losses', C.c_void_p),
-                ('soft_weight', C.c_float), ('grad_scale', C.c_float), ('inv_world', C.c_float)]
+                ('soft_weight', C.c_float), ('grad_scale', C.c_float), ('inv_world', C.c_float),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
 class DetDesc(C.Structure):
@@ -99,6 +100,8 @@ lib.dsl_wgrad_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_wgrad_group_workspace_bytes'):
     lib.dsl_wgrad_group_workspace_bytes.restype = C.c_size_t
 lib.dsl_conv2d_workspace_bytes.restype = C.c_size_t
+if hasattr(lib, 'dsl_fcos_workspace_bytes'):
+    lib.dsl_fcos_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_groupnorm_workspace_bytes'):
     lib.dsl_groupnorm_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_detect_workspace_bytes'):
@@ -110,7 +113,7 @@ _SIGS = {
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
     'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp], 'dsl_groupnorm_workspace_bytes': [_vp],
     'dsl_sum2x2': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], 'dsl_colsum': [_vp, _vp, _l, _i, _i, _vp],
-    'dsl_fcos_points': [_vp, _vp, _vp], 'dsl_fcos_assign': [_vp, _vp], 'dsl_fcos_loss': [_vp, _vp],
+    'dsl_fcos_points': [_vp, _vp, _vp], 'dsl_fcos_workspace_bytes': [_vp], 'dsl_fcos_assign': [_vp, _vp], 'dsl_fcos_loss': [_vp, _vp],
     'dsl_sumsq': [_vp, _l, _vp, _vp],
     'dsl_sgd_step': [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _i, _vp],
     'dsl_ema_lerp': [_vp, _vp, _l, _f, _vp], 'dsl_cast_bf16': [_vp, _vp, _l, _vp],

@@ -29,6 +29,7 @@ struct FcK {
   const float* scales; const float* norm;
   uint16_t* g_cls; int ld_gcls; uint16_t* g_rc; int ld_grc;
   float* g_scales; float* losses;
+  float* part;            // block records of the loss / assignment sums (fixed-order second pass, no float atomics)
 };
 
 __device__ __forceinline__ void decode_loc(const FcK& p, int m, int& lvl, int& img, int& y, int& x) {
@@ -130,10 +131,41 @@ __global__ __launch_bounds__(256) void assign_kernel(const FcK p) {
   }
   const float np = block_sum(is_pos, sh);
   const float cs = block_sum(ctr, sh);
-  if (threadIdx.x == 0 && (np != 0.f)) {
-    atomicAdd(p.stats, np);
-    atomicAdd(p.stats + 1, cs);
+  if (threadIdx.x == 0) {
+    p.part[2 * blockIdx.x] = np;
+    p.part[2 * blockIdx.x + 1] = cs;
   }
+}
+
+// fixed-order sum of per-block records: out[v] = sum_b part[b * V + v] * scale(v); one workgroup
+constexpr int FIN_T = 256;
+__global__ __launch_bounds__(FIN_T) void fcos_finalize_kernel(const float* __restrict__ part, int nblocks, int V, float* out0,
+                                                              int n0, float* out1, const float* norm, float inv_world,
+                                                              float soft_weight, int mode) {
+  __shared__ float sh[FIN_T];
+  // thread (q, v): blocks q, q + Q, ... ; then thread v adds the Q partial sums in order
+  const int Q = FIN_T / V;
+  const int v = threadIdx.x % V, q = threadIdx.x / V;
+  float a = 0.f;
+  if (q < Q)
+    for (int b = q; b < nblocks; b += Q) a += part[(long long)b * V + v];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < V) {
+    float t = 0.f;
+    for (int k = 0; k < Q; ++k) t += sh[k * V + threadIdx.x];
+    if (mode == 1) {           // loss records: [cls, sisoft, bbox, centerness, g_scale x 5] -> losses[4] + g_scales[5]
+      const float num_pos = fmaxf(norm[0] * inv_world, 1.0f), denorm = fmaxf(norm[1] * inv_world, 1e-6f);
+      if (threadIdx.x == 0) out0[0] = t / num_pos;
+      else if (threadIdx.x == 1) out0[3] = t * soft_weight;
+      else if (threadIdx.x == 2) out0[1] = t / denorm;
+      else if (threadIdx.x == 3) out0[2] = t / num_pos;
+      else if (threadIdx.x - 4 < n0) out1[threadIdx.x - 4] = t;
+    } else if (threadIdx.x < n0) {
+      out0[threadIdx.x] = t;
+    }
+  }
+  if (mode == 0 && (int)threadIdx.x >= V && threadIdx.x < 8) out0[threadIdx.x] = 0.f;      // stats[2..7] are reserved, kept zero
 }
 
 __global__ void points_kernel(const FcK p, float* __restrict__ pts) {
@@ -232,9 +264,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const FcK p) {
   }
   lsum = block_sum(lsum, sh);
   ssum = block_sum(ssum, sh);
+  float* rec = p.part + 16ll * blockIdx.x;          // [cls, sisoft, bbox, centerness, g_scale x 5, pad]
   if (threadIdx.x == 0) {
-    if (lsum != 0.f) atomicAdd(p.losses + 0, lsum / num_pos);
-    if (ssum != 0.f) atomicAdd(p.losses + 3, ssum * p.soft_weight);
+    rec[0] = lsum;
+    rec[1] = ssum;
   }
 
   // ---------------- boxes + centerness: one thread per location ---------------------------------
@@ -318,14 +351,17 @@ __global__ __launch_bounds__(256) void loss_kernel(const FcK p) {
   bsum = block_sum(bsum, sh);
   csum = block_sum(csum, sh);
   if (threadIdx.x == 0) {
-    if (bsum != 0.f) atomicAdd(p.losses + 1, bsum / denorm);
-    if (csum != 0.f) atomicAdd(p.losses + 2, csum / num_pos);
+    rec[2] = bsum;
+    rec[3] = csum;
   }
 #pragma unroll
   for (int l = 0; l < DSL_MAX_SEG; ++l) {
     const float v = block_sum(gsc[l], sh);
-    if (threadIdx.x == 0 && v != 0.f) atomicAdd(p.g_scales + l, v);
+    if (threadIdx.x == 0) rec[4 + l] = v;
   }
+#pragma unroll
+  for (int l = 4 + DSL_MAX_SEG; l < 16; ++l)
+    if (threadIdx.x == 0) rec[l] = 0.f;
 }
 
 int fill(const dsl_fcos_desc* d, FcK& k) {
@@ -341,6 +377,7 @@ int fill(const dsl_fcos_desc* d, FcK& k) {
     m += d->n * d->h[l] * d->w[l];
   }
   k.mstart[d->nlvl] = m;
+  k.part = (float*)d->workspace;
   k.radius = d->radius; k.loss_weight = d->loss_weight; k.soft_weight = d->soft_weight;
   k.grad_scale = d->grad_scale; k.inv_world = d->inv_world;
   k.gt_boxes = d->gt_boxes; k.gt_labels = (const long long*)d->gt_labels; k.gt_off = d->gt_off;
@@ -355,6 +392,14 @@ int fill(const dsl_fcos_desc* d, FcK& k) {
 }
 
 }  // namespace
+
+extern "C" size_t dsl_fcos_workspace_bytes(const dsl_fcos_desc* d) {
+  if (!d) return 0;
+  long long M = 0;
+  for (int l = 0; l < d->nlvl; ++l) M += (long long)d->n * d->h[l] * d->w[l];
+  const size_t assign_rec = (size_t)((M + 255) / 256) * 2, loss_rec = 2048 * 16;
+  return (assign_rec > loss_rec ? assign_rec : loss_rec) * sizeof(float);
+}
 
 extern "C" int dsl_fcos_points(const dsl_fcos_desc* d, float* points, void* stream) {
   FcK k;
@@ -374,9 +419,13 @@ extern "C" int dsl_fcos_assign(const dsl_fcos_desc* d, void* stream) {
                 d->cls_weight && d->pos_weight && d->stats,
             "dsl_fcos_assign: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(d->stats, 0, sizeof(float) * 8, st);
   const int M = k.mstart[k.nlvl];
-  hipLaunchKernelGGL(assign_kernel, dim3((M + 255) / 256), dim3(256), 0, st, k);
+  const int nb = (M + 255) / 256;
+  DSL_CHECK(d->workspace && d->workspace_bytes >= dsl_fcos_workspace_bytes(d), "dsl_fcos_assign: workspace too small");
+  hipLaunchKernelGGL(assign_kernel, dim3(nb), dim3(256), 0, st, k);
+  // stats[0] = num_pos, stats[1] = sum of centerness targets (this rank), stats[2..7] = 0: block records added in block order
+  hipLaunchKernelGGL(fcos_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, (const float*)k.part, nb, 2, d->stats, 2, (float*)nullptr,
+                     (const float*)nullptr, 1.f, 0.f, 0);
   DSL_LAUNCH_CHECK("assign_kernel");
   return 0;
 }
@@ -390,12 +439,13 @@ extern "C" int dsl_fcos_loss(const dsl_fcos_desc* d, void* stream) {
   DSL_CHECK(d->num_classes % 4 == 0 && d->ld_cls % 4 == 0 && d->ld_gcls % 4 == 0 && d->ld_grc % 8 == 0 && d->ld_rc >= 5,
             "dsl_fcos_loss: unsupported strides / class count");
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(d->losses, 0, sizeof(float) * 4, st);
-  hipMemsetAsync(d->g_scales, 0, sizeof(float) * DSL_MAX_SEG, st);
+  DSL_CHECK(d->workspace && d->workspace_bytes >= dsl_fcos_workspace_bytes(d), "dsl_fcos_loss: workspace too small");
   const int M = k.mstart[k.nlvl];
   int blocks = (int)(((long long)M * (d->num_classes / 4) + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(256), 0, st, k);
+  hipLaunchKernelGGL(fcos_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, (const float*)k.part, blocks, 16, d->losses,
+                     DSL_MAX_SEG, d->g_scales, d->norm, d->inv_world, d->soft_weight, 1);
   DSL_LAUNCH_CHECK("loss_kernel");
   return 0;
 }

@@ -15,6 +15,7 @@ off-GPU raises.
 from collections import OrderedDict
 
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -207,12 +208,25 @@ class _TrainStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, det, plan):
         ctx.det, ctx.plan, ctx.eager = det, plan, det.eager_backward
+        ctx.n_losses = 4 if plan.lossplan.desc.soft_weight != 0.0 else 3
         return plan.lossplan.losses.clone()
 
     @staticmethod
     def backward(ctx, g):
+        """The backward lists compute d(sum of the losses)/d(parameters): the loss kernel already produced the head
+        gradients for d(total)/d(loss_k) = grad_scale (1/world).  Any other incoming gradient - loss scaling, loss / k for
+        gradient accumulation, re-weighted loss keys - is NOT representable: it is rejected instead of silently ignored.
+        The check reads g back (one host sync), so it runs whenever the step syncs anyway (lazy_log False) or when
+        DSL_CHECK_BACKWARD_GRAD=1; fold a constant factor into `FCOS.loss_scale` instead."""
+        det = ctx.det
+        if not det.lazy_log or os.environ.get('DSL_CHECK_BACKWARD_GRAD'):
+            k = ctx.n_losses
+            if not bool((g[:k] == 1).all()):
+                raise NotImplementedError(
+                    'dsl_amd: loss.backward() reached the HIP step with a gradient != 1 for its loss terms '
+                    f'({g[:k].tolist()}): scale through FCOS.loss_scale (folded into the loss kernel), not by scaling the loss tensor')
         if not ctx.eager:                 # eager: the kernels were queued right behind the loss kernel
-            ctx.det._run_backward(ctx.plan)
+            det._run_backward(ctx.plan)
         return None, None, None
 
 
@@ -244,6 +258,7 @@ class FCOS(nn.Module):
         # backward instead of sitting between forward and backward).  For loops that always call loss.backward()
         # once per train_step, as mmcv's OptimizerHook does.
         self.eager_backward = False
+        self.loss_scale = 1.0         # constant factor on every gradient (gradient accumulation: 1/k); the reported losses stay unscaled
         self._pending = []
         self._comm_stream = None
 
@@ -324,7 +339,7 @@ class FCOS(nn.Module):
         lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
         sw = head.effective_soft_weight(N)
         ws = self.world_size
-        lp.configure(loss_weight=head.loss_weight, soft_weight=sw, grad_scale=1.0 / ws, inv_world=1.0 / ws)
+        lp.configure(loss_weight=head.loss_weight, soft_weight=sw, grad_scale=self.loss_scale / ws, inv_world=1.0 / ws)
         plan.img.copy_(img, non_blocking=True)
         plan.assign_ops.run()
         work = None

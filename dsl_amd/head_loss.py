@@ -58,6 +58,9 @@ class FcosLossPlan:
                      losses=self.losses)
         self.desc.ld_cls, self.desc.ld_rc = self.LD_CLS, self.LD_RC
         self.desc.ld_gcls, self.desc.ld_grc = self.LD_GCLS, self.LD_GRC
+        need = L.lib.dsl_fcos_workspace_bytes(C.byref(self.desc))
+        self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.desc.workspace, self.desc.workspace_bytes = L.ptr(self.ws), need
 
     # -- ground truth upload (host lists -> one pinned staging copy) --------------------------------
     def set_targets(self, gt_bboxes, gt_labels, gt_bboxes_ignore=None):

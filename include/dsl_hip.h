@@ -196,7 +196,10 @@ typedef struct dsl_fcos_desc {
   float soft_weight;                   /* effective sisoft weight (0 = off) */
   float grad_scale;                    /* d(total)/d(each loss), normally 1 */
   float inv_world;                     /* 1/world_size: norm[] holds the SUM over ranks of stats[0:2] */
+  void* workspace;                     /* >= dsl_fcos_workspace_bytes(d): block records of the loss / num_pos sums, which */
+  size_t workspace_bytes;              /* are added up in a fixed order (bit-identical results from run to run) */
 } dsl_fcos_desc;
+size_t dsl_fcos_workspace_bytes(const dsl_fcos_desc* d);
 
 int dsl_fcos_points(const dsl_fcos_desc* d, float* points /* [P][2] */, void* stream);
 int dsl_fcos_assign(const dsl_fcos_desc* d, void* stream);

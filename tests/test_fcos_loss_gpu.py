@@ -132,3 +132,33 @@ def test_loss_scale_relu_chain_vs_oracle():
     assert torch.allclose(plan.g_scales.cpu(), scales.grad, rtol=1e-3, atol=1e-5)
     gr = flat_levels([r.grad for r in raw])
     assert torch.allclose(plan.g_rc.float().cpu()[:, :4], gr, rtol=2 ** -7, atol=1e-5)
+
+
+def test_points_and_deterministic_sums():
+    """dsl_fcos_points == get_points (anchor_free_head.py:287-321, fcos_head.py:550-560); the loss / num_pos sums are added
+    in a fixed order (block records + one finalize pass): bit-identical on a re-run."""
+    import ctypes as C
+    from dsl_amd import _lib as L
+    from dsl_amd.head_loss import FcosLossPlan
+    from oracle import fcos_oracle as O
+    sizes = [(25, 42), (13, 21), (7, 11), (4, 6), (2, 3)]
+    plan = FcosLossPlan(2, sizes, 'cuda')
+    P = sum(h * w for h, w in sizes)
+    pts = torch.empty(P, 2, device='cuda')
+    L.check(L.lib.dsl_fcos_points(C.byref(plan.desc), L.ptr(pts), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(pts.cpu(), torch.cat(O.get_points(sizes)))
+    g = torch.Generator().manual_seed(2)
+    rng = np.random.RandomState(2)
+    cls = [torch.randn(2, 80, h, w, generator=g) - 2 for h, w in sizes]
+    reg = [torch.rand(2, 4, h, w, generator=g) * 4 for h, w in sizes]
+    ctr = [torch.randn(2, 1, h, w, generator=g) for h, w in sizes]
+    gtb = [T(O.synth_boxes(rng, 6, H=200, W=336, lo=8, hi=150)) for _ in range(2)]
+    gtl = [T(rng.randint(0, 80, len(b)).astype('int64')) for b in gtb]
+    runs = []
+    for _ in range(2):
+        p = run_plan(sizes, 2, cls, reg, ctr, gtb, gtl, None)
+        runs.append((p.losses.clone(), p.stats.clone(), p.g_scales.clone(), p.g_cls.clone(), p.g_rc.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert float(runs[0][1][0]) > 0 and float(runs[0][1][2:].abs().sum()) == 0
