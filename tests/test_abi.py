@@ -23,12 +23,23 @@ def test_header_symbols_exported():
     assert isinstance(_lib.lib.dsl_last_error(), bytes)
 
 
-def test_descriptor_sizes_match_header_layout():
-    """ctypes mirrors must have the C struct sizes (natural alignment, LP64)."""
+def test_descriptor_sizes_match_header_layout(tmp_path):
+    """The ctypes mirrors have exactly the sizes (and the offsets of their last fields) that a C compiler gives the
+    structs of include/dsl_hip.h: the header is compiled with gcc and asked."""
+    import subprocess
     from dsl_amd import _lib as L
-    assert ctypes.sizeof(L.ConvDesc) == 2 * 4 + 8 * 5 * 4 + 13 * 4 + 4 + 9 * 8     # 4 bytes padding before the pointers
-    assert ctypes.sizeof(L.Op) == 4 + 7 * 4 + 8 + 4 * 8 + 2 * 8
-    assert ctypes.sizeof(L.GnDesc) % 8 == 0 and ctypes.sizeof(L.FcosDesc) % 8 == 0
+    pairs = [('dsl_conv_desc', L.ConvDesc, 'cs_real'), ('dsl_wgrad_desc', L.WgradDesc, 'workspace_bytes'),
+             ('dsl_gn_desc', L.GnDesc, 'workspace_bytes'), ('dsl_fcos_desc', L.FcosDesc, 'workspace_bytes'),
+             ('dsl_det_desc', L.DetDesc, 'workspace_bytes'), ('dsl_pack_item', L.PackItem, 'tiles_co'), ('dsl_op', L.Op, 'l')]
+    src = tmp_path / 'sizes.c'
+    body = ''.join(f'  printf("%zu %zu\\n", sizeof({c}), offsetof({c}, {f}));\n' for c, _, f in pairs)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dsl_hip.h"\nint main(void) {\n' + body + '  return 0;\n}\n')
+    exe = tmp_path / 'sizes'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    for i, (c, t, f) in enumerate(pairs):
+        assert ctypes.sizeof(t) == int(out[2 * i]), (c, ctypes.sizeof(t), out[2 * i])
+        assert getattr(t, f).offset == int(out[2 * i + 1]), (c, f)
 
 
 def test_errors_are_reported_not_swallowed():

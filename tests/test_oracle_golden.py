@@ -180,12 +180,11 @@ def test_adaptive_thresholds_match_reference_adathres():
     hook = UnlabelPredHook()
     for rnd in d['rounds']:
         by_c = {}
-        hook.bank = {}
+        hook.bank.entries.clear()              # the round's files replace the previous round's; the thresholds carry over
         for k, (tags, scores) in enumerate(rnd['per_img']):
             for t, s in zip(tags, scores):
                 by_c.setdefault(idx[t], []).append(s)
-            hook.bank[f'im{k}'] = dict(rects=np.zeros((len(tags), 4), np.int64), tags=np.array([idx[t] for t in tags], np.int64),
-                                       scores=np.array(scores, np.float64))
+            hook.bank.put(f'im{k}', np.zeros((len(tags), 4), np.int64), [idx[t] for t in tags], scores)
         thr, w = adaptive_thresholds(by_c, prev)
         assert {d['names'][c] for c in thr} == set(rnd['thres'])
         for name, v in rnd['thres'].items():
