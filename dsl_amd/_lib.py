@@ -21,6 +21,8 @@ CONV_RELU_OUT, CONV_RELU_IN, CONV_OUT_F32, CONV_MASK_FIRST, CONV_MASK_LAST, CONV
     CONV_SMALL_C = 1, 2, 4, 8, 16, 32, 64
 (OP_CONV, OP_WGRAD, OP_GN_FWD, OP_GN_BWD, OP_MAXPOOL, OP_SUM2X2, OP_COLSUM, OP_MEMSET, OP_PACK_IMAGE,
  OP_ASSIGN, OP_LOSS, OP_FORK, OP_JOIN, OP_WGRAD_GROUP, OP_RECORD, OP_WAIT) = range(1, 17)
+OP_RLA = 17
+(RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST) = range(2, 8)
 MAX_GROUP = 8
 
 
@@ -33,7 +35,7 @@ class ConvDesc(C.Structure):
                 ('mode', C.c_int32), ('os', C.c_int32), ('flags', C.c_int32),
                 ('src', C.c_void_p), ('wgt', C.c_void_p), ('dst', C.c_void_p),
                 ('scale', C.c_void_p), ('bias', C.c_void_p), ('addend', C.c_void_p), ('mask', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('cs_real', C.c_int32)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('cs_real', C.c_int32), ('lds', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -43,7 +45,8 @@ class WgradDesc(C.Structure):
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
                 ('splits', C.c_int32),
                 ('dy', C.c_void_p), ('x', C.c_void_p), ('scale', C.c_void_p), ('dw', C.c_void_p),
-                ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+                ('ldx', C.c_int32), ('shared', C.c_int32)]
 
 
 class GnDesc(C.Structure):
@@ -90,6 +93,16 @@ class PackItem(C.Structure):
                 ('block_start', C.c_int32), ('tiles_ci', C.c_int32), ('tiles_co', C.c_int32), ('pad_', C.c_int32)]
 
 
+class RlaDesc(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 8), ('f', C.c_float * 2), ('rows', C.c_int64), ('p', C.c_void_p * 10)]
+
+
+class BnPostItem(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('dw', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('gamma', C.c_void_p),
+                ('mean', C.c_void_p), ('var', C.c_void_p), ('rows', C.c_int32), ('k', C.c_int32), ('row_start', C.c_int32),
+                ('pad_', C.c_int32)]
+
+
 class Op(C.Structure):
     _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 7), ('desc', C.c_void_p),
                 ('p', C.c_void_p * 4), ('l', C.c_int64 * 2)]
@@ -100,6 +113,8 @@ lib.dsl_wgrad_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_wgrad_group_workspace_bytes'):
     lib.dsl_wgrad_group_workspace_bytes.restype = C.c_size_t
 lib.dsl_conv2d_workspace_bytes.restype = C.c_size_t
+if hasattr(lib, 'dsl_bn_tanh_bwd_workspace_bytes'):
+    lib.dsl_bn_tanh_bwd_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_fcos_workspace_bytes'):
     lib.dsl_fcos_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_groupnorm_workspace_bytes'):
@@ -111,6 +126,12 @@ _SIGS = {
     'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_workspace_bytes': [_vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
     'dsl_wgrad_workspace_bytes': [_vp], 'dsl_wgrad_group_workspace_bytes': [_vp, _i], 'dsl_conv2d_wgrad_group': [_vp, _i, _vp],
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
+    'dsl_maxpool3x3s2_ld': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'dsl_avgpool2x2': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    'dsl_avgpool2x2_bwd': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    'dsl_bn_tanh_fwd': [_vp, _i, _vp, _vp, _vp, _i, _l, _i, _vp], 'dsl_bn_tanh_bwd_workspace_bytes': [_l, _i],
+    'dsl_bn_tanh_bwd': [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
+    'dsl_bn_fold': [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp], 'dsl_bn_wgrad_post': [_vp, _i, _i, _f, _vp], 'dsl_rla_op': [_vp, _vp],
     'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp], 'dsl_groupnorm_workspace_bytes': [_vp],
     'dsl_sum2x2': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], 'dsl_colsum': [_vp, _vp, _l, _i, _i, _vp],
     'dsl_fcos_points': [_vp, _vp, _vp], 'dsl_fcos_workspace_bytes': [_vp], 'dsl_fcos_assign': [_vp, _vp], 'dsl_fcos_loss': [_vp, _vp],

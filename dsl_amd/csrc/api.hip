@@ -99,7 +99,8 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
       case DSL_OP_WGRAD_GROUP: rc = dsl_conv2d_wgrad_group((const dsl_wgrad_desc*)o.desc, o.i[0], stream); break;
       case DSL_OP_GN_FWD: rc = dsl_groupnorm_relu_fwd((const dsl_gn_desc*)o.desc, stream); break;
       case DSL_OP_GN_BWD: rc = dsl_groupnorm_relu_bwd((const dsl_gn_desc*)o.desc, stream); break;
-      case DSL_OP_MAXPOOL: rc = dsl_maxpool3x3s2(o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], stream); break;
+      case DSL_OP_MAXPOOL: rc = dsl_maxpool3x3s2_ld(o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] > 0 ? o.i[4] : o.i[3], stream); break;
+      case DSL_OP_RLA: rc = dsl_rla_op((const dsl_rla_desc*)o.desc, stream); break;
       case DSL_OP_SUM2X2: rc = dsl_sum2x2(o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], stream); break;
       case DSL_OP_COLSUM: rc = dsl_colsum(o.p[0], (float*)o.p[1], (long)o.l[0], o.i[0], o.i[1], stream); break;
       case DSL_OP_MEMSET:

@@ -28,6 +28,7 @@ struct ConvK {
   int pxstart[DSL_MAX_SEG + 1];
   long long soff[DSL_MAX_SEG], doff[DSL_MAX_SEG], aoff[DSL_MAX_SEG];   // segment starts, in pixels
   int cs, cd, ldd, lda, ldm, kh, kw, stride, pad, mode, os, flags;
+  int lds;                            // source pixel stride in elements (>= cs: the source may be a channel slice of wider rows)
   int ktiles, kc;
   int ident;                          // 1: destination pixel index == compute-grid pixel index (os 1, same sizes)
   int dbg;                            // ablation knobs, compiled in only by tools/build_ablate.sh (-DDSL_ABLATE_BUILD; DSL_ABLATE env)
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvK p) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (ok) {
         const long long pix = pr[i].base + (long long)sy * pr[i].sw + sx;
-        v = *reinterpret_cast<const u32x4*>(p.src + pix * p.cs + coff);
+        v = *reinterpret_cast<const u32x4*>(p.src + pix * p.lds + coff);
       }
       rx[i] = v;
     }
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_glds_kernel(const ConvK p
         }
       }
       ok = ok && (unsigned)sy < (unsigned)sh && (unsigned)sx < (unsigned)sw;
-      const long long off = ((long long)(r_base[i] + sy * sw + sx)) * p.cs + coff;
+      const long long off = ((long long)(r_base[i] + sy * sw + sx)) * p.lds + coff;
       const gptr_t g = ok ? (gptr_t)(p.src + off) : zero;
       __builtin_amdgcn_global_load_lds(g, (lptr_t)(stage + TILE_W + (i * RPP + wave * 8) * 128), 16, 0, 0);
     }
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
 
   // buffer resources: base shifted back by `margin` so that every VALID tap has a non-negative per-lane offset
   // (the hardware range-checks the per-lane offset, not the scalar one)
-  const unsigned margin = (unsigned)(p.kw * p.cs * 2);
+  const unsigned margin = (unsigned)(p.kw * p.lds * 2);
   const __amdgpu_buffer_rsrc_t rs_src =
       __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.src) - margin), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, 0x7fffffff, 0x00020000);
@@ -716,9 +717,9 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
       if (ok && (unsigned)sx < (unsigned)sw) m |= 0x100u << s_;
     }
     r_mask[i] = m;
-    const unsigned pitch = (unsigned)(sw * p.cs * 2);
+    const unsigned pitch = (unsigned)(sw * p.lds * 2);
     r_step[i] = p.mode == 0 ? pitch : 0u - pitch;
-    const unsigned base = (unsigned)(((int)(p.soff[seg]) + img * sh * sw + row0 * sw + col0) * p.cs + chunk * 8) * 2u + margin;
+    const unsigned base = (unsigned)(((int)(p.soff[seg]) + img * sh * sw + row0 * sw + col0) * p.lds + chunk * 8) * 2u + margin;
     r_cur[i] = base + (unsigned)tap_r * r_step[i];
   }
   const unsigned w_voff = (unsigned)(lrow * (int)p.wrow + chunk * 8) * 2u;
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
     unsigned char* stage = smem + ld_slot * STAGE;
     const bool live = kt_next < kt1;
     const unsigned sel = live ? ((1u << tap_r) | (0x100u << tap_s)) : 0xffffffffu;
-    const unsigned s_off = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.cs * 2 + cidx * 128);
+    const unsigned s_off = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds * 2 + cidx * 128);
     const unsigned wv = live ? w_voff : 0x80000000u;
     int s_tr = 0, s_ts = 0;
     bool s_ok = false;
@@ -953,6 +954,7 @@ struct WgK {
   int gx, gy, splits;       // v2: workgroup grid (cout tiles, column tiles) and split count for the XCD-aware 1-D launch
   int chunk;                // v2: consecutive work items (split-major) per XCD
   int group;                // v2: convolutions sharing this geometry in one launch (dsl_conv2d_wgrad_group)
+  int ldx;                  // pixel stride of X in elements (>= cs)
   int cyp;                  // v2: cy rounded up to the cout tile (partial-tile rows in the workspace); dY columns >= cy read as zero
   const uint16_t* dyv[DSL_MAX_GROUP];
   const uint16_t* xv[DSL_MAX_GROUP];
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK p) {
         const int sy = (int)y * p.stride + tr - p.pad, sx = (int)x * p.stride + ts - p.pad;
         if ((unsigned)sy < (unsigned)p.sh[seg] && (unsigned)sx < (unsigned)p.sw[seg]) {
           const long long pix = p.xoff[seg] + ((long long)img * p.sh[seg] + sy) * p.sw[seg] + sx;
-          v = *reinterpret_cast<const u32x4*>(p.x + pix * p.cs + ci0 + xchunk * 8);
+          v = *reinterpret_cast<const u32x4*>(p.x + pix * p.ldx + ci0 + xchunk * 8);
         }
       }
       rx[i] = v;
@@ -1373,7 +1375,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
           const uint32_t x = rem - y * t.d2;
           const int sy = (int)y * p.stride + tr - p.pad, sx = (int)x * p.stride + ts - p.pad;
           if ((unsigned)sy < (unsigned)t.sh && (unsigned)sx < (unsigned)t.sw)
-            my_off = (int)((t.xoff + ((long long)img * t.sh + sy) * t.sw + sx) * p.cs + ci0);
+            my_off = (int)((t.xoff + ((long long)img * t.sh + sy) * t.sw + sx) * p.ldx + ci0);
         }
       }
       int gx[LX];
@@ -1520,7 +1522,8 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
   long long src_px = 0;
   for (int sg = 0; sg < d->nseg; ++sg) src_px += (long long)d->n * d->sh[sg] * d->sw[sg];
   // the DMA kernels address the source with 32-bit buffer offsets and per-axis tap masks
-  const bool dma_ok = conv_v2_only(d) || (d->kh <= 8 && d->kw <= 8 && src_px * d->cs * 2 + (long long)d->kw * d->cs * 2 < 0x7fff0000LL);
+  const long long lds_ = d->lds > 0 ? d->lds : d->cs;
+  const bool dma_ok = conv_v2_only(d) || (d->kh <= 8 && d->kw <= 8 && src_px * lds_ * 2 + (long long)d->kw * lds_ * 2 < 0x7fff0000LL);
   const bool smallc_pipe = smallc && d->cd_pad % 64 == 0 && !getenv("DSL_STEM_V1");    // stem: pipelined kernel, 64-cout tile
   const bool v1_only = (smallc && !smallc_pipe) || (d->flags & DSL_CONV_RELU_IN) || !dma_ok;
   if (!v1_only && force != 15) {
@@ -1634,6 +1637,8 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   for (int s = 0; s < d->nseg; ++s)
     if (d->gh[s] != d->dh[s] || d->gw[s] != d->dw[s]) k.ident = 0;
   k.cs = d->cs; k.cd = d->cd; k.ldd = d->ldd; k.lda = d->lda; k.ldm = d->ldm;
+  k.lds = d->lds > 0 ? d->lds : d->cs;
+  DSL_CHECK(k.lds >= d->cs && k.lds % 8 == 0, "dsl_conv2d: lds=%d must be >= cs=%d and a multiple of 8", k.lds, d->cs);
   k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.mode = d->mode; k.os = d->os;
   k.flags = d->flags;
   if (smallc) {
@@ -1834,6 +1839,7 @@ extern "C" int dsl_colsum(const void* x, float* out, long rows, int c, int ld, v
 int dsl_colsum_acc(const void* x, float* out, long rows, int c, int ld, void* stream);   // no memset: out += column sums
 
 static bool wgrad_same_geometry(const dsl_wgrad_desc* a, const dsl_wgrad_desc* b) {
+  if (a->ldx != b->ldx || a->shared != b->shared) return false;
   if (a->nseg != b->nseg || a->n != b->n || a->cs != b->cs || a->cy != b->cy || a->cd != b->cd || a->kh != b->kh ||
       a->kw != b->kw || a->stride != b->stride || a->pad != b->pad)
     return false;
@@ -1886,7 +1892,9 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     xo += (long long)d->n * d->sh[s] * d->sw[s];
   }
   DSL_CHECK(px < (1 << 20), "dsl_conv2d_wgrad: %d pixels exceed the 2^20 fast-division range", px);
-  DSL_CHECK(xo * d->cs < (1LL << 31), "dsl_conv2d_wgrad: X has more than 2^31 elements");
+  const int ldx = d->ldx > 0 ? d->ldx : d->cs;
+  DSL_CHECK(ldx >= d->cs && ldx % 8 == 0, "dsl_conv2d_wgrad: ldx=%d must be >= cs=%d and a multiple of 8", ldx, d->cs);
+  DSL_CHECK(xo * ldx < (1LL << 31), "dsl_conv2d_wgrad: X has more than 2^31 elements");
   k.pxstart[d->nseg] = px;
   k.cs = d->cs; k.cy = d->cy; k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad;
   k.ktiles = ktiles;
@@ -1895,6 +1903,7 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
   k.krow = (long long)d->kh * d->kw * d->cs;
   k.dy = (const uint16_t*)d->dy; k.x = (const uint16_t*)d->x; k.ws = (float*)d->workspace;
   k.group = count;
+  k.ldx = ldx;
   k.cyp = cyp;
   for (int g = 0; g < DSL_MAX_GROUP; ++g) {
     k.dyv[g] = (const uint16_t*)descs[g < count ? g : 0].dy;
@@ -1964,6 +1973,16 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     r.dw[g] = descs[g < count ? g : 0].dw;
     r.scale[g] = descs[g < count ? g : 0].scale;
     r.db[g] = g < count ? descs[g].db : nullptr;
+  }
+  if (d->shared && count > 1) {
+    // the members are applications of ONE convolution (weights shared along a recurrence): their partial tiles are just
+    // more splits of the same dW - [split][member] pairs are contiguous in the workspace
+    for (int g = 1; g < count; ++g)
+      DSL_CHECK(descs[g].dw == d->dw && descs[g].scale == d->scale && !descs[g].db, "dsl_conv2d_wgrad_group: shared members must share dw / scale and have no db");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb * count, 1), dim3(256), 0, st, (const float*)d->workspace, r, splits * count, 1,
+                       cyp, d->cd, k.krow);
+    DSL_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return 0;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb, count), dim3(256), 0, st, (const float*)d->workspace, r, splits, count,
                      cyp, d->cd, k.krow);

@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t max2bf(uint32_t a, uint32_t b) {
   return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
 }
 __global__ void maxpool_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int n, int h,
-                               int w, int c, int oh, int ow) {
+                               int w, int c, int oh, int ow, int ldy) {
   const int c8 = c / 8;
   const long long total = (long long)n * oh * ow * c8;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -47,7 +47,7 @@ __global__ void maxpool_kernel(const uint16_t* __restrict__ x, uint16_t* __restr
         for (int e = 0; e < 4; ++e) m[e] = max2bf(m[e], v[e]);
       }
     }
-    *reinterpret_cast<u32x4*>(y + i * 8) = m;
+    *reinterpret_cast<u32x4*>(y + (i / c8) * ldy + cc * 8) = m;
   }
 }
 
@@ -519,14 +519,18 @@ extern "C" int dsl_pack_image(const float* img, void* out, int n, int h, int w, 
   return 0;
 }
 
+extern "C" int dsl_maxpool3x3s2_ld(const void* x, void* y, int n, int h, int w, int c, int ldy, void* stream);
 extern "C" int dsl_maxpool3x3s2(const void* x, void* y, int n, int h, int w, int c, void* stream) {
-  DSL_CHECK(x && y && c % 8 == 0, "dsl_maxpool3x3s2: bad arguments (C=%d)", c);
+  return dsl_maxpool3x3s2_ld(x, y, n, h, w, c, c, stream);
+}
+extern "C" int dsl_maxpool3x3s2_ld(const void* x, void* y, int n, int h, int w, int c, int ldy, void* stream) {
+  DSL_CHECK(x && y && c % 8 == 0 && ldy >= c && ldy % 8 == 0, "dsl_maxpool3x3s2: bad arguments (C=%d ldy=%d)", c, ldy);
   const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
   const long long total = (long long)n * oh * ow * (c / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
-                     (uint16_t*)y, n, h, w, c, oh, ow);
+                     (uint16_t*)y, n, h, w, c, oh, ow, ldy);
   DSL_LAUNCH_CHECK("maxpool_kernel");
   return 0;
 }

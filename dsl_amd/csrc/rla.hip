@@ -1,0 +1,289 @@
+// Memory-bound layers of the RLA_ResNet backbone (mmdet/models/backbones/resnet_rla.py of the reference): the
+// recurrent-layer-aggregation path h <- conv3x3(tanh(BN(h + conv1x1(out)))) next to every bottleneck (:289-327), the 2x2
+// average pool of h at stage transitions (:98-100,129-130), and what TRAINABLE eval-mode BatchNorm affine parameters need (the reference freezes only
+// the statistics, norm_eval, :380-388): the per-step fold gamma/sqrt(var+eps), and the (gamma, beta) gradients of a
+// conv -> BN pair from the unscaled weight gradient.
+// All tensors NHWC bf16 with explicit row strides ("ld", in elements): the block input of RLA is cat(x, h), kept as ONE
+// buffer [pixel][C + 128] = [x | h (32) | zeros] so that conv1 reads it as an ordinary source.
+#include "common.hpp"
+
+namespace {
+
+// ---- 2x2 stride-2 average pool (nn.AvgPool2d((2, 2), stride=(2, 2))) and its backward ------------------------------------
+__global__ void avgpool2_kernel(const uint16_t* __restrict__ x, int ldx, uint16_t* __restrict__ y, int ldy, int n, int h, int w,
+                                int c8) {
+  const int oh = h / 2, ow = w / 2;
+  const long long total = (long long)n * oh * ow * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % c8) * 8;
+    long long t = i / c8;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const int b = (int)(t / oh);
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((long long)b * h + 2 * oy + dy) * w + 2 * ox + dx) * ldx + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[2 * e] += bflo(v[e]);
+          a[2 * e + 1] += bfhi(v[e]);
+        }
+      }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(a[2 * e] * 0.25f, a[2 * e + 1] * 0.25f);
+    *reinterpret_cast<u32x4*>(y + (((long long)b * oh + oy) * ow + ox) * ldy + k) = o;
+  }
+}
+
+__global__ void avgpool2_bwd_kernel(const uint16_t* __restrict__ gy, int ldgy, uint16_t* __restrict__ gx, int ldgx, int n, int h,
+                                    int w, int c8) {
+  const int oh = h / 2, ow = w / 2;
+  const long long total = (long long)n * h * w * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % c8) * 8;
+    long long t = i / c8;
+    const int x_ = (int)(t % w);
+    t /= w;
+    const int y_ = (int)(t % h);
+    const int b = (int)(t / h);
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (y_ / 2 < oh && x_ / 2 < ow) {      // odd trailing rows / columns are outside every pooling window
+      const u32x4 v = *reinterpret_cast<const u32x4*>(gy + (((long long)b * oh + y_ / 2) * ow + x_ / 2) * ldgy + k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(bflo(v[e]) * 0.25f, bfhi(v[e]) * 0.25f);
+    }
+    *reinterpret_cast<u32x4*>(gx + (((long long)b * h + y_) * w + x_) * ldgx + k) = o;
+  }
+}
+
+// ---- t = tanh(u * scale[c] + bias[c])   (eval-mode BN folded to scale / bias) ---------------------------------------------
+__global__ void bn_tanh_kernel(const uint16_t* __restrict__ u, int ldu, const float* __restrict__ scale,
+                               const float* __restrict__ bias, uint16_t* __restrict__ t, int ldt, long long rows, int c8) {
+  const long long total = rows * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c8;
+    const int k = (int)(i - r * c8) * 8;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(u + r * ldu + k);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = tanhf(bflo(a[e]) * scale[k + 2 * e] + bias[k + 2 * e]);
+      const float hi = tanhf(bfhi(a[e]) * scale[k + 2 * e + 1] + bias[k + 2 * e + 1]);
+      o[e] = pack2bf(lo, hi);
+    }
+    *reinterpret_cast<u32x4*>(t + r * ldt + k) = o;
+  }
+}
+
+// backward: g_v = g_t (1 - t^2); g_u = g_v * scale;  block records of dgamma = sum g_v (u - mean) invstd, dbeta = sum g_v
+constexpr int BT_T = 256, BT_ROWS = 256;       // rows per block
+__global__ __launch_bounds__(BT_T) void bn_tanh_bwd_kernel(const uint16_t* __restrict__ gt, int ldgt, const uint16_t* __restrict__ t,
+                                                            int ldt, const uint16_t* __restrict__ u, int ldu,
+                                                            const float* __restrict__ scale, const float* __restrict__ mean,
+                                                            const float* __restrict__ var, float eps, uint16_t* __restrict__ gu,
+                                                            int ldgu, float* __restrict__ rec, long long rows, int c8) {
+  __shared__ float sh[BT_T * 16];
+  const int c = c8 * 8;
+  const int rpi = BT_T / c8;                      // rows per iteration
+  const int chunk = threadIdx.x % c8, prow = threadIdx.x / c8;
+  const int k = chunk * 8;
+  float sc[8], mu[8], is[8], dg[8], db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = scale[k + e];
+    mu[e] = mean[k + e];
+    is[e] = rsqrtf(var[k + e] + eps);
+    dg[e] = db[e] = 0.f;
+  }
+  const long long r0 = (long long)blockIdx.x * BT_ROWS, r1 = min(r0 + (long long)BT_ROWS, rows);
+  if (prow < rpi)
+    for (long long r = r0 + prow; r < r1; r += rpi) {
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(gt + r * ldgt + k);
+      const u32x4 tv = *reinterpret_cast<const u32x4*>(t + r * ldt + k);
+      const u32x4 uv = *reinterpret_cast<const u32x4*>(u + r * ldu + k);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float g = (e & 1) ? bfhi(gv[e >> 1]) : bflo(gv[e >> 1]);
+        const float tt = (e & 1) ? bfhi(tv[e >> 1]) : bflo(tv[e >> 1]);
+        const float uu = (e & 1) ? bfhi(uv[e >> 1]) : bflo(uv[e >> 1]);
+        const float gvv = g * (1.f - tt * tt);
+        dg[e] += gvv * (uu - mu[e]) * is[e];
+        db[e] += gvv;
+        o[e] = gvv * sc[e];
+      }
+      *reinterpret_cast<u32x4*>(gu + r * ldgu + k) = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sh[threadIdx.x * 16 + e] = (prow < rpi) ? dg[e] : 0.f;
+    sh[threadIdx.x * 16 + 8 + e] = (prow < rpi) ? db[e] : 0.f;
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += BT_T) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rpi; ++r) {
+      a += sh[(r * c8 + ch / 8) * 16 + (ch % 8)];
+      b += sh[(r * c8 + ch / 8) * 16 + 8 + (ch % 8)];
+    }
+    rec[(long long)blockIdx.x * 2 * c + ch] = a;
+    rec[(long long)blockIdx.x * 2 * c + c + ch] = b;
+  }
+}
+
+// out[v] (+)= sum over blocks of rec[b][v], fixed order; one workgroup
+__global__ __launch_bounds__(256) void rec_sum_kernel(const float* __restrict__ rec, int nblocks, int V, float* __restrict__ out_a,
+                                                      float* __restrict__ out_b, int half, int accumulate) {
+  __shared__ float sh[256];
+  const int Q = 256 / V;
+  const int v = threadIdx.x % V, q = threadIdx.x / V;
+  float a = 0.f;
+  if (q < Q)
+    for (int b = q; b < nblocks; b += Q) a += rec[(long long)b * V + v];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < V) {
+    float t = 0.f;
+    for (int k = 0; k < Q; ++k) t += sh[k * V + threadIdx.x];
+    float* dst = threadIdx.x < half ? out_a + threadIdx.x : out_b + (threadIdx.x - half);
+    *dst = accumulate ? *dst + t : t;
+  }
+}
+
+// ---- eval-mode BN fold: scale = gamma / sqrt(var + eps), bias = beta - mean * scale --------------------------------------
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                               const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ bias, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = gamma[i] * rsqrtf(var[i] + eps);
+  scale[i] = s;
+  bias[i] = beta[i] - mean[i] * s;
+}
+
+// ---- (gamma, beta) gradients of conv -> BN(eval) from the UNSCALED weight gradient ----------------------------------------
+// y = gamma * (conv(x) - mean) * invstd + beta.  With dWu[c][k] = sum_p g_y[p][c] x[p@k] (the weight gradient w.r.t. the raw
+// conv output, no BN scale) and S[c] = sum_p g_y[p][c]:
+//   sum_p g_y[p][c] conv(x)[p][c] = <W[c,:], dWu[c,:]>     (conv is linear in W)
+//   dgamma[c] = (<W[c], dWu[c]> - mean[c] S[c]) * invstd[c],   dbeta[c] = S[c],   dW[c,:] = dWu[c,:] * gamma[c] * invstd[c]
+// - no pre-BN activation has to be kept and nothing is divided by gamma (zero_init_last_bn starts bn3.weight at 0).
+// One workgroup per weight row; dbeta already holds S (the weight-gradient launch's column sum of g_y).
+struct BnPostItem {
+  const float* w; float* dw; float* dgamma; const float* dbeta; const float* gamma; const float* mean; const float* var;
+  int rows, k, row_start, pad_;
+};
+__global__ __launch_bounds__(256) void bn_wgrad_post_kernel(const BnPostItem* __restrict__ items, int n, float eps) {
+  __shared__ float sh[16];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= items[mid].row_start) lo = mid; else hi = mid - 1;
+  }
+  const BnPostItem I = items[lo];
+  const int c = blockIdx.x - I.row_start;
+  const float* w = I.w + (long long)c * I.k;
+  float* dw = I.dw + (long long)c * I.k;
+  float dot = 0.f;
+  for (int i = threadIdx.x * 4; i < I.k; i += 256 * 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + i), b = *reinterpret_cast<const f32x4*>(dw + i);
+    dot += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  }
+  dot = block_sum(dot, sh);
+  const float invstd = rsqrtf(I.var[c] + eps);
+  if (threadIdx.x == 0) I.dgamma[c] = (dot - I.mean[c] * I.dbeta[c]) * invstd;
+  const float s = I.gamma[c] * invstd;
+  for (int i = threadIdx.x * 4; i < I.k; i += 256 * 4) {
+    f32x4 b = *reinterpret_cast<const f32x4*>(dw + i);
+    b *= s;
+    *reinterpret_cast<f32x4*>(dw + i) = b;
+  }
+}
+
+inline int grid_for(long long total, int threads, int cap = 16384) {
+  long long b = (total + threads - 1) / threads;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int dsl_avgpool2x2(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int c, void* stream) {
+  DSL_CHECK(x && y && c % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && h >= 2 && w >= 2, "dsl_avgpool2x2: bad arguments");
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for((long long)n * (h / 2) * (w / 2) * (c / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x, ldx, (uint16_t*)y, ldy, n, h, w, c / 8);
+  DSL_LAUNCH_CHECK("avgpool2_kernel");
+  return 0;
+}
+
+extern "C" int dsl_avgpool2x2_bwd(const void* gy, int ldgy, void* gx, int ldgx, int n, int h, int w, int c, void* stream) {
+  DSL_CHECK(gy && gx && c % 8 == 0 && ldgy % 8 == 0 && ldgx % 8 == 0, "dsl_avgpool2x2_bwd: bad arguments");
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for((long long)n * h * w * (c / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)gy, ldgy, (uint16_t*)gx, ldgx, n, h, w, c / 8);
+  DSL_LAUNCH_CHECK("avgpool2_bwd_kernel");
+  return 0;
+}
+
+extern "C" int dsl_bn_tanh_fwd(const void* u, int ldu, const float* scale, const float* bias, void* t, int ldt, long rows, int c,
+                               void* stream) {
+  DSL_CHECK(u && scale && bias && t && c % 8 == 0 && ldu % 8 == 0 && ldt % 8 == 0, "dsl_bn_tanh_fwd: bad arguments");
+  hipLaunchKernelGGL(bn_tanh_kernel, dim3(grid_for((long long)rows * (c / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)u, ldu, scale, bias, (uint16_t*)t, ldt, (long long)rows, c / 8);
+  DSL_LAUNCH_CHECK("bn_tanh_kernel");
+  return 0;
+}
+
+extern "C" size_t dsl_bn_tanh_bwd_workspace_bytes(long rows, int c) {
+  return (size_t)((rows + BT_ROWS - 1) / BT_ROWS) * 2 * c * sizeof(float);
+}
+
+extern "C" int dsl_bn_tanh_bwd(const void* gt, int ldgt, const void* t, int ldt, const void* u, int ldu, const float* scale,
+                               const float* mean, const float* var, float eps, void* gu, int ldgu, float* dgamma, float* dbeta,
+                               void* workspace, long rows, int c, void* stream) {
+  DSL_CHECK(gt && t && u && scale && mean && var && gu && dgamma && dbeta && workspace, "dsl_bn_tanh_bwd: null pointer");
+  DSL_CHECK(c % 8 == 0 && 2 * c <= 256 && 256 % (2 * c) == 0 && BT_T % (c / 8) == 0, "dsl_bn_tanh_bwd: unsupported channel count %d", c);
+  const int nb = (int)((rows + BT_ROWS - 1) / BT_ROWS);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_tanh_bwd_kernel, dim3(nb), dim3(BT_T), 0, st, (const uint16_t*)gt, ldgt, (const uint16_t*)t, ldt,
+                     (const uint16_t*)u, ldu, scale, mean, var, eps, (uint16_t*)gu, ldgu, (float*)workspace, (long long)rows, c / 8);
+  hipLaunchKernelGGL(rec_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, nb, 2 * c, dgamma, dbeta, c, 0);
+  DSL_LAUNCH_CHECK("bn_tanh_bwd_kernel");
+  return 0;
+}
+
+extern "C" int dsl_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                           float* bias, int n, void* stream) {
+  DSL_CHECK(gamma && beta && mean && var && scale && bias && n > 0, "dsl_bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, scale, bias, n);
+  DSL_LAUNCH_CHECK("bn_fold_kernel");
+  return 0;
+}
+
+extern "C" int dsl_bn_wgrad_post(const dsl_bn_post_item* items_dev, int n, int total_rows, float eps, void* stream) {
+  static_assert(sizeof(dsl_bn_post_item) == sizeof(BnPostItem), "item layout");
+  DSL_CHECK(items_dev && n > 0 && total_rows > 0, "dsl_bn_wgrad_post: bad arguments");
+  hipLaunchKernelGGL(bn_wgrad_post_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, (const BnPostItem*)items_dev, n, eps);
+  DSL_LAUNCH_CHECK("bn_wgrad_post_kernel");
+  return 0;
+}
+
+extern "C" int dsl_rla_op(const dsl_rla_desc* d, void* stream) {
+  DSL_CHECK(d != nullptr, "dsl_rla_op: null descriptor");
+  const int32_t* i = d->i;
+  void* const* p = d->p;
+  switch (d->kind) {
+    case DSL_RLA_AVGPOOL: return dsl_avgpool2x2(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], stream);
+    case DSL_RLA_AVGPOOL_BWD: return dsl_avgpool2x2_bwd(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], stream);
+    case DSL_RLA_BN_TANH: return dsl_bn_tanh_fwd(p[0], i[0], (const float*)p[1], (const float*)p[2], p[3], i[1], (long)d->rows, i[2], stream);
+    case DSL_RLA_BN_TANH_BWD:
+      return dsl_bn_tanh_bwd(p[0], i[0], p[1], i[1], p[2], i[2], (const float*)p[3], (const float*)p[4], (const float*)p[5], d->f[0],
+                             p[6], i[3], (float*)p[7], (float*)p[8], p[9], (long)d->rows, i[4], stream);
+    case DSL_RLA_BN_FOLD:
+      return dsl_bn_fold((const float*)p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], d->f[0], (float*)p[4],
+                         (float*)p[5], i[0], stream);
+    case DSL_RLA_BN_POST: return dsl_bn_wgrad_post((const dsl_bn_post_item*)p[0], i[0], i[1], d->f[0], stream);
+    default: dsl_set_error("dsl_rla_op: unknown kind %d", d->kind); return -1;
+  }
+}

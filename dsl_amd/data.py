@@ -74,6 +74,7 @@ class SyntheticSemiLoader:
         self._len = iters_per_epoch or max(n_labeled, n_unlabeled)
         self._epoch, self._pos = 0, 0
         self._cache = {}
+        self.CLASSES = tuple(bank.class_names) if bank.class_names else tuple(f'class_{i}' for i in range(bank.num_classes))
         self.unlabeled = SyntheticUnlabeled(self)
         rng = np.random.RandomState(2024 + self.seed)
         self._gt = []

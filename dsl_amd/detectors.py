@@ -108,12 +108,23 @@ class ResNet(nn.Module):
 
 @BACKBONES.register_module()
 class RLA_ResNet(nn.Module):
-    def __init__(self, *a, **kw):
+    """mmdet/models/backbones/resnet_rla.py:140-388 with the arguments of configs/fcos_semi/RLA_*.py:3-13: layers
+    [3, 4, 6, 3], rla_channel 32, no SE / ECA, frozen_stages 1, norm_eval, style 'pytorch' (the 3x3 convolutions stride).
+    The computation is dsl_amd/engine_rla.py; this class validates the configuration and names the checkpoint."""
+    backbone_kind = 'rla'
+
+    def __init__(self, block=None, layers=(3, 4, 6, 3), num_classes=1000, rla_channel=32, SE=False, ECA=None,
+                 frozen_stages=-1, norm_eval=True, style='pytorch', zero_init_last_bn=True, groups=1, width_per_group=64,
+                 replace_stride_with_dilation=None, norm_layer=None, pretrained=None, init_cfg=None, **kw):
         super().__init__()
-        raise NotImplementedError(
-            'RLA_ResNet (mmdet/models/backbones/resnet_rla.py) is a SURVEY.md §8(f) "next" row; build the DSL config '
-            "with --cfg-options model.backbone.type=ResNet model.backbone.depth=50 model.backbone.style=caffe "
-            'model.backbone.norm_cfg="dict(type=\'BN\', requires_grad=False)"')
+        _expect(block is None and list(layers) == [3, 4, 6, 3] and rla_channel == 32, 'RLA_Bottleneck, layers [3, 4, 6, 3], 32 RLA channels')
+        _expect(not SE and ECA is None and groups == 1 and width_per_group == 64 and replace_stride_with_dilation is None
+                and norm_layer is None, 'no SE / ECA, no groups, no dilation, BatchNorm2d')
+        _expect(frozen_stages == 1 and norm_eval and style == 'pytorch', "frozen_stages=1, norm_eval=True, style='pytorch'")
+        self.zero_init_last_bn = zero_init_last_bn
+        self.pretrained_checkpoint = pretrained
+        if isinstance(init_cfg, dict) and init_cfg.get('type') == 'Pretrained':
+            self.pretrained_checkpoint = init_cfg['checkpoint']
 
 
 @NECKS.register_module()
@@ -243,7 +254,7 @@ class FCOS(nn.Module):
         bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
         self.bbox_head = build_head(bbox_head)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
-        self.store = ParamStore(self.bbox_head.num_classes, 'cpu')
+        self.store = ParamStore(self.bbox_head.num_classes, 'cpu', backbone=getattr(self.backbone, 'backbone_kind', 'resnet'))
         self.store.init_reference_style(0)
         self._params = None
         self._engine = None

@@ -145,21 +145,23 @@ class Plan:
         return t
 
     def _conv(self, spec, src, dst, n, in_hw, out_hw, *, relu=False, addend=None, add_hw=None, flags=0, dst_ld=None,
-              small_c=False):
+              small_c=False, cs=None, lds=0, lda=None, affine=True):
+        """cs: source channels read per tap (default: the stored weight rows' cin_store); lds: source pixel stride when the
+        source is a channel slice of wider rows; lda: addend row stride (default cout); affine=False: no BN fold / bias."""
         st = self.store
         scale = bias = None
-        if spec.bn:
+        if affine and spec.bn:
             scale, bias = st.bn_ptrs(spec.bn)
-        elif spec.bias:
+        elif affine and spec.bias:
             bias = st.t32_ptr(spec.name + '.bias')
         f = flags | (L.CONV_RELU_OUT if relu else 0) | (L.CONV_SMALL_C if small_c else 0)
         if add_hw is not None:
             f |= L.CONV_ADD_UPSAMPLE
         return ops.conv_desc(src, st.w16_ptr(spec), dst, n=n, grid=out_hw, src_hw=in_hw, dst_hw=out_hw,
-                             cs=8 if small_c else spec.cin, cd=spec.cout, cd_pad=spec.cout_pad,
+                             cs=8 if small_c else (cs or spec.cin_store), cd=spec.cout, cd_pad=spec.cout_pad,
                              ldd=dst_ld or spec.cout, kh=spec.k, kw=spec.k, stride=spec.stride, pad=spec.pad,
-                             flags=f, scale=scale, bias=bias, addend=addend, lda=spec.cout, add_hw=add_hw,
-                             workspace=None if small_c else self.conv_ws)
+                             flags=f, scale=scale, bias=bias, addend=addend, lda=lda or spec.cout, add_hw=add_hw,
+                             workspace=None if small_c else self.conv_ws, lds=lds)
 
     def _build_forward(self):
         st, N, H, W, f = self.store, self.N, self.H, self.W, self.fwd
@@ -170,30 +172,14 @@ class Plan:
         s1 = self.buf('stem', N, h1, w1, 64)
         f.conv(self._conv(cv['backbone.conv1'], x8, s1, N, [(H, W)], [(h1, w1)], relu=True, small_c=True))
         h, w = conv_out(h1, 3, 2, 1), conv_out(w1, 3, 2, 1)
-        x = self.buf('pool', N, h, w, 64)
-        f.maxpool(s1, x, N, h1, w1, 64)
-        self.blocks = []        # per block: dict(xin, a1, a2, out, idt, in_hw, out_hw, prefix, stride)
-        self.stage_out = []
-        for li, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
-            for b in range(nb):
-                p = f'backbone.layer{li + 1}.{b}'
-                c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
-                s = c1.stride
-                oh, ow = conv_out(h, 1, s, 0), conv_out(w, 1, s, 0)
-                a1 = self.buf(p + '.a1', N, oh, ow, planes)
-                a2 = self.buf(p + '.a2', N, oh, ow, planes)
-                out = self.buf(p + '.out', N, oh, ow, planes * 4)
-                f.conv(self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True))
-                f.conv(self._conv(c2, a1, a2, N, [(oh, ow)], [(oh, ow)], relu=True))
-                idt = x
-                if b == 0:
-                    idt = self.buf(p + '.idt', N, oh, ow, planes * 4)
-                    f.conv(self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)]))
-                f.conv(self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt))
-                self.blocks.append(dict(prefix=p, xin=x, a1=a1, a2=a2, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
-                                        stage=li, b=b, planes=planes))
-                x, h, w = out, oh, ow
-            self.stage_out.append((x, (h, w)))
+        self.stage_out, self.stage_ld = [], []      # per stage: (tensor / pointer of the output's first channel, (h, w)), row stride
+        if st.backbone == 'rla':
+            from . import engine_rla
+            engine_rla.build_forward(self, s1, h1, w1)
+        else:
+            x = self.buf('pool', N, h, w, 64)
+            f.maxpool(s1, x, N, h1, w1, 64)
+            self._fwd_resnet(x, h, w)
         # ---- FPN (start_level=1) ----
         (c3, hw3), (c4, hw4), (c5, hw5) = self.stage_out[1], self.stage_out[2], self.stage_out[3]
         hw6 = (conv_out(hw5[0], 3, 2, 1), conv_out(hw5[1], 3, 2, 1))
@@ -206,9 +192,10 @@ class Plan:
             self.seg_off.append(self.seg_off[-1] + N * a * b)
         lat = [self.buf(f'lat{i}', N, hw[0], hw[1], 256) for i, hw in enumerate((hw3, hw4, hw5))]
         lc = [cv[f'neck.lateral_convs.{i}.conv'] for i in range(3)]
-        f.conv(self._conv(lc[2], c5, lat[2], N, [hw5], [hw5]))
-        f.conv(self._conv(lc[1], c4, lat[1], N, [hw4], [hw4], addend=lat[2], add_hw=[hw5]))
-        f.conv(self._conv(lc[0], c3, lat[0], N, [hw3], [hw3], addend=lat[1], add_hw=[hw4]))
+        ld3, ld4, ld5 = self.stage_ld[1:4]       # RLA keeps a stage output as the x part of the next [C + 128]-wide block input
+        f.conv(self._conv(lc[2], c5, lat[2], N, [hw5], [hw5], lds=ld5))
+        f.conv(self._conv(lc[1], c4, lat[1], N, [hw4], [hw4], addend=lat[2], add_hw=[hw5], lds=ld4))
+        f.conv(self._conv(lc[0], c3, lat[0], N, [hw3], [hw3], addend=lat[1], add_hw=[hw4], lds=ld3))
         feats = self.buf('feats', self.M, 256)
         self.feat_seg = [feats.data_ptr() + self.seg_off[i] * 256 * 2 for i in range(5)]
         fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
@@ -258,6 +245,32 @@ class Plan:
         if FSIDE:
             f.join(FSIDE)
 
+    def _fwd_resnet(self, x, h, w):
+        st, N, f = self.store, self.N, self.fwd
+        cv = st.convs
+        self.blocks = []        # per block: dict(xin, a1, a2, out, idt, in_hw, out_hw, prefix, stride)
+        for li, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
+            for b in range(nb):
+                p = f'backbone.layer{li + 1}.{b}'
+                c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
+                s = c1.stride
+                oh, ow = conv_out(h, 1, s, 0), conv_out(w, 1, s, 0)
+                a1 = self.buf(p + '.a1', N, oh, ow, planes)
+                a2 = self.buf(p + '.a2', N, oh, ow, planes)
+                out = self.buf(p + '.out', N, oh, ow, planes * 4)
+                f.conv(self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True))
+                f.conv(self._conv(c2, a1, a2, N, [(oh, ow)], [(oh, ow)], relu=True))
+                idt = x
+                if b == 0:
+                    idt = self.buf(p + '.idt', N, oh, ow, planes * 4)
+                    f.conv(self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)]))
+                f.conv(self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt))
+                self.blocks.append(dict(prefix=p, xin=x, a1=a1, a2=a2, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
+                                        stage=li, b=b, planes=planes))
+                x, h, w = out, oh, ow
+            self.stage_out.append((x, (h, w)))
+            self.stage_ld.append(planes * 4)
+
     def _gn_workspace(self, key):
         """Launches on one stream run one after the other and may share the block-record scratch."""
         ws = self._gn_ws.get(key)
@@ -269,21 +282,24 @@ class Plan:
 
     # ---------------------------------------------------------------------------------------------
     def _wgrad(self, ol, spec, dy, x, n, out_hw, in_hw, cy=None, cd=None, wregion=None, bregion=None, side=False,
-               emit=True, no_db=False):
-        """emit=False: only build the descriptor (for a later grouped launch)."""
+               emit=True, no_db=False, ldx=0, shared=0, raw=False, db_ptr=None):
+        """emit=False: only build the descriptor (for a later grouped launch).  raw=True: no BatchNorm scale on the rows (the
+        BN post-pass derives dgamma from the unscaled gradient and scales it afterwards); db_ptr: where the column sum of dy
+        goes (that BatchNorm's dbeta)."""
         st = self.store
-        scale = st.bn_ptrs(spec.bn)[0] if (spec is not None and spec.bn) else None
+        scale = st.bn_ptrs(spec.bn)[0] if (spec is not None and spec.bn and not raw) else None
         name = wregion or (spec.name + '.weight')
-        db = None
+        db = db_ptr
         if bregion is not None:
             db = st.t32_ptr(bregion, st.grad)
         elif spec is not None and spec.bias and not no_db:
             db = st.t32_ptr(spec.name + '.bias', st.grad)
         k = 3 if spec is None else spec.k
+        cs = 256 if spec is None else spec.cin_store
         d = ops.wgrad_desc(dy, x, st.t32_ptr(name, st.grad), n=n, grid=out_hw, src_hw=in_hw,
-                           cs=256 if spec is None else spec.cin, cy=cy or spec.cout_pad, cd=cd or spec.cout,
+                           cs=cs, cy=cy or spec.cout_pad, cd=cd or spec.cout,
                            kh=k, kw=k, stride=1 if spec is None else spec.stride, pad=1 if spec is None else spec.pad,
-                           scale=scale, db=db, workspace=self._wg_ws(n, out_hw, in_hw, spec, cy))
+                           scale=scale, db=db, workspace=self._wg_ws(n, out_hw, in_hw, spec, cy), ldx=ldx, shared=shared)
         if emit:
             ol.wgrad(d, side=side)
         return d
@@ -303,7 +319,7 @@ class Plan:
         ol.wgrad_group(ops.wgrad_group(descs, workspace=self._wg_buf(need, ws_name)), side=side)
 
     def _wg_ws(self, n, out_hw, in_hw, spec, cy):
-        need = ops.wgrad_workspace_bytes(n=n, grid=out_hw, src_hw=in_hw, cs=256 if spec is None else spec.cin,
+        need = ops.wgrad_workspace_bytes(n=n, grid=out_hw, src_hw=in_hw, cs=256 if spec is None else spec.cin_store,
                                          cy=cy or spec.cout_pad, cd=1, kh=3 if spec is None else spec.k,
                                          kw=3 if spec is None else spec.k, stride=1 if spec is None else spec.stride,
                                          pad=1 if spec is None else spec.pad)
@@ -320,13 +336,15 @@ class Plan:
         return ws
 
     def _dgrad(self, name, dy, dst, n, dy_hw, dst_hw, *, cs, cd, k, stride, pad, os=1, addend=None, mask=None,
-               mask_first=False, mask_last=False, cs_real=0):
+               mask_first=False, mask_last=False, cs_real=0, wptr=None, cd_pad=None, ldd=None, lda=None, ldm=None):
+        """wptr: explicit pointer into a dgrad pack (a row range = an input-channel range of the forward conv)."""
         st = self.store
         f = (L.CONV_MASK_FIRST if mask_first else 0) | (L.CONV_MASK_LAST if mask_last else 0)
         grid = dy_hw if os > 1 else dst_hw
-        return ops.conv_desc(dy, st.wT_ptr(name), dst, n=n, grid=grid, src_hw=dy_hw, dst_hw=dst_hw, cs=cs, cd=cd,
-                             cd_pad=cd, ldd=cd, kh=k, kw=k, stride=stride, pad=pad, mode=1, os=os, flags=f,
-                             addend=addend, lda=cd, mask=mask, ldm=cd, workspace=self.conv_ws, cs_real=cs_real)
+        return ops.conv_desc(dy, wptr if wptr is not None else st.wT_ptr(name), dst, n=n, grid=grid, src_hw=dy_hw, dst_hw=dst_hw,
+                             cs=cs, cd=cd, cd_pad=cd_pad or cd, ldd=ldd or cd, kh=k, kw=k, stride=stride, pad=pad, mode=1, os=os,
+                             flags=f, addend=addend, lda=lda or cd, mask=mask, ldm=ldm or cd, workspace=self.conv_ws,
+                             cs_real=cs_real)
 
     def _build_backward(self):
         """Backward op lists.  The data-gradient chain runs on the caller's stream; every weight gradient is
@@ -412,14 +430,19 @@ class Plan:
                             addend=s1))
         # laterals -> gradients w.r.t. C3, C4, C5 (masked by the ReLU that produced them)
         self.g_stage = {}
+        rla = st.backbone == 'rla'
         for i, (li, hw) in enumerate(((1, hw3), (2, hw4), (3, hw5))):
             cfeat = self.stage_out[li][0]
             cch = STAGE_PLANES[li] * 4
-            self._wgrad(ol, lc[i], g_lat[i], cfeat, N, [hw], [hw], side=SIDE)
+            ldc = self.stage_ld[li]
+            self._wgrad(ol, lc[i], g_lat[i], cfeat, N, [hw], [hw], side=SIDE, ldx=ldc if ldc != cch else 0)
             g0b = self.buf(f'g_stage{li}_last', N, hw[0], hw[1], cch)
             self.g_stage[li] = g0b
+            # ResNet: the gradient w.r.t. the stage output is masked by its ReLU here.  RLA: the outputs of stages 1, 2 also
+            # feed the recurrent path; their mask is applied once every contribution has arrived (engine_rla)
+            masked = not rla or li == 3
             ol.conv(self._dgrad(lc[i].name, g_lat[i], g0b, N, [hw], [hw], cs=256, cd=cch, k=1, stride=1, pad=0,
-                                mask=cfeat, mask_first=True))
+                                mask=cfeat if masked else None, mask_first=masked, ldm=ldc))
         buckets = st.grad_buckets()
         # no JOIN here: this segment's weight gradients keep running on the side stream under the next segment's
         # data-gradient chain.  Named event slot s marks "side-stream work of segment s queued": once it has fired, gradient
@@ -428,6 +451,10 @@ class Plan:
         ol.record(0)
         self.bwd_segments.append((ol, dict(bucket=buckets[0], slot=0, main=False)))
         # ================= backbone: layer4, layer3, layer2 =================
+        if rla:
+            from . import engine_rla
+            engine_rla.build_backward(self, buckets, SIDE)
+            return
         blocks_by_stage = {li: [b for b in self.blocks if b['stage'] == li] for li in (1, 2, 3)}
         for li in (3, 2, 1):
             ol = OpList()

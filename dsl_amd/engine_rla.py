@@ -1,0 +1,236 @@
+"""Kernel lists of the RLA_ResNet backbone (reference: mmdet/models/backbones/resnet_rla.py:71-137 RLA_Bottleneck,
+:289-327 RLA_ResNet._forward_impl, :343-388 freezing) for dsl_amd.engine.Plan.
+
+Data layout.  A block's input cat(x, h) (:106) is ONE NHWC buffer "XH" of C + 128 channels = [x (C) | h (32) | zeros]:
+the previous block's conv3 epilogue writes x = relu(bn3(.) + identity) into the first C channels (row stride C + 128),
+its recurrent conv writes h behind them, and conv1 (weights stored with C + 128 input channels, zero columns behind the
+real C + 32) reads the rows as an ordinary source - no concat copy.  Consumers of x alone (downsample, conv_out, the FPN
+laterals, the ReLU masks and residual addends of the backward) address the same rows with that row stride.
+
+What the reference computes, restated (pinned by tests/golden/rla_tiny.npz against the reference's own module):
+  * style 'pytorch': the 3x3 strides (:84-86); conv1 is stride 1 on the block's input resolution;
+  * `y = out` (:123) aliases the tensor that `out += identity` and the in-place ReLU then modify (:132-133), so the y that
+    feeds conv_out is the block OUTPUT; the recurrent update is h = recurrent_conv(tanh(bn_b(h' + conv_out(out)))) with
+    h' = avgpool2x2(h) in the first block of stages 1-3 (:129-130,314-321);
+  * every BatchNorm runs in eval mode; those of stages 1-3 keep TRAINABLE affine parameters: forward folds them per step
+    (ParamStore.refold_bn), backward gets (dgamma, dbeta) of conv -> BN pairs from the unscaled weight gradient
+    (dsl_bn_wgrad_post) and of the recurrent path's BN from dsl_bn_tanh_bwd;
+  * the h produced by the last block of the last stage is never used (:322-327): not computed.
+
+Backward.  The gradient w.r.t. a block output `out` collects, UNMASKED, the next block's conv1 x-part data gradient, its
+identity path (or downsample data gradient), the FPN lateral's (stage outputs) - and is masked by ReLU(out) in the epilogue
+of conv_out's data gradient, which adds the recurrent path's contribution last.  conv_out / recurrent_conv are shared by
+the blocks of a stage: their weight gradients are one grouped launch whose members are summed (dsl_wgrad_desc.shared).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .params import RLA_C, RLA_PAD, STAGE_BLOCKS, STAGE_PLANES
+
+BF = torch.bfloat16
+
+
+def _rla_op(ol, kind, p=(), i=(), f=(), rows=0, side=False):
+    d = L.RlaDesc()
+    d.kind = kind
+    for k, v in enumerate(p):
+        d.p[k] = v if isinstance(v, int) else (0 if v is None else v.data_ptr())
+    for k, v in enumerate(i):
+        d.i[k] = int(v)
+    for k, v in enumerate(f):
+        d.f[k] = float(v)
+    d.rows = int(rows)
+    d._keep = [v for v in p if not isinstance(v, int)]
+    ol._add(L.OP_RLA, d, i=(0, 0, 0, 0, 0, 0, int(side)))
+    return d
+
+
+def conv_out_hw(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def build_forward(plan, s1, h1, w1):
+    """Stem output s1 (N, h1, w1, 64) -> maxpool into the first XH -> 16 RLA blocks; fills plan.stage_out / stage_ld and
+    plan.rla_blocks (what the backward needs)."""
+    st, N, f = plan.store, plan.N, plan.fwd
+    cv = st.convs
+    h, w = conv_out_hw(h1, 3, 2, 1), conv_out_hw(w1, 3, 2, 1)
+    cx = 64
+    xh = plan.buf('rla.xh.0.0', N * h * w, cx + RLA_PAD, zero=True)
+    f._add(L.OP_MAXPOOL, i=(N, h1, w1, 64, cx + RLA_PAD), p=(s1, xh))
+    plan.rla_blocks = []
+    for s_, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
+        c4 = planes * 4
+        co, rc = cv[f'backbone.conv_outs.{s_}'], cv[f'backbone.recurrent_convs.{s_}']
+        for b in range(nb):
+            p = f'backbone.stages.{s_}.{b}'
+            c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
+            stride = c2.stride
+            oh, ow = conv_out_hw(h, 3, stride, 1), conv_out_hw(w, 3, stride, 1)
+            ldx = cx + RLA_PAD
+            a1 = plan.buf(p + '.a1', N * h * w, planes)
+            a2 = plan.buf(p + '.a2', N * oh * ow, planes)
+            last = s_ == 3 and b == nb - 1
+            nxt = plan.buf(f'rla.xh.{s_}.{b + 1}', N * oh * ow, c4 + RLA_PAD, zero=True)      # the next block's XH
+            f.conv(plan._conv(c1, xh, a1, N, [(h, w)], [(h, w)], relu=True, cs=ldx, lds=ldx))
+            f.conv(plan._conv(c2, a1, a2, N, [(h, w)], [(oh, ow)], relu=True))
+            if b == 0:
+                idt = plan.buf(p + '.idt', N * oh * ow, c4)
+                f.conv(plan._conv(cv[p + '.downsample.0'], xh, idt, N, [(h, w)], [(oh, ow)], cs=cx, lds=ldx))
+                idt_ld = c4
+            else:
+                idt, idt_ld = xh, ldx                      # the block input itself (x part of its rows)
+            f.conv(plan._conv(c3, a2, nxt, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt, lda=idt_ld, dst_ld=c4 + RLA_PAD))
+            blk = dict(prefix=p, stage=s_, b=b, planes=planes, cx=cx, c4=c4, xh=xh, ldx=ldx, a1=a1, a2=a2, out=nxt,
+                       ld_out=c4 + RLA_PAD, in_hw=(h, w), out_hw=(oh, ow), stride=stride, last=last, pooled=False)
+            if not last:
+                h_ptr, h_ld = xh.data_ptr() + cx * 2, ldx       # h part of this block's input rows
+                if b == 0 and stride != 1:
+                    hp = plan.buf(p + '.hpool', N * oh * ow, RLA_C)
+                    _rla_op(f, L.RLA_AVGPOOL, p=(h_ptr, hp), i=(ldx, RLA_C, N, h, w, RLA_C))
+                    h_ptr, h_ld = hp.data_ptr(), RLA_C
+                    blk['pooled'] = True
+                u = plan.buf(p + '.u', N * oh * ow, RLA_C)
+                f.conv(plan._conv(co, nxt, u, N, [(oh, ow)], [(oh, ow)], cs=c4, lds=c4 + RLA_PAD, addend=h_ptr, lda=h_ld,
+                                  dst_ld=RLA_C, affine=False))
+                tw = rc.cin_store                              # 64 (frozen stage 0) / 128: T rows are as wide as the stored K
+                t = plan.buf(p + '.t', N * oh * ow, tw, zero=True)
+                bnn = f'backbone.stage_bns.{s_}.{b}'
+                sc, bi = st.bn_ptrs(bnn)
+                _rla_op(f, L.RLA_BN_TANH, p=(u, sc, bi, t), i=(RLA_C, tw, RLA_C), rows=N * oh * ow)
+                f.conv(plan._conv(rc, t, nxt.data_ptr() + c4 * 2, N, [(oh, ow)], [(oh, ow)], cs=tw, dst_ld=c4 + RLA_PAD,
+                                  affine=False))
+                blk.update(u=u, t=t, tw=tw, bn=bnn)
+            plan.rla_blocks.append(blk)
+            xh, cx, h, w = nxt, c4, oh, ow
+        plan.stage_out.append((xh, (h, w)))
+        plan.stage_ld.append(c4 + RLA_PAD)
+
+
+def build_backward(plan, buckets, SIDE):
+    """Backward segments of stages 3, 2, 1 (plan.bwd_segments already holds head + FPN)."""
+    st, N = plan.store, plan.N
+    cv = st.convs
+    g32 = lambda name: st.t32_ptr(name, st.grad)
+    bn_g = lambda bn, leaf: st.t32_ptr('bn_train.' + leaf, st.grad) + st.bn_train_off[bn][0] * 4
+    bn_p = lambda bn, leaf: st.t32_ptr('bn_train.' + leaf) + st.bn_train_off[bn][0] * 4
+    bn_f = lambda bn, leaf: st.frozen.data_ptr() + (st.frozen_regions['bn_train.' + leaf][0] + st.bn_train_off[bn][0]) * 4
+    from .engine import OpList
+    gh_next = None            # gradient w.r.t. the h a block PRODUCES ([px_out][64], 32 real), written by its consumer
+    for s_ in (3, 2, 1):
+        ol = OpList()
+        blks = [b for b in plan.rla_blocks if b['stage'] == s_]
+        planes, c4 = blks[0]['planes'], blks[0]['c4']
+        co, rc = cv[f'backbone.conv_outs.{s_}'], cv[f'backbone.recurrent_convs.{s_}']
+        gx = plan.g_stage[s_]                 # gradient w.r.t. the stage's last output (FPN lateral + next stage), unmasked for s < 3
+        g3, g2, g1, g_co, g_rc, post = [], [], [], [], [], []
+        for blk in reversed(blks):
+            p, b = blk['prefix'], blk['b']
+            c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
+            (h, w), (oh, ow) = blk['in_hw'], blk['out_hw']
+            cx, ldx, stride = blk['cx'], blk['ldx'], blk['stride']
+            pin, pout = N * h * w, N * oh * ow
+            first = s_ == 1 and b == 0                       # input comes from the frozen stage 0: no data gradient
+            if blk['last']:
+                g_pre = gx                                   # masked by the lateral's data gradient already
+                g_u = None
+            else:
+                # ---- recurrent path: h_out = recurrent_conv(t), t = tanh(bn(u)), u = h' + conv_out(out)
+                gh = gh_next
+                g_t = plan.buf(p + '.g_t', pout, RLA_C)
+                ol.conv(plan._dgrad(rc.name, gh, g_t, N, [(oh, ow)], [(oh, ow)], cs=64, cd=RLA_C, cd_pad=rc.cin_store, k=3,
+                                    stride=1, pad=1, ldd=RLA_C))
+                g_rc.append(plan._wgrad(ol, rc, gh, blk['t'], N, [(oh, ow)], [(oh, ow)], cy=64, cd=RLA_C, emit=False, shared=1))
+                g_u = plan.buf(p + '.g_u', pout, 64, zero=True)
+                ws = plan.buf(p + '.bnws', L.lib.dsl_bn_tanh_bwd_workspace_bytes(pout, RLA_C) // 4 + 8, dtype=torch.float32)
+                sc, _ = st.bn_ptrs(blk['bn'])
+                _rla_op(ol, L.RLA_BN_TANH_BWD, p=(g_t, blk['t'], blk['u'], sc, bn_f(blk['bn'], 'running_mean'),
+                                                  bn_f(blk['bn'], 'running_var'), g_u, bn_g(blk['bn'], 'weight'),
+                                                  bn_g(blk['bn'], 'bias'), ws),
+                        i=(RLA_C, blk['tw'], RLA_C, 64, RLA_C), f=(1e-5,), rows=pout)
+                g_co.append(plan._wgrad(ol, co, g_u, blk['out'], N, [(oh, ow)], [(oh, ow)], cy=64, cd=RLA_C, emit=False,
+                                        ldx=blk['ld_out'], shared=1))
+                # g_pre = (gx + conv_out^T g_u) * [out > 0]: every contribution to d/d(out) has arrived, mask once
+                g_pre = plan.buf(p + '.g_pre', pout, c4)
+                ol.conv(plan._dgrad(co.name, g_u, g_pre, N, [(oh, ow)], [(oh, ow)], cs=64, cd=c4, k=1, stride=1, pad=0,
+                                    addend=gx, mask=blk['out'], ldm=blk['ld_out'], mask_last=True, cs_real=RLA_C))
+            # ---- bottleneck: out = relu(bn3(conv3(a2)) + identity)
+            gA2 = plan.buf(p + '.g_a2', pout, planes)
+            gA1 = plan.buf(p + '.g_a1', pin, planes)
+            g3.append(plan._wgrad(ol, c3, g_pre, blk['a2'], N, [(oh, ow)], [(oh, ow)], emit=False, raw=True,
+                                  db_ptr=bn_g(c3.bn, 'bias')))
+            ol.conv(plan._dgrad(c3.name, g_pre, gA2, N, [(oh, ow)], [(oh, ow)], cs=c4, cd=planes, k=1, stride=1, pad=0,
+                                mask=blk['a2'], mask_last=True))
+            d2 = plan._wgrad(ol, c2, gA2, blk['a1'], N, [(oh, ow)], [(h, w)], emit=False, raw=True, db_ptr=bn_g(c2.bn, 'bias'))
+            if stride == 1:
+                g2.append(d2)                # the stage's stride-1 3x3 convolutions share a geometry
+            else:
+                ol.wgrad(d2, side=SIDE)
+            ol.conv(plan._dgrad(c2.name, gA2, gA1, N, [(oh, ow)], [(h, w)], cs=planes, cd=planes, k=3, stride=stride, pad=1,
+                                mask=blk['a1'], mask_last=True))
+            d1 = plan._wgrad(ol, c1, gA1, blk['xh'], N, [(h, w)], [(h, w)], emit=False, raw=True, db_ptr=bn_g(c1.bn, 'bias'))
+            if b > 0:
+                g1.append(d1)
+            else:
+                ol.wgrad(d1, side=SIDE)
+            # ---- gradient w.r.t. the block input (x part) and w.r.t. the incoming h
+            if b == 0:
+                ds = cv[p + '.downsample.0']
+                ol.wgrad(plan._wgrad(ol, ds, g_pre, blk['xh'], N, [(oh, ow)], [(h, w)], emit=False, raw=True,
+                                     db_ptr=bn_g(ds.bn, 'bias'), ldx=ldx), side=SIDE)
+            if not first:
+                wT = st.wT_ptr(c1.name)                      # CRSK rows = input channels of conv1: [x (cx) | h (32) | zeros]
+                if b > 0:
+                    gx_prev = plan.buf(p + '.g_in', pin, cx)
+                    ol.conv(plan._dgrad(c1.name, gA1, gx_prev, N, [(h, w)], [(h, w)], cs=planes, cd=cx, k=1, stride=1, pad=0,
+                                        addend=g_pre))      # + the identity path; masked by the consumer of gx_prev
+                else:
+                    gx_prev = plan.g_stage[s_ - 1]           # holds the FPN lateral's contribution already
+                    ol.conv(plan._dgrad(ds.name, g_pre, gx_prev, N, [(oh, ow)], [(h, w)], cs=c4, cd=cx, k=1, stride=1, pad=0,
+                                        os=stride, addend=gx_prev))
+                    ol.conv(plan._dgrad(c1.name, gA1, gx_prev, N, [(h, w)], [(h, w)], cs=planes, cd=cx, k=1, stride=1, pad=0,
+                                        addend=gx_prev))
+                # h part: rows [cx, cx + 64) of the pack; + the recurrent path's own h' term
+                gh_prev = plan.buf(p + '.g_hin', pin, 64, zero=True)
+                add, lda = None, None
+                if g_u is not None:
+                    if blk['pooled']:
+                        add = plan.buf(p + '.g_hpool', pin, 64, zero=True)
+                        _rla_op(ol, L.RLA_AVGPOOL_BWD, p=(g_u, add), i=(64, 64, N, h, w, RLA_C))
+                    else:
+                        add = g_u
+                    lda = 64
+                ol.conv(plan._dgrad(c1.name, gA1, gh_prev, N, [(h, w)], [(h, w)], cs=planes, cd=RLA_C, cd_pad=64, k=1, stride=1,
+                                    pad=0, ldd=64, addend=add, lda=lda, wptr=wT + cx * c1.cout_pad * 2))
+                gh_next = gh_prev
+                gx = gx_prev
+            post += [c1, c2, c3] + ([cv[p + '.downsample.0']] if b == 0 else [])
+        # ---- the stage's weight gradients: grouped where the geometry is shared, then the BatchNorm post-pass
+        post_specs = post
+        for grp in (g3, g2, g1):
+            plan._wgrad_group(ol, grp, side=SIDE)
+        for grp in (g_co, g_rc):
+            if grp:
+                plan._wgrad_group(ol, grp, side=SIDE, ws_name='wg_ws_shared')
+        items, rows = [], 0
+        for spec in post_specs:
+            it = L.BnPostItem()
+            it.w, it.dw = st.t32_ptr(spec.name + '.weight'), g32(spec.name + '.weight')
+            it.dgamma, it.dbeta, it.gamma = bn_g(spec.bn, 'weight'), bn_g(spec.bn, 'bias'), bn_p(spec.bn, 'weight')
+            it.mean, it.var = bn_f(spec.bn, 'running_mean'), bn_f(spec.bn, 'running_var')
+            it.rows, it.k, it.row_start = spec.cout, spec.k * spec.k * spec.cin_store, rows
+            rows += spec.cout
+            items.append(it)
+        arr = (L.BnPostItem * len(items))(*items)
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(plan.dev)
+        plan.bufs[f'rla.bnpost.{s_}'] = tab
+        # behind the weight gradients on their stream: dgamma from <W, dWu>, then the rows are scaled in place
+        _rla_op(ol, L.RLA_BN_POST, p=(tab,), i=(len(items), rows), f=(1e-5,), side=SIDE)
+        seg = 4 - s_
+        ol.record(seg)
+        if s_ == 1:
+            ol.join()
+        plan.bwd_segments.append((ol, dict(bucket=buckets[seg], slot=seg, main=False)))

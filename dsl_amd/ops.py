@@ -16,7 +16,7 @@ def _segs(shapes):
 
 def conv_desc(src, wgt, dst, *, n, grid, src_hw, dst_hw, cs, cd, cd_pad, ldd, kh, kw, stride=1, pad=0,
               mode=0, os=1, flags=0, scale=None, bias=None, addend=None, lda=0, add_hw=None, mask=None,
-              ldm=0, workspace=None, cs_real=0):
+              ldm=0, workspace=None, cs_real=0, lds=0):
     """grid/src_hw/dst_hw/add_hw: list of (h, w) per level segment."""
     d = L.ConvDesc()
     d.nseg, d.n = len(grid), n
@@ -27,7 +27,7 @@ def conv_desc(src, wgt, dst, *, n, grid, src_hw, dst_hw, cs, cd, cd_pad, ldd, kh
         d.ah, d.aw = _segs(add_hw)
     d.cs, d.cd, d.cd_pad, d.ldd, d.lda, d.ldm = cs, cd, cd_pad, ldd, lda, ldm
     d.kh, d.kw, d.stride, d.pad, d.mode, d.os, d.flags = kh, kw, stride, pad, mode, os, flags
-    d.cs_real = cs_real
+    d.cs_real, d.lds = cs_real, lds
     d.src, d.wgt, d.dst = L.ptr(src), L.ptr(wgt), L.ptr(dst)
     d.scale, d.bias, d.addend, d.mask = L.ptr(scale), L.ptr(bias), L.ptr(addend), L.ptr(mask)
     if workspace is not None:
@@ -47,12 +47,13 @@ def conv2d(*a, **k):
 
 
 def wgrad_desc(dy, x, dw, *, n, grid, src_hw, cs, cy, cd, kh, kw, stride=1, pad=0, scale=None, db=None,
-               workspace=None, force_cfg=None):
+               workspace=None, force_cfg=None, ldx=0, shared=0):
     d = L.WgradDesc()
     d.nseg, d.n = len(grid), n
     d.gh, d.gw = _segs(grid)
     d.sh, d.sw = _segs(src_hw)
     d.cs, d.cy, d.cd, d.kh, d.kw, d.stride, d.pad = cs, cy, cd, kh, kw, stride, pad
+    d.ldx, d.shared = ldx, shared
     d.splits = 0 if force_cfg is None else -(force_cfg + 1)     # negative: test hook forcing a tile config
     if force_cfg is None:
         d.splits = lib.dsl_wgrad_splits(C.byref(d))

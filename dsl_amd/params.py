@@ -26,10 +26,18 @@ def _round_up(x, m):
 
 
 class ConvSpec:
-    def __init__(self, name, cin, cout, k, stride, pad, bn=None, bias=False, trainable=True):
+    def __init__(self, name, cin, cout, k, stride, pad, bn=None, bias=False, trainable=True, cin_store=None, bn_train=False,
+                 stage=None, no_dgrad=False):
+        """cin_store: input channels of the STORED weight rows (>= cin; the extra columns are zero and stay zero: their
+        inputs are zero padding) - RLA's conv1 reads cat(x, h) from one [C + 128]-wide buffer.  bn_train: the BatchNorm
+        behind the conv runs in eval mode but its affine parameters train (RLA_ResNet).  stage: backward segment
+        (0..3 = backbone stages) the gradients belong to."""
         self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
         self.bn, self.bias, self.trainable = bn, bias, trainable
         self.cout_pad = _round_up(cout, 64)
+        self.cin_store = cin_store or cin
+        self.bn_train = bn_train and trainable
+        self.stage, self.no_dgrad = stage, no_dgrad
 
 
 def backbone_specs():
@@ -51,6 +59,46 @@ def backbone_specs():
     return specs
 
 
+RLA_C = 32          # channels of the recurrent state h (resnet_rla.py: rla_channel)
+RLA_PAD = 128       # cat(x, h) is stored [x | h | zeros] with C + RLA_PAD channels (multiple of the 128-channel wgrad tile)
+
+
+def rla_backbone_specs():
+    """RLA_ResNet (mmdet/models/backbones/resnet_rla.py:140-287), layers [3, 4, 6, 3], style 'pytorch' (the 3x3 strides),
+    frozen_stages=1: stem, stage 0 and its RLA layers frozen; the BatchNorms of stages 1-3 keep trainable affine parameters
+    (eval-mode statistics).  Names are the reference's module names."""
+    specs = [ConvSpec('backbone.conv1', 3, 64, 7, 2, 3, bn='backbone.bn1', trainable=False)]
+    inpl = 64
+    for s_, (planes, blocks) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
+        tr = s_ >= 1
+        for b in range(blocks):
+            p = f'backbone.stages.{s_}.{b}'
+            st = 2 if (b == 0 and s_ > 0) else 1
+            first_trainable = tr and s_ == 1 and b == 0        # fed by the frozen stage 0: no data gradient needed
+            specs.append(ConvSpec(p + '.conv1', inpl + RLA_C, planes, 1, 1, 0, bn=p + '.bn1', trainable=tr, bn_train=True,
+                                  cin_store=inpl + RLA_PAD, stage=s_, no_dgrad=first_trainable))
+            specs.append(ConvSpec(p + '.conv2', planes, planes, 3, st, 1, bn=p + '.bn2', trainable=tr, bn_train=True, stage=s_))
+            specs.append(ConvSpec(p + '.conv3', planes, planes * 4, 1, 1, 0, bn=p + '.bn3', trainable=tr, bn_train=True, stage=s_))
+            if b == 0:
+                specs.append(ConvSpec(p + '.downsample.0', inpl, planes * 4, 1, st, 0, bn=p + '.downsample.1', trainable=tr,
+                                      bn_train=True, stage=s_, no_dgrad=first_trainable))
+            inpl = planes * 4
+        # the stage's shared RLA convolutions: conv_out 1x1 (4*planes -> 32), recurrent 3x3 (32 -> 32, stored 64 -> 32 over a
+        # zero-padded source)
+        specs.append(ConvSpec(f'backbone.conv_outs.{s_}', planes * 4, RLA_C, 1, 1, 0, trainable=tr, stage=s_))
+        # (stored 128 wide where it trains: the weight-gradient kernel tiles input channels by 128)
+        specs.append(ConvSpec(f'backbone.recurrent_convs.{s_}', RLA_C, RLA_C, 3, 1, 1, trainable=tr, cin_store=128 if tr else 64,
+                              stage=s_))
+    return specs
+
+
+def rla_stage_bns():
+    """(name, trainable) of the per-block BatchNorm(32) layers on the recurrent path (stage_bns, resnet_rla.py:236,283);
+    stage_bns.3.2 is frozen by _freeze_stages (:364-366)."""
+    return [(f'backbone.stage_bns.{s_}.{b}', s_ >= 1 and not (s_ == 3 and b == 2))
+            for s_, blocks in enumerate(STAGE_BLOCKS) for b in range(blocks)]
+
+
 def neck_specs():
     specs = [ConvSpec(f'neck.lateral_convs.{i}.conv', c, 256, 1, 1, 0, bias=True)
              for i, c in enumerate((512, 1024, 2048))]
@@ -68,10 +116,12 @@ def head_specs():
 class ParamStore:
     """Flat buffers + named views.  One instance for the student, one for the EMA teacher."""
 
-    def __init__(self, num_classes=80, device='cpu'):
-        assert num_classes == 80
-        self.num_classes = num_classes
-        self.convs = {s.name: s for s in backbone_specs() + neck_specs() + head_specs()}
+    def __init__(self, num_classes=80, device='cpu', backbone='resnet'):
+        assert num_classes == 80 and backbone in ('resnet', 'rla')
+        self.num_classes, self.backbone = num_classes, backbone
+        bspecs = backbone_specs() if backbone == 'resnet' else rla_backbone_specs()
+        self.convs = {s.name: s for s in bspecs + neck_specs() + head_specs()}
+        self.extra_bns = rla_stage_bns() if backbone == 'rla' else []        # BatchNorms that follow no convolution
         self.train_regions = {}     # name -> (offset, numel, shape)   (shape = storage shape)
         self.frozen_regions = {}
         toff = foff = 0
@@ -81,17 +131,37 @@ class ParamStore:
             regions[name] = (off, n, tuple(shape))
             return off + n
 
+        # BatchNorms with TRAINABLE affine parameters (eval-mode statistics; RLA_ResNet): every gamma in one block, every
+        # beta in the next, at the START of the flat buffer - i.e. inside the gradient bucket that completes last - and the
+        # statistics in the same order in the frozen buffer: the per-step fold to (scale, bias) is one launch
+        self.bn_train = [(s.bn, s.cout) for s in self.convs.values() if s.bn and s.bn_train] + \
+                        [(n, RLA_C) for n, tr in self.extra_bns if tr]
+        self.bn_train_off = {}
+        if self.bn_train:
+            ctot = 0
+            for n, c in self.bn_train:
+                self.bn_train_off[n] = (ctot, c)
+                ctot += c
+            self.bn_train_ch = ctot
+            toff = add(self.train_regions, toff, 'bn_train.weight', (ctot,))
+            toff = add(self.train_regions, toff, 'bn_train.bias', (ctot,))
+            foff = add(self.frozen_regions, foff, 'bn_train.running_mean', (ctot,))
+            foff = add(self.frozen_regions, foff, 'bn_train.running_var', (ctot,))
         for s in self.convs.values():
-            shape = (s.cout, s.k, s.k, s.cin)
+            shape = (s.cout, s.k, s.k, s.cin_store)
             if s.trainable:
                 toff = add(self.train_regions, toff, s.name + '.weight', shape)
                 if s.bias:
                     toff = add(self.train_regions, toff, s.name + '.bias', (s.cout,))
             else:
                 foff = add(self.frozen_regions, foff, s.name + '.weight', shape)
-            if s.bn:
+            if s.bn and not s.bn_train:
                 for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
                     foff = add(self.frozen_regions, foff, f'{s.bn}.{leaf}', (s.cout,))
+        for n, tr in self.extra_bns:
+            if not tr:
+                for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
+                    foff = add(self.frozen_regions, foff, f'{n}.{leaf}', (RLA_C,))
         for tower in ('cls_convs', 'reg_convs'):
             for i in range(4):
                 toff = add(self.train_regions, toff, f'bbox_head.{tower}.{i}.gn.weight', (256,))
@@ -108,6 +178,7 @@ class ParamStore:
         self.frozen = torch.zeros(foff, dtype=torch.float32, device=device)
         self.grad = torch.zeros(toff, dtype=torch.float32, device=device)
         self.nbt = {s.bn: torch.zeros((), dtype=torch.long, device=device) for s in self.convs.values() if s.bn}
+        self.nbt.update({n: torch.zeros((), dtype=torch.long, device=device) for n, _ in self.extra_bns})
         # bias group mask for the optimizer's paramwise rules (bias_lr_mult / bias_decay_mult apply to
         # conv biases, not to norm layers: mmcv DefaultOptimizerConstructor, SURVEY.md §8a note)
         grp = torch.zeros(toff, dtype=torch.uint8)
@@ -146,9 +217,22 @@ class ParamStore:
 
         def conv_w(s):
             v = self.tview(s.name + '.weight', tb) if s.trainable else (self.fview(s.name + '.weight') if buf is None else None)
-            return None if v is None else v.permute(0, 3, 1, 2)
+            if v is None:
+                return None
+            if s.cin_store != s.cin:      # stored rows carry zero columns behind the real input channels
+                v = v[..., :s.cin]
+            return v.permute(0, 3, 1, 2)
 
         def bn(name):
+            if name in self.bn_train_off:          # trainable affine parameters: slices of the gamma / beta blocks
+                o, c = self.bn_train_off[name]
+                out[f'{name}.weight'] = self.tview('bn_train.weight', tb)[o:o + c]
+                out[f'{name}.bias'] = self.tview('bn_train.bias', tb)[o:o + c]
+                if buf is None:
+                    out[f'{name}.running_mean'] = self.fview('bn_train.running_mean')[o:o + c]
+                    out[f'{name}.running_var'] = self.fview('bn_train.running_var')[o:o + c]
+                    out[f'{name}.num_batches_tracked'] = self.nbt[name]
+                return
             if buf is not None:
                 return
             for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
@@ -167,6 +251,8 @@ class ParamStore:
                 base = s.name[:-5]
                 out[base + '.gn.weight'] = self.tview(base + '.gn.weight', tb)
                 out[base + '.gn.bias'] = self.tview(base + '.gn.bias', tb)
+        for n, _ in self.extra_bns:
+            bn(n)
         cw, cb = self.tview('head.cls_w', tb), self.tview('head.cls_b', tb)
         rw, rb = self.tview('head.regctr_w', tb), self.tview('head.regctr_b', tb)
         out['bbox_head.conv_cls.weight'] = cw[:80].permute(0, 3, 1, 2)
@@ -209,11 +295,11 @@ class ParamStore:
         if getattr(self, '_wT', None) is None:
             off, lay = 0, {}
             for s in self.convs.values():
-                if not s.trainable:
+                if not s.trainable or s.no_dgrad:
                     continue
                 if s.name in ('backbone.layer2.0.conv1', 'backbone.layer2.0.downsample.0'):
                     continue      # fed by frozen layer1: no data gradient needed
-                lay[s.name] = (off, s.cin * s.k * s.k * s.cout_pad)
+                lay[s.name] = (off, s.cin_store * s.k * s.k * s.cout_pad)
                 off += _round_up(lay[s.name][1], 8)
             lay['head.cls'] = (off, 256 * 9 * 128)
             off += 256 * 9 * 128
@@ -228,16 +314,26 @@ class ParamStore:
         dev = self.device
         scs, bis, self.bn_off = [], [], {}
         off = 0
-        for s in self.convs.values():
-            if not s.bn:
-                continue
-            g, b = self.fview(s.bn + '.weight'), self.fview(s.bn + '.bias')
-            m, v = self.fview(s.bn + '.running_mean'), self.fview(s.bn + '.running_var')
+        frozen_bns = [(s.bn, s.cout) for s in self.convs.values() if s.bn and not s.bn_train] + \
+                     [(n, RLA_C) for n, tr in self.extra_bns if not tr]
+        for name, c in frozen_bns:
+            g, b = self.fview(name + '.weight'), self.fview(name + '.bias')
+            m, v = self.fview(name + '.running_mean'), self.fview(name + '.running_var')
             sc = g / torch.sqrt(v + 1e-5)
             scs.append(sc)
             bis.append(b - m * sc)
-            self.bn_off[s.bn] = off
-            off += s.cout
+            self.bn_off[name] = off
+            off += c
+        # trainable-affine BatchNorms: the tail of the same arrays, re-folded after every optimizer step (refold_bn)
+        self.bn_train_base = off
+        if self.bn_train:
+            for name, (o, c) in self.bn_train_off.items():
+                self.bn_off[name] = off + o
+            g, b = self.tview('bn_train.weight'), self.tview('bn_train.bias')
+            m, v = self.fview('bn_train.running_mean'), self.fview('bn_train.running_var')
+            sc = g / torch.sqrt(v + 1e-5)
+            scs.append(sc)
+            bis.append(b - m * sc)
         wp = torch.zeros(64, 7 * 64, device=dev)
         w = self.fview('backbone.conv1.weight')           # [64][7][7][3] -> [64][448], k = tap*8 + c
         wp[:, :392] = torch.cat([w, torch.zeros(64, 7, 7, 5, device=dev)], -1).reshape(64, 392)
@@ -252,6 +348,17 @@ class ParamStore:
                 setattr(self, name, val.contiguous())
                 self._pack_tab = None        # holds pointers into bn_scale
                 self.generation = getattr(self, 'generation', 0) + 1    # plans built against older buffers are stale
+
+    def refold_bn(self, sp=None):
+        """Eval-mode BatchNorms whose affine parameters train (RLA_ResNet): scale = gamma / sqrt(var + eps), bias = beta -
+        mean * scale, re-made on the device after every optimizer step (one launch over all their channels)."""
+        if not self.bn_train:
+            return
+        o = self.bn_train_base * 4
+        L.check(L.lib.dsl_bn_fold(L.ptr(self.tview('bn_train.weight')), L.ptr(self.tview('bn_train.bias')),
+                                  L.ptr(self.fview('bn_train.running_mean')), L.ptr(self.fview('bn_train.running_var')), 1e-5,
+                                  self.bn_scale.data_ptr() + o, self.bn_bias.data_ptr() + o, self.bn_train_ch,
+                                  sp or L.stream_ptr()), 'dsl_bn_fold')
 
     def refresh_train_packs(self, stream_ptr=None):
         """bf16 forward pack (= cast of the flat buffer) and dgrad packs.  Called after load_state_dict;
@@ -270,6 +377,7 @@ class ParamStore:
             self.wT16 = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
             self._pack_tab = None
         sp = sp or L.stream_ptr()
+        self.refold_bn(sp)          # the packs fold the BatchNorm scale: keep it current first
         if getattr(self, '_pack_tab', None) is None:
             items, start = [], 0
             for name, (off, n) in lay.items():
@@ -279,7 +387,7 @@ class ParamStore:
                     w, co, cop, taps, cin, sc = self.tview('head.regctr_w'), 5, 64, 9, 256, None
                 else:
                     s = self.convs[name]
-                    w, co, cop, taps, cin = self.tview(name + '.weight'), s.cout, s.cout_pad, s.k * s.k, s.cin
+                    w, co, cop, taps, cin = self.tview(name + '.weight'), s.cout, s.cout_pad, s.k * s.k, s.cin_store
                     sc = self.bn_scale[self.bn_off[s.bn]:] if s.bn else None
                 it = L.PackItem()
                 it.w, it.scale, it.out = w.data_ptr(), (sc.data_ptr() if sc is not None else 0), self.wT16.data_ptr() + off * 2
@@ -300,11 +408,15 @@ class ParamStore:
         self.dirty = False
 
     def grad_buckets(self):
-        """Contiguous gradient ranges in the order the backward completes them: head+FPN, layer4, layer3,
-        layer2.  Together they cover the whole flat gradient buffer exactly once."""
+        """Contiguous gradient ranges in the order the backward completes them: head+FPN, last backbone stage, ..., first
+        trainable stage (with the trainable BatchNorm blocks in front of it).  Together they cover the whole flat gradient
+        buffer exactly once."""
         r = self.train_regions
-        b = [r[f'backbone.layer{i}.0.conv1.weight'][0] for i in (2, 3, 4)] + [r['neck.lateral_convs.0.conv.weight'][0],
-                                                                             self.n_train]
+        if self.backbone == 'resnet':
+            first = [r[f'backbone.layer{i}.0.conv1.weight'][0] for i in (2, 3, 4)]
+        else:
+            first = [0] + [r[f'backbone.stages.{i}.0.conv1.weight'][0] for i in (2, 3)]
+        b = first + [r['neck.lateral_convs.0.conv.weight'][0], self.n_train]
         return [(b[3], b[4]), (b[2], b[3]), (b[1], b[2]), (b[0], b[1])]
 
     # -- pointers used by the plans -----------------------------------------------------------------
@@ -358,6 +470,8 @@ class ParamStore:
                     t = torch.randn(shape, generator=g) * 0.01
             elif leaf == 'weight':
                 t = torch.ones(shape)
+                if self.backbone == 'rla' and k.endswith('.bn3.weight'):
+                    t = torch.zeros(shape)          # zero_init_last_bn (resnet_rla.py:251-256)
             else:
                 t = torch.zeros(shape)
                 if k == 'bbox_head.conv_cls.bias':

@@ -254,6 +254,9 @@ class SemiEpochBasedRunner:
         return ck
 
 
+RUNNERS.register_module(name='EpochBasedRunner', module=SemiEpochBasedRunner)     # the supervised config's runner: same loop, no teacher
+
+
 @HOOKS.register_module()
 class OptimizerHook(Hook):
     """mmcv OptimizerHook: zero_grad; loss.backward(); [clip]; step.  Clipping is fused into the SGD kernel."""

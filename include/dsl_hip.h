@@ -75,6 +75,8 @@ typedef struct dsl_conv_desc {
   int32_t cs_real;                                   /* 0 = cs; else the source's real channel count when cs is padded (the
                                                       * 80- / 5-channel predictor gradients stored 128 / 64 wide): only the
                                                       * algorithmic FLOP / byte counts of dsl_prof_* use it */
+  int32_t lds;                                       /* 0 = cs; else the source's pixel stride in elements (>= cs, multiple of
+                                                      * 8): the source is a channel slice [0, cs) of wider rows */
 } dsl_conv_desc;
 
 /* bytes of split-K scratch this conv would like (0 if it will not split); any smaller buffer is legal */
@@ -100,6 +102,9 @@ typedef struct dsl_wgrad_desc {
   float* db;                                         /* fp32 [cd] or NULL */
   void* workspace;
   size_t workspace_bytes;
+  int32_t ldx;                                       /* 0 = cs; else X's pixel stride in elements (X is a channel slice of wider rows) */
+  int32_t shared;                                    /* group launches: 1 = the members are applications of ONE convolution (same dw):
+                                                      * their gradients are summed into dw (RLA's recurrent / conv_out layers) */
 } dsl_wgrad_desc;
 
 int dsl_wgrad_splits(const dsl_wgrad_desc* d);
@@ -122,6 +127,7 @@ int dsl_pack_image(const float* img_nchw, void* out_nhwc8, int n, int h, int w, 
 
 /* 3x3 stride-2 pad-1 max pool, NHWC bf16 (resnet.py:610,638). */
 int dsl_maxpool3x3s2(const void* x, void* y, int n, int h, int w, int c, void* stream);
+int dsl_maxpool3x3s2_ld(const void* x, void* y, int n, int h, int w, int c, int ldy, void* stream);   /* output row stride ldy >= c */
 
 /* GroupNorm(32 groups, eps) + ReLU over level-major NHWC bf16 (mmcv ConvModule norm+act as used at
  * anchor_free_head.py:104-133).  stats = [nseg*n*groups][2] fp32 (mean, rstd), written by fwd.
@@ -148,6 +154,46 @@ typedef struct dsl_gn_desc {
 size_t dsl_groupnorm_workspace_bytes(const dsl_gn_desc* d);
 int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream);
 int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RLA_ResNet layers (mmdet/models/backbones/resnet_rla.py:71-137,289-327): explicit row strides (ld, elements) because the
+ * block input cat(x, h) is ONE buffer [pixel][C + 128] = [x | h (32) | zeros]
+ * ---------------------------------------------------------------------------------------- */
+/* nn.AvgPool2d((2, 2), stride=(2, 2)) on h at a stage transition (:98-100,129-130) and its backward */
+int dsl_avgpool2x2(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int c, void* stream);
+int dsl_avgpool2x2_bwd(const void* gy, int ldgy, void* gx, int ldgx, int n, int h, int w, int c, void* stream);
+/* t = tanh(bn(u)), BN in eval mode folded to (scale, bias) (:318-320), and its backward: g_u, dgamma, dbeta (overwritten;
+ * block records in `workspace`, fixed-order sums) */
+int dsl_bn_tanh_fwd(const void* u, int ldu, const float* scale, const float* bias, void* t, int ldt, long rows, int c,
+                    void* stream);
+size_t dsl_bn_tanh_bwd_workspace_bytes(long rows, int c);
+int dsl_bn_tanh_bwd(const void* gt, int ldgt, const void* t, int ldt, const void* u, int ldu, const float* scale,
+                    const float* mean, const float* var, float eps, void* gu, int ldgu, float* dgamma, float* dbeta,
+                    void* workspace, long rows, int c, void* stream);
+/* eval-mode BatchNorm with TRAINABLE affine parameters (norm_eval freezes the statistics only, :380-388): per-step fold
+ * scale = gamma / sqrt(var + eps), bias = beta - mean * scale over n channels */
+int dsl_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                float* bias, int n, void* stream);
+/* (gamma, beta) gradients of conv -> BN(eval) pairs from the UNSCALED weight gradient dWu (dsl_conv2d_wgrad with scale =
+ * NULL, db = dbeta): dgamma[c] = (<W[c], dWu[c]> - mean[c] dbeta[c]) / sqrt(var[c] + eps), then dWu[c] *= gamma[c] /
+ * sqrt(var[c] + eps) in place.  `items` is a DEVICE array; one workgroup per weight row (row_start = prefix sum of rows). */
+typedef struct dsl_bn_post_item {
+  const float* w; float* dw; float* dgamma; const float* dbeta; const float* gamma; const float* mean; const float* var;
+  int32_t rows, k, row_start, pad_;
+} dsl_bn_post_item;
+int dsl_bn_wgrad_post(const dsl_bn_post_item* items_dev, int n, int total_rows, float eps, void* stream);
+/* one of the above as an op-list entry (DSL_OP_RLA): kind selects the call, the arguments are taken in declaration order
+ * from p[] (pointers), i[] (ints: strides / sizes), f[] (eps), rows */
+enum { DSL_RLA_AVGPOOL = 2, DSL_RLA_AVGPOOL_BWD = 3, DSL_RLA_BN_TANH = 4, DSL_RLA_BN_TANH_BWD = 5,
+       DSL_RLA_BN_FOLD = 6, DSL_RLA_BN_POST = 7 };
+typedef struct dsl_rla_desc {
+  int32_t kind;
+  int32_t i[8];
+  float f[2];
+  int64_t rows;
+  void* p[10];
+} dsl_rla_desc;
+int dsl_rla_op(const dsl_rla_desc* d, void* stream);
 
 /* out[n][y][x][c] = sum over the children of (y,x) in g (backward of the FPN nearest upsample,
  * fpn.py:163-172).  out is (h, w), g is (ch, cw) (normally 2h x 2w); bf16. */
@@ -265,10 +311,11 @@ int dsl_pseudo_label_fuse(const float* dets, const int64_t* labels, const int32_
  * ---------------------------------------------------------------------------------------- */
 enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, DSL_OP_MAXPOOL = 5,
        DSL_OP_SUM2X2 = 6, DSL_OP_COLSUM = 7, DSL_OP_MEMSET = 8, DSL_OP_PACK_IMAGE = 9,
-       DSL_OP_ASSIGN = 10, DSL_OP_LOSS = 11,
+       DSL_OP_ASSIGN = 10, DSL_OP_LOSS = 11,   /* MAXPOOL: i[4] = output row stride (0 = c) */
        DSL_OP_FORK = 12,   /* side stream i[0] (default 1) waits for everything queued so far on stream i[1] (default 0 = caller's) */
        DSL_OP_JOIN = 13,   /* stream i[1] (default 0 = caller's) waits for everything queued so far on side stream i[0] (default 1) */
        DSL_OP_WGRAD_GROUP = 14,  /* desc = dsl_wgrad_desc[i[0]] -> dsl_conv2d_wgrad_group */
+       DSL_OP_RLA = 17,    /* desc = dsl_rla_desc -> dsl_rla_op */
        DSL_OP_RECORD = 15, /* mark "everything queued so far on stream i[0]" in named event slot i[1] (0..15); survives the call */
        DSL_OP_WAIT = 16 }; /* stream i[0] waits for named event slot i[1] (no-op if the slot was never recorded) */
 typedef struct dsl_op {

@@ -404,9 +404,52 @@ def gen_fuse():
     print('wrote fuse.json', [(len(c['dets']), c['targetNum']) for c in cases])
 
 
+def gen_rla():
+    """RLA_ResNet of the reference (mmdet/models/backbones/resnet_rla.py, imported unmodified; `.flops = True` selects its
+    CPU path for the initial h, :297-300) on a seeded 2 x 3 x 64 x 96 input with the synthetic weights of
+    oracle/rla_oracle.py: the four stage outputs and the gradients of sum_i <out_i, r_i> w.r.t. every parameter that
+    _freeze_stages leaves trainable."""
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import rla_oracle as RO
+    R.install()
+    mod = importlib.import_module('mmdet.models.backbones.resnet_rla')
+    net = mod.RLA_ResNet(layers=[3, 4, 6, 3], frozen_stages=1, norm_eval=True, style='pytorch')
+    net.flops = True
+    sd = RO.synth_state_dict(0)
+    bsd = {k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}
+    missing, unexpected = net.load_state_dict(bsd, strict=True), None
+    net.train()
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(2, 3, 64, 96, generator=g) * 40).bfloat16().float()
+    outs = net(x)
+    rs = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * r).sum() for o, r in zip(outs, rs)).backward()
+    named = dict(net.named_parameters())
+    tk = [k for k, p in named.items() if p.requires_grad]
+    assert sorted('backbone.' + k for k in tk) == sorted(k for k in RO.trainable_keys(sd) if k.startswith('backbone.')), 'trainable sets differ'
+    out = dict(x=x.numpy(), n_train=len(tk))
+    for i, (o, r) in enumerate(zip(outs, rs)):
+        out[f'out{i}'] = o.detach().numpy()
+        out[f'r{i}'] = r.numpy()
+    keys = sorted(tk)
+    out['grad_keys'] = np.array(['backbone.' + k for k in keys])
+    out['grad_norms'] = np.array([float(named[k].grad.norm()) for k in keys])
+    # full gradients of a few representative parameters (first / middle / last stage, every kind of layer)
+    for k in ('stages.1.0.conv1.weight', 'stages.1.0.bn1.weight', 'stages.1.0.bn3.bias', 'stages.1.0.downsample.0.weight',
+              'stages.1.0.downsample.1.weight', 'stages.2.3.conv2.weight', 'stages.3.2.conv3.weight', 'stages.3.1.bn2.bias',
+              'conv_outs.1.weight', 'recurrent_convs.2.weight', 'stage_bns.1.2.weight', 'stage_bns.3.0.bias', 'conv_outs.3.weight'):
+        out['grad:backbone.' + k] = named[k].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'rla_tiny.npz'), **out)
+    print('wrote rla_tiny.npz', [tuple(o.shape) for o in outs], len(tk), 'trainable tensors')
+
+
 if __name__ == '__main__':
     if sys.argv[1:] == ['parse_dets']:
         gen_parse_dets()
+        sys.exit(0)
+    if sys.argv[1:] == ['rla']:
+        gen_rla()
         sys.exit(0)
     if sys.argv[1:] == ['fuse']:
         gen_fuse()

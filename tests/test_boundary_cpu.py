@@ -54,14 +54,56 @@ def test_reference_config_builds_unmodified():
     assert type(m).__name__ == 'FCOS' and opt.bias_lr_mult == 2.0 and opt.bias_decay_mult == 0.0
     cfg.merge_from_dict(Config.parse_cfg_options(['model.bbox_head.loss_weight=3.0', 'data.samples_per_gpu=4']))
     assert cfg.model.bbox_head.loss_weight == 3.0 and cfg.data.samples_per_gpu == 4
+    # the DSL config: RLA_ResNet backbone, semi-supervised head, and every section train_detector reads
     dsl = Config.fromfile(os.path.join(os.path.dirname(REF_CFG), [f for f in os.listdir(os.path.dirname(REF_CFG)) if f.startswith('RLA')][0]))
-    with pytest.raises(NotImplementedError):
-        build_detector(dsl.model)          # RLA_ResNet is a "next" row; the error says how to override
-    dsl.merge_from_dict({'model.backbone': dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
-                                                frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=False),
-                                                norm_eval=True, style='caffe')})
     m2 = build_detector(dsl.model)
+    assert type(m2.backbone).__name__ == 'RLA_ResNet' and m2.store.backbone == 'rla'
     assert m2.bbox_head.loss_weight == 3.0 and m2.bbox_head.soft_warm_up == 5000
+    assert m2.backbone.pretrained_checkpoint.endswith('resnet50_rla_2283.pth.tar')
+    from oracle import rla_oracle as RO
+    sd, shapes = m2.state_dict(), RO.rla_param_shapes()
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    assert sorted(k for k, p in m2.named_parameters() if p.requires_grad) == sorted(RO.trainable_keys(RO.synth_state_dict(0)))
+    opt2 = build_optimizer(m2, dsl.optimizer, grad_clip=dsl.optimizer_config.get('grad_clip'))
+    assert opt2.max_norm == 35.0
+    from dsl_amd.runner import SemiEpochBasedRunner, UnlabelPredHook
+    from dsl_amd.apis import build_runner
+    r = build_runner(dsl.runner, default_args=dict(model=m2, optimizer=opt2, work_dir=None, logger=None, meta=None, ema_model=m,
+                                                   scale_invariant=dsl.get('scale_invariant', False)))
+    assert isinstance(r, SemiEpochBasedRunner) and r.scale_invariant and r.max_epochs == 28
+    r.register_training_hooks(dsl.lr_config, dsl.optimizer_config, dsl.ema_config, dsl.checkpoint_config, dsl.log_config)
+    names = [type(h).__name__ for h in r._hooks]
+    assert names == ['StepLrUpdaterHook', 'OptimizerHook', 'EMAOWNHook', 'CheckpointHook', 'TextLoggerHook'], names
+    up = dict(dsl.data.unlabel_pred)
+    up.pop('category_info_path')          # a file of the training machine
+    hook = UnlabelPredHook(up, dsl, 'Det', interval_mode=up['eval_checkpoint_config']['mode'], interval=up['eval_checkpoint_config']['interval'])
+    assert (hook.interval_mode, hook.interval, hook.start_point, hook.iou, hook.use_ema, hook.adathres_compute) == ('iteration', 1, 8, 0.6, True, True)
+
+
+def test_pretrained_backbone_checkpoint_is_loaded_or_loudly_missing(tmp_path, monkeypatch):
+    """init_cfg=dict(type='Pretrained', checkpoint=...) of the configs: the backbone-only checkpoint (un-prefixed keys) goes
+    into the frozen / trainable buffers; a checkpoint that is not on the machine warns instead of silently training on
+    random frozen features."""
+    import warnings
+    from dsl_amd import detectors
+    from dsl_amd.registry import build_detector
+    cfg = fcos_model_cfg()
+    cfg['backbone']['init_cfg'] = dict(type='Pretrained', checkpoint='open-mmlab://detectron2/resnet50_caffe')
+    m = build_detector(cfg)
+    monkeypatch.setenv('DSL_PRETRAINED_DIR', str(tmp_path))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        m.init_weights()
+    assert any('not found' in str(x.message) for x in w)
+    ref = {k[len('backbone.'):]: torch.randn_like(v) for k, v in m.state_dict().items() if k.startswith('backbone.') and v.is_floating_point()}
+    torch.save(dict(state_dict=ref), tmp_path / 'resnet50_msra-5891d200.pth')
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        m.init_weights()
+    assert not any('not found' in str(x.message) for x in w)
+    sd = m.state_dict()
+    assert all(torch.equal(sd['backbone.' + k], v) for k, v in ref.items())
+    assert detectors.resolve_checkpoint(str(tmp_path / 'resnet50_msra-5891d200.pth')) is not None
 
 
 def test_scale_invariant_batch_matches_oracle():

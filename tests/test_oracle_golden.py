@@ -227,3 +227,28 @@ def test_parse_det_results_matches_reference():
         assert got['scores'].tolist() == [o['score'] for o in case['out']]
         assert got['tags'].tolist() == [o['c'] for o in case['out']]
         assert got['rects'].tolist() == [o['bbox'] for o in case['out']]
+
+
+def test_rla_resnet_oracle_matches_reference(golden):
+    """oracle/rla_oracle.py == the reference's RLA_ResNet (resnet_rla.py, imported unmodified by make_golden.py rla): stage
+    outputs, the set of trainable tensors, every gradient norm and the full gradients of thirteen representative parameters
+    (conv / trainable eval-mode BN / downsample / shared conv_out and recurrent conv / per-block stage BN)."""
+    from oracle import fcos_oracle as O
+    from oracle import rla_oracle as RO
+    d = golden('rla_tiny.npz')
+    sd = RO.synth_state_dict(0)
+    tk = [k for k in RO.trainable_keys(sd) if k.startswith('backbone.')]
+    assert len(tk) == int(d['n_train']) and sorted(tk) == sorted(str(k) for k in d['grad_keys'])
+    p = {k: (v.clone().requires_grad_(k in tk) if v.is_floating_point() else v) for k, v in sd.items()}
+    outs = RO.rla_resnet_forward(p, torch.from_numpy(d['x']), O.Quant(False))
+    for i, o in enumerate(outs):
+        assert torch.allclose(o, torch.from_numpy(d[f'out{i}']), rtol=1e-4, atol=1e-5), i
+    sum((o * torch.from_numpy(d[f'r{i}'])).sum() for i, o in enumerate(outs)).backward()
+    norms = dict(zip((str(k) for k in d['grad_keys']), d['grad_norms']))
+    for k in tk:
+        assert float(p[k].grad.norm()) == pytest.approx(float(norms[k]), rel=2e-3, abs=1e-6), k
+    full = [k for k in d.files if k.startswith('grad:')]
+    assert len(full) == 13
+    for k in full:
+        ref = torch.from_numpy(d[k])
+        assert torch.allclose(p[k[5:]].grad, ref, rtol=2e-3, atol=2e-4 * float(ref.abs().max())), k
