@@ -115,3 +115,43 @@ class SyntheticSemiLoader:
         self._pos += 1
         return dict(img=img, img_metas=metas, gt_bboxes=[gtb, ugt], gt_labels=[gtl, ugl],
                     gt_bboxes_ignore=[torch.zeros(0, 4), uig])
+
+
+class SyntheticValLoader:
+    """Validation-side loader contract (what EvalHook / single_gpu_test consume): batches dict(img, img_metas) in dataset
+    order, rank-strided like DistributedSampler(shuffle=False); the dataset attributes the COCO json export and the built-in
+    evaluator need (`img_ids`, `cat_ids`, `annotations`, `num_images`)."""
+
+    def __init__(self, n_images=4, num_classes=80, H=800, W=1344, W_img=None, seed=0, device='cuda', samples_per_gpu=1,
+                 rank=0, world_size=1, cat_ids=None):
+        self.num_images, self.H, self.W, self.W_img = n_images, H, W, (W_img if W_img is not None else W)
+        self.device, self.bs, self.rank, self.world = device, samples_per_gpu, rank, world_size
+        self.img_ids = [1000 + i for i in range(n_images)]
+        self.cat_ids = list(cat_ids) if cat_ids is not None else list(range(1, num_classes + 1))
+        rng = np.random.RandomState(4242 + seed)
+        self.annotations, self._imgs, self.seed = [], {}, seed
+        for _ in range(n_images):
+            b = synth_boxes(rng, int(np.clip(rng.poisson(7), 1, 40)), H=H, W=self.W_img, lo=min(16.0, H / 8), hi=min(600.0, H))
+            lab = rng.randint(0, num_classes, len(b))
+            self.annotations.append([dict(bbox=[float(x[0]), float(x[1]), float(x[2] - x[0]), float(x[3] - x[1])],
+                                          category_id=self.cat_ids[int(l)], iscrowd=0) for x, l in zip(b, lab)])
+        self.dataset = self
+
+    def __len__(self):
+        mine = len(range(self.rank, self.num_images, self.world))
+        return (mine + self.bs - 1) // self.bs
+
+    def _image(self, i):
+        if i not in self._imgs:
+            g = torch.Generator().manual_seed(15485863 * (i + 1) + self.seed)
+            self._imgs[i] = torch.randn(3, self.H, self.W, generator=g).bfloat16().float().to(self.device)
+        return self._imgs[i]
+
+    def __iter__(self):
+        idx = list(range(self.rank, self.num_images, self.world))
+        for k in range(0, len(idx), self.bs):
+            chunk = idx[k:k + self.bs]
+            metas = [dict(filename=f'val_{i:05d}.jpg', ori_filename=f'val_{i:05d}.jpg', ori_shape=(self.H, self.W_img, 3),
+                          img_shape=(self.H, self.W_img, 3), pad_shape=(self.H, self.W, 3),
+                          scale_factor=np.ones(4, dtype=np.float32), flip=False) for i in chunk]
+            yield dict(img=[torch.stack([self._image(i) for i in chunk])], img_metas=[metas])   # MultiScaleFlipAug's one-element lists

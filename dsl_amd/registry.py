@@ -137,8 +137,14 @@ class Config:
     def __getattr__(self, k):
         return getattr(self._cfg, k)
 
+    def __setattr__(self, k, v):
+        self._cfg[k] = _wrap(v)
+
     def __getitem__(self, k):
         return self._cfg[k]
+
+    def __setitem__(self, k, v):
+        self._cfg[k] = _wrap(v)
 
     def get(self, k, default=None):
         return self._cfg.get(k, default)

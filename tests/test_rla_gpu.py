@@ -199,8 +199,11 @@ def test_dsl_config_trains_through_train_detector(tmp_path):
         teacher.init_weights()
     bank = PseudoLabelBank(num_classes=80, thres='adathres.json')
     loader = SyntheticSemiLoader(bank, n_labeled=3, n_unlabeled=3, iters_per_epoch=3, H=128, W=192, W_img=190, img_std=30.0)
+    from dsl_amd.data import SyntheticValLoader
+    cfg.val_dataloader = SyntheticValLoader(n_images=2, H=128, W=192, W_img=190)
+    cfg.evaluation = dict(interval=1, metric='bbox')
     w0 = student.store.train.clone()
-    runner = train_detector(student, [loader], cfg, distributed=False, validate=False, ema_model=teacher)
+    runner = train_detector(student, [loader], cfg, distributed=False, validate=True, ema_model=teacher)
     torch.cuda.synchronize()
     assert runner.iter == 6 and runner.epoch == 2 and runner.ema_flag
     kinds = [type(h).__name__ for h in runner._hooks]
@@ -212,5 +215,7 @@ def test_dsl_config_trains_through_train_detector(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), 'epoch_2.pth')) and os.path.exists(os.path.join(str(tmp_path), 'epoch_2.pth_ema'))
     ck = torch.load(os.path.join(str(tmp_path), 'latest.pth'), map_location='cpu')
     assert set(ck) == {'meta', 'state_dict', 'optimizer'} and len(ck['state_dict']) == 465 and ck['meta']['iter'] == 6
+    ev = [h for h in runner._hooks if type(h).__name__ == 'EvalHook'][0]
+    assert [e for e, _ in ev.history] == [1, 2] and os.path.exists(os.path.join(str(tmp_path), 'eval_epoch_2.bbox.json'))
     hook = [h for h in runner._hooks if type(h).__name__ == 'UnlabelPredHook'][0]
     assert hook.bank is bank and hook.n_refreshed == 3 + 1 and bank.thres is not None
