@@ -22,6 +22,10 @@ CONV_RELU_OUT, CONV_RELU_IN, CONV_OUT_F32, CONV_MASK_FIRST, CONV_MASK_LAST, CONV
 (OP_CONV, OP_WGRAD, OP_GN_FWD, OP_GN_BWD, OP_MAXPOOL, OP_SUM2X2, OP_COLSUM, OP_MEMSET, OP_PACK_IMAGE,
  OP_ASSIGN, OP_LOSS, OP_FORK, OP_JOIN, OP_WGRAD_GROUP, OP_RECORD, OP_WAIT) = range(1, 17)
 OP_RLA = 17
+OP_PACK_DGRAD = 18
+OP_WGRAD_MULTI = 19
+MAX_MULTI = 16
+SLOT_PACKS = 15      # named event: the data-gradient weight packs of the last optimizer step are complete
 (RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST) = range(2, 8)
 MAX_GROUP = 8
 
@@ -113,6 +117,9 @@ lib.dsl_wgrad_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_wgrad_group_workspace_bytes'):
     lib.dsl_wgrad_group_workspace_bytes.restype = C.c_size_t
 lib.dsl_conv2d_workspace_bytes.restype = C.c_size_t
+for _n in ('dsl_wgrad_multi_table_bytes', 'dsl_wgrad_multi_workspace_bytes'):
+    if hasattr(lib, _n):
+        getattr(lib, _n).restype = C.c_size_t
 if hasattr(lib, 'dsl_bn_tanh_bwd_workspace_bytes'):
     lib.dsl_bn_tanh_bwd_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_fcos_workspace_bytes'):
@@ -125,6 +132,8 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
     'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_workspace_bytes': [_vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
     'dsl_wgrad_workspace_bytes': [_vp], 'dsl_wgrad_group_workspace_bytes': [_vp, _i], 'dsl_conv2d_wgrad_group': [_vp, _i, _vp],
+    'dsl_wgrad_multi_config': [_vp], 'dsl_wgrad_multi_table_bytes': [], 'dsl_wgrad_multi_workspace_bytes': [_vp, _vp, _i],
+    'dsl_wgrad_multi_build': [_vp, _vp, _i, _vp, C.c_size_t, _vp, C.c_size_t], 'dsl_conv2d_wgrad_multi': [_vp, _vp, _vp], 'dsl_wgrad_multi_info': [_vp, _vp, _vp, _vp, _vp, _vp],
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
     'dsl_maxpool3x3s2_ld': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_avgpool2x2': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

@@ -962,6 +962,11 @@ struct WgK {
   const uint16_t* dy;
   const uint16_t* x;
   float* ws;
+  // multi-launch (dsl_conv2d_wgrad_multi): with direct = 1 (splits == 1) the finished tile goes straight into dW (x scale)
+  int direct, cd;
+  int totpx;                // = pxstart[nseg] (a runtime-indexed read would keep a table copy of this struct in scratch)
+  float* dwv[DSL_MAX_GROUP];
+  const float* scalev[DSL_MAX_GROUP];
 };
 
 template <int ROWBYTES>
@@ -1190,8 +1195,7 @@ __device__ __forceinline__ SegSel seg_select(const WgK& p, int gp) {
 }
 
 template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
-__global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void wgrad_glds_body(const WgK& p, const int bid, unsigned char* smem) {
   constexpr int NW = WCO * WCI;
   constexpr int YB = BCO * 2, XB = BCI * 2;          // bytes per pixel row of each tile
   constexpr int TILE_Y = KS * YB, TILE_X = KS * XB, STAGE = TILE_Y + TILE_X;
@@ -1213,7 +1217,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
   // once per tap.  Placement only affects speed.
   const int tiles_per_member = p.gx * p.gy;
   const int tiles_per_split_wg = tiles_per_member * p.group;
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int xcd = bid & 7, jj = bid >> 3;
   const int witem = xcd * p.chunk + jj;              // work items are split-major: an XCD owns a contiguous range
   if (jj >= p.chunk || witem >= tiles_per_split_wg * p.splits) return;
   const int sp = witem / tiles_per_split_wg;
@@ -1237,7 +1241,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
   const int tr = tap / p.kw, ts = tap - tr * p.kw;
   const int kt0 = sp * p.tiles_per_split;
   const int kt1 = min(kt0 + p.tiles_per_split, p.ktiles);
-  const int totpx = p.pxstart[p.nseg];
+  const int totpx = p.totpx;
   const gptr_t zero = (gptr_t)g_zero_line;
 
   // per DMA instruction this lane's (row, source channel) inside the tile
@@ -1409,6 +1413,27 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
 #endif
 
   const int frow = lane & 31, fhalf = lane >> 5;
+  if (p.direct) {          // one split: this tile is the whole sum - scale and store it into dW, no partial / reduce pass
+    float* dw_p = p.dwv[0];
+    const float* sc_p = p.scalev[0];
+#pragma unroll
+    for (int g = 1; g < DSL_MAX_GROUP; ++g) {
+      dw_p = member == g ? p.dwv[g] : dw_p;
+      sc_p = member == g ? p.scalev[g] : sc_p;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const long long col = (long long)tap * p.cs + ci0 + wave_ci * (32 * IT) + it * 32 + frow;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int co = co0 + wave_co * (32 * CT) + ct * 32 + (j & 3) + 8 * (j >> 2) + 4 * fhalf;
+          if (co < p.cd) dw_p[(long long)co * p.krow + col] = sc_p ? acc[ct][it][j] * sc_p[co] : acc[ct][it][j];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -1420,6 +1445,72 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
         p.ws[(((long long)sp * p.group + member) * p.cyp + co) * p.krow + col] = acc[ct][it][j];
       }
     }
+}
+
+template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
+__global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  wgrad_glds_body<BCO, BCI, WCO, WCI, KS, NST>(p, (int)blockIdx.x, smem);
+}
+
+// Several weight-gradient launches of ONE tile configuration as one grid (dsl_conv2d_wgrad_multi): sub-launch s owns the
+// blocks [wg_end[s-1], wg_end[s]) (multiples of 8, so a block's XCD is the same as in a launch of its own); its WgK comes
+// from a table in device memory, read once with scalar loads before the K loop.  The host orders the sub-launches by
+// decreasing work per workgroup: the hardware dispatches blocks in index order, so the short ones fill the tail.
+constexpr int kMaxMulti = DSL_MAX_MULTI;
+struct WgMultiHdr {
+  int nsub;
+  int wg_end[kMaxMulti];
+};
+template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
+__global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_multi_kernel(const WgMultiHdr h, const WgK* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int sub = 0, start = 0;
+#pragma unroll
+  for (int s = 1; s < kMaxMulti; ++s) {
+    const bool in = s < h.nsub && (int)blockIdx.x >= h.wg_end[s - 1];
+    sub = in ? s : sub;
+    start = in ? h.wg_end[s - 1] : start;
+  }
+  const WgK p = tab[sub];
+  wgrad_glds_body<BCO, BCI, WCO, WCI, KS, NST>(p, (int)blockIdx.x - start, smem);
+}
+
+// the reduce passes of a multi launch: entry e (one member of one sub-launch with more than one split) owns the blocks
+// [blk_start, blk_start + nblk)
+struct RedEnt {
+  const float* ws;         // this member's first partial: ws + member * cyp * krow
+  float* dw;
+  const float* scale;
+  float* db;               // cleared here for the column-sum pass that follows (or NULL)
+  long long krow, sstride;
+  int splits, cd, blk_start, nblk;
+};
+__global__ void wgrad_reduce_multi_kernel(const RedEnt* __restrict__ tab, int n) {
+  int e = 0;
+  for (int i = 1; i < n; ++i) e = (int)blockIdx.x >= tab[i].blk_start ? i : e;
+  const RedEnt r = tab[e];
+  const int lb = (int)blockIdx.x - r.blk_start;
+  if (lb == 0 && r.db)
+    for (int c = threadIdx.x; c < r.cd; c += blockDim.x) r.db[c] = 0.f;
+  const long long total4 = (long long)r.cd * r.krow / 4;
+  for (long long i = (long long)lb * blockDim.x + threadIdx.x; i < total4; i += (long long)r.nblk * blockDim.x) {
+    const long long el = i * 4;
+    const int co = (int)(el / r.krow);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* base = r.ws + el;
+    int sp = 0;
+    for (; sp + 4 <= r.splits; sp += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(base + sp * r.sstride);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(base + (sp + 1) * r.sstride);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(base + (sp + 2) * r.sstride);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(base + (sp + 3) * r.sstride);
+      s += (a + b) + (c + d);
+    }
+    for (; sp < r.splits; ++sp) s += *reinterpret_cast<const f32x4*>(base + sp * r.sstride);
+    if (r.scale) s *= r.scale[co];
+    *reinterpret_cast<f32x4*>(r.dw + el) = s;
+  }
 }
 
 struct RedK {
@@ -1896,6 +1987,7 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
   DSL_CHECK(ldx >= d->cs && ldx % 8 == 0, "dsl_conv2d_wgrad: ldx=%d must be >= cs=%d and a multiple of 8", ldx, d->cs);
   DSL_CHECK(xo * ldx < (1LL << 31), "dsl_conv2d_wgrad: X has more than 2^31 elements");
   k.pxstart[d->nseg] = px;
+  k.totpx = px;
   k.cs = d->cs; k.cy = d->cy; k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad;
   k.ktiles = ktiles;
   k.tiles_per_split = (ktiles + splits - 1) / splits;
@@ -1992,6 +2084,274 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
       const int rc = dsl_colsum_acc(descs[g].dy, descs[g].db, (long)px, d->cd, d->cy, stream);
       if (rc) return rc;
     }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi launch: the weight gradients of several geometries (one tile configuration) as ONE grid + ONE reduce grid
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMaxRed = 128, kMaxColsum = 64;
+struct ColsumItem { const void* x; float* out; long long rows; int c, ld, clear; };
+struct WgMultiTable {
+  int magic, cfg, nsub, total_blocks;
+  WgMultiHdr hdr;
+  int n_red, red_blocks, n_colsum, pad_;
+  double flops, bytes;
+  ColsumItem colsum[kMaxColsum];
+  WgK k[kMaxMulti];
+  RedEnt red[kMaxRed];
+};
+constexpr int kMultiMagic = 0x574d5431;
+
+int wgrad_fill_k(const dsl_wgrad_desc* descs, int count, int splits, int cfg, WgK& k, long long* px_out, long long* xo_out) {
+  const dsl_wgrad_desc* d = descs;
+  memset(&k, 0, sizeof(k));
+  k.nseg = d->nseg; k.n = d->n;
+  int px = 0;
+  long long xo = 0;
+  for (int s = 0; s < d->nseg; ++s) {
+    k.gh[s] = d->gh[s]; k.gw[s] = d->gw[s]; k.sh[s] = d->sh[s]; k.sw[s] = d->sw[s];
+    k.pxstart[s] = px;
+    k.xoff[s] = xo;
+    k.dhw[s] = make_fastdiv((uint32_t)(d->gh[s] * d->gw[s]));
+    k.dwd[s] = make_fastdiv((uint32_t)d->gw[s]);
+    px += d->n * d->gh[s] * d->gw[s];
+    xo += (long long)d->n * d->sh[s] * d->sw[s];
+  }
+  DSL_CHECK(px < (1 << 20), "dsl_conv2d_wgrad: %d pixels exceed the 2^20 fast-division range", px);
+  const int ldx = d->ldx > 0 ? d->ldx : d->cs;
+  DSL_CHECK(ldx >= d->cs && ldx % 8 == 0, "dsl_conv2d_wgrad: ldx=%d must be >= cs=%d and a multiple of 8", ldx, d->cs);
+  DSL_CHECK(xo * ldx < (1LL << 31), "dsl_conv2d_wgrad: X has more than 2^31 elements");
+  k.pxstart[d->nseg] = px;
+  k.totpx = px;
+  k.cs = d->cs; k.cy = d->cy; k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad;
+  k.ctiles_per_tap = d->cs / 128;
+  k.krow = (long long)d->kh * d->kw * d->cs;
+  k.group = count;
+  k.ldx = ldx;
+  k.cyp = (int)wgrad_cy_pad(d);
+  k.cd = d->cd;
+  for (int g = 0; g < DSL_MAX_GROUP; ++g) {
+    const dsl_wgrad_desc& m = descs[g < count ? g : 0];
+    k.dyv[g] = (const uint16_t*)m.dy;
+    k.xv[g] = (const uint16_t*)m.x;
+    k.dwv[g] = m.dw;
+    k.scalev[g] = m.scale;
+  }
+  k.dy = k.dyv[0]; k.x = k.xv[0];
+  const int bcos[5] = {0, 256, 256, 128, 128}, bcis[5] = {0, 256, 128, 256, 128};
+  DSL_CHECK(k.cyp % bcos[cfg] == 0 && d->cs % bcis[cfg] == 0, "dsl_conv2d_wgrad: tile config %d does not divide cy=%d / cs=%d", cfg, d->cy, d->cs);
+  k.gx = k.cyp / bcos[cfg];
+  k.gy = d->kh * d->kw * d->cs / bcis[cfg];
+  k.splits = splits;
+  k.chunk = (k.gx * k.gy * count * splits + 7) / 8;
+  k.ktiles = (px + 63) / 64;
+  k.tiles_per_split = (k.ktiles + splits - 1) / splits;
+  *px_out = px;
+  *xo_out = xo;
+  return 0;
+}
+
+int wgrad_slots() {
+  static const int slots = [] { const char* e = getenv("DSL_WGRAD_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 160; }();
+  return slots;
+}
+
+// split factors of a multi launch: every workgroup gets at most ~1/slots of the launch's K-tile iterations
+int wgrad_multi_splits(const dsl_wgrad_desc* descs, const int* counts, int nsub, int* splits) {
+  long long total = 0;
+  int off = 0;
+  for (int s = 0; s < nsub; ++s) {
+    int ktiles, tiles, bco;
+    wgrad_geometry(&descs[off], &ktiles, &tiles, &bco);
+    total += (long long)ktiles * tiles * counts[s];
+    off += counts[s];
+  }
+  const int cfg = wgrad_pick(descs);
+  const int slots = wgrad_slots() * (cfg == 4 ? 2 : 1);
+  long long lmax = (total + slots - 1) / slots;
+  if (lmax < 4) lmax = 4;
+  off = 0;
+  for (int s = 0; s < nsub; ++s) {
+    int ktiles, tiles, bco;
+    wgrad_geometry(&descs[off], &ktiles, &tiles, &bco);
+    int sp = (int)((ktiles + lmax - 1) / lmax);
+    const int max_by_k = ktiles / 4 > 0 ? ktiles / 4 : 1;
+    if (sp > max_by_k) sp = max_by_k;
+    if (sp < 1) sp = 1;
+    splits[s] = sp;
+    off += counts[s];
+  }
+  return 0;
+}
+
+int wgrad_multi_check(const dsl_wgrad_desc* descs, const int* counts, int nsub) {
+  DSL_CHECK(descs && counts && nsub >= 1 && nsub <= kMaxMulti, "dsl_wgrad_multi: bad sub-launch list (n=%d)", nsub);
+  const int cfg = wgrad_pick(descs);
+  DSL_CHECK(cfg >= 1 && cfg <= 4, "dsl_wgrad_multi: tile configuration %d has no multi form", cfg);
+  int off = 0;
+  for (int s = 0; s < nsub; ++s) {
+    DSL_CHECK(counts[s] >= 1 && counts[s] <= DSL_MAX_GROUP, "dsl_wgrad_multi: sub-launch %d has %d members", s, counts[s]);
+    const dsl_wgrad_desc* d = &descs[off];
+    DSL_CHECK(d->nseg >= 1 && d->nseg <= DSL_MAX_SEG && d->cs % 128 == 0 && d->cy % 64 == 0 && d->cd <= d->cy,
+              "dsl_wgrad_multi: bad geometry in sub-launch %d", s);
+    DSL_CHECK(wgrad_pick(d) == cfg, "dsl_wgrad_multi: sub-launch %d needs tile configuration %d, the launch uses %d", s, wgrad_pick(d), cfg);
+    for (int g = 0; g < counts[s]; ++g) {
+      DSL_CHECK(d[g].dy && d[g].x && d[g].dw, "dsl_wgrad_multi: null pointer (sub-launch %d member %d)", s, g);
+      DSL_CHECK(!d[g].shared, "dsl_wgrad_multi: shared-weight groups use dsl_conv2d_wgrad_group");
+      DSL_CHECK(wgrad_same_geometry(d, &d[g]), "dsl_wgrad_multi: sub-launch %d member %d has a different geometry", s, g);
+    }
+    off += counts[s];
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int dsl_wgrad_multi_config(const dsl_wgrad_desc* d) {
+  DSL_CHECK(d != nullptr, "dsl_wgrad_multi_config: null descriptor");
+  return d->shared ? 0 : wgrad_pick(d);
+}
+
+extern "C" size_t dsl_wgrad_multi_table_bytes(void) { return sizeof(WgMultiTable); }
+
+extern "C" size_t dsl_wgrad_multi_workspace_bytes(const dsl_wgrad_desc* descs, const int* counts, int nsub) {
+  if (wgrad_multi_check(descs, counts, nsub)) return 0;
+  int splits[kMaxMulti];
+  wgrad_multi_splits(descs, counts, nsub, splits);
+  size_t need = 0;
+  int off = 0;
+  for (int s = 0; s < nsub; ++s) {
+    const dsl_wgrad_desc* d = &descs[off];
+    if (splits[s] > 1) need += (size_t)splits[s] * counts[s] * wgrad_cy_pad(d) * (size_t)d->kh * d->kw * d->cs * sizeof(float);
+    off += counts[s];
+  }
+  return need ? need : 16;
+}
+
+// Fills `table_host` (dsl_wgrad_multi_table_bytes()) for the sub-launches descs[0 .. sum(counts)) (sub-launch s = counts[s]
+// consecutive same-geometry descriptors, all of one tile configuration, dsl_wgrad_multi_config).  The caller copies the
+// bytes to device memory once and passes both copies to dsl_conv2d_wgrad_multi; the table stays valid while the
+// descriptors' pointers and `workspace` do.
+extern "C" int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* counts, int nsub, void* workspace, size_t ws_bytes,
+                                     void* table_host, size_t table_bytes) {
+  if (int rc = wgrad_multi_check(descs, counts, nsub)) return rc;
+  DSL_CHECK(table_host && table_bytes >= sizeof(WgMultiTable), "dsl_wgrad_multi_build: table buffer too small");
+  DSL_CHECK(workspace && ws_bytes >= dsl_wgrad_multi_workspace_bytes(descs, counts, nsub), "dsl_wgrad_multi_build: workspace too small");
+  WgMultiTable* t = (WgMultiTable*)table_host;
+  memset(t, 0, sizeof(*t));
+  t->magic = kMultiMagic;
+  t->cfg = wgrad_pick(descs);
+  t->nsub = nsub;
+  int splits[kMaxMulti], first[kMaxMulti], order[kMaxMulti];
+  wgrad_multi_splits(descs, counts, nsub, splits);
+  long long per_wg[kMaxMulti];
+  {
+    int off = 0;
+    for (int s = 0; s < nsub; ++s) {
+      int ktiles, tiles, bco;
+      wgrad_geometry(&descs[off], &ktiles, &tiles, &bco);
+      per_wg[s] = (ktiles + splits[s] - 1) / splits[s];
+      first[s] = off;
+      order[s] = s;
+      off += counts[s];
+    }
+  }
+  for (int i = 1; i < nsub; ++i)            // longest workgroups first (stable insertion sort)
+    for (int j = i; j > 0 && per_wg[order[j]] > per_wg[order[j - 1]]; --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
+  unsigned char* ws = (unsigned char*)workspace;
+  int blocks = 0, red_blocks = 0;
+  for (int i = 0; i < nsub; ++i) {
+    const int s = order[i];
+    const dsl_wgrad_desc* d = &descs[first[s]];
+    WgK& k = t->k[i];
+    long long px, xo;
+    if (int rc = wgrad_fill_k(d, counts[s], splits[s], t->cfg, k, &px, &xo)) return rc;
+    k.direct = splits[s] == 1 ? 1 : 0;
+    k.ws = (float*)ws;
+    blocks += k.chunk * 8;
+    t->hdr.wg_end[i] = blocks;
+    t->flops += 2.0 * counts[s] * px * (double)d->cd * d->kh * d->kw * d->cs;
+    t->bytes += counts[s] * ((double)px * d->cd * 2.0 + (double)xo * d->cs * 2.0 + (double)d->cd * d->kh * d->kw * d->cs * 4.0);
+    const long long sub_elems = (long long)counts[s] * k.cyp * k.krow;
+    for (int g = 0; g < counts[s]; ++g) {
+      if (!k.direct) {
+        DSL_CHECK(t->n_red < kMaxRed, "dsl_wgrad_multi_build: more than %d reduce entries", kMaxRed);
+        RedEnt& r = t->red[t->n_red++];
+        r.ws = (const float*)ws + (long long)g * k.cyp * k.krow;
+        r.dw = d[g].dw; r.scale = d[g].scale; r.db = d[g].db;
+        r.krow = k.krow; r.sstride = sub_elems; r.splits = splits[s]; r.cd = d->cd;
+        const long long total4 = (long long)d->cd * k.krow / 4;
+        int nb = (int)((total4 + 1023) / 1024);        // ~4 f32x4 per thread
+        if (nb > 512) nb = 512;
+        if (nb < 1) nb = 1;
+        r.blk_start = red_blocks; r.nblk = nb;
+        red_blocks += nb;
+      }
+      if (d[g].db) {
+        DSL_CHECK(t->n_colsum < kMaxColsum, "dsl_wgrad_multi_build: more than %d bias gradients", kMaxColsum);
+        ColsumItem& c = t->colsum[t->n_colsum++];
+        c.x = d[g].dy; c.out = d[g].db; c.rows = px; c.c = d->cd; c.ld = d->cy; c.clear = k.direct;
+      }
+    }
+    if (!k.direct) ws += (size_t)splits[s] * sub_elems * sizeof(float);
+  }
+  t->hdr.nsub = nsub;
+  t->total_blocks = blocks;
+  t->red_blocks = red_blocks;
+  return 0;
+}
+
+// what a table holds (profiling tools): algorithmic flops / bytes of the launch, its workgroups, reduce workgroups, sub-launches
+extern "C" int dsl_wgrad_multi_info(const void* table_host, double* flops, double* bytes, int* blocks, int* red_blocks, int* nsub) {
+  const WgMultiTable* t = (const WgMultiTable*)table_host;
+  DSL_CHECK(t && t->magic == kMultiMagic, "dsl_wgrad_multi_info: not a table of dsl_wgrad_multi_build");
+  if (flops) *flops = t->flops;
+  if (bytes) *bytes = t->bytes;
+  if (blocks) *blocks = t->total_blocks;
+  if (red_blocks) *red_blocks = t->red_blocks;
+  if (nsub) *nsub = t->nsub;
+  return 0;
+}
+
+extern "C" int dsl_conv2d_wgrad_multi(const void* table_host, const void* table_dev, void* stream) {
+  const WgMultiTable* t = (const WgMultiTable*)table_host;
+  DSL_CHECK(t && table_dev && t->magic == kMultiMagic, "dsl_conv2d_wgrad_multi: not a table of dsl_wgrad_multi_build");
+  const WgK* ktab = (const WgK*)((const unsigned char*)table_dev + offsetof(WgMultiTable, k));
+  const RedEnt* rtab = (const RedEnt*)((const unsigned char*)table_dev + offsetof(WgMultiTable, red));
+  hipStream_t st = (hipStream_t)stream;
+  const int prof = dsl_prof_active() ? dsl_prof_begin(3, t->flops, st, t->bytes) : -1;
+  const int bcos[5] = {0, 256, 256, 128, 128}, bcis[5] = {0, 256, 128, 256, 128}, nsts[5] = {2, 2, 3, 3, 2};
+  const size_t lds2 = (size_t)nsts[t->cfg] * 64 * 2 * (bcos[t->cfg] + bcis[t->cfg]);
+  const dim3 grid(t->total_blocks);
+#define LAUNCHM(A, B, C_, D, KS_, S_)                                                                                \
+  do {                                                                                                               \
+    static bool a_ = false;                                                                                          \
+    if (!a_) {                                                                                                       \
+      hipFuncSetAttribute((const void*)wgrad_glds_multi_kernel<A, B, C_, D, KS_, S_>,                                \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                    \
+      a_ = true;                                                                                                     \
+    }                                                                                                                \
+    hipLaunchKernelGGL((wgrad_glds_multi_kernel<A, B, C_, D, KS_, S_>), grid, dim3(64 * C_ * D), lds2, st, t->hdr, ktab); \
+  } while (0)
+  switch (t->cfg) {
+    case 1: LAUNCHM(256, 256, 2, 4, 64, 2); break;
+    case 2: LAUNCHM(256, 128, 4, 2, 64, 3); break;
+    case 3: LAUNCHM(128, 256, 2, 4, 64, 3); break;
+    default: LAUNCHM(128, 128, 2, 2, 64, 2); break;
+  }
+#undef LAUNCHM
+  dsl_prof_end(prof, st);
+  DSL_LAUNCH_CHECK("wgrad_glds_multi_kernel");
+  if (t->n_red > 0) {
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(t->red_blocks), dim3(256), 0, st, rtab, t->n_red);
+    DSL_LAUNCH_CHECK("wgrad_reduce_multi_kernel");
+  }
+  for (int i = 0; i < t->n_colsum; ++i) {
+    const ColsumItem& c = t->colsum[i];
+    const int rc = c.clear ? dsl_colsum(c.x, c.out, (long)c.rows, c.c, c.ld, stream) : dsl_colsum_acc(c.x, c.out, (long)c.rows, c.c, c.ld, stream);
+    if (rc) return rc;
+  }
   return 0;
 }
 

@@ -62,6 +62,13 @@ class OpList:
             self._add(L.OP_FORK)
         self._add(L.OP_WGRAD_GROUP, arr, i=(len(arr), 0, 0, 0, 0, 0, 1 if side else 0))
 
+    def wgrad_multi(self, plan, side=False):
+        """plan: ops.WgradMulti (sub-launches of one tile configuration as one grid)."""
+        if side:
+            self._add(L.OP_FORK)
+        self._add(L.OP_WGRAD_MULTI, i=(0, 0, 0, 0, 0, 0, 1 if side else 0), p=(plan.host.data_ptr(), plan.dev.data_ptr()))
+        self.keep.append(plan)
+
     def join(self, side=1):
         self._add(L.OP_JOIN, i=(side,))
 
@@ -119,6 +126,7 @@ class Plan:
         dev = store.device
         self.dev = dev
         self.bufs = {}
+        self._multi_on, self._wg_pending = False, []
         self.fwd = OpList()
         self.loss_ops = OpList()
         self.assign_ops = OpList()
@@ -301,13 +309,19 @@ class Plan:
                            kh=k, kw=k, stride=1 if spec is None else spec.stride, pad=1 if spec is None else spec.pad,
                            scale=scale, db=db, workspace=self._wg_ws(n, out_hw, in_hw, spec, cy), ldx=ldx, shared=shared)
         if emit:
-            ol.wgrad(d, side=side)
+            if side and self._multi_on:
+                self._wg_pending.append([d])        # goes out with the next _flush_wgrads
+            else:
+                ol.wgrad(d, side=side)
         return d
 
     def _wgrad_group(self, ol, descs, side=True, ws_name='wg_ws'):
         """One launch for same-geometry convolutions (the blocks of a ResNet stage, the layers of a head tower): the
         split-K partial traffic of the group is what ONE of its members would need alone."""
         if not descs:
+            return
+        if side and self._multi_on:
+            self._wg_pending.append(list(descs))
             return
         if len(descs) == 1:
             ol.wgrad(descs[0], side=side)
@@ -317,6 +331,26 @@ class Plan:
             C.memmove(C.addressof(arr0[i]), C.addressof(d), C.sizeof(L.WgradDesc))
         need = L.lib.dsl_wgrad_group_workspace_bytes(arr0, len(descs))
         ol.wgrad_group(ops.wgrad_group(descs, workspace=self._wg_buf(need, ws_name)), side=side)
+
+    def _flush_wgrads(self, ol, side=True, ws_name='wg_ws'):
+        """Emits the deferred weight gradients: all sub-launches of one tile configuration as ONE multi launch
+        (dsl_conv2d_wgrad_multi: one grid + one reduce grid, split factors chosen for the launch as a whole)."""
+        pending, self._wg_pending = self._wg_pending, []
+        if not pending:
+            return
+        by_cfg = {}
+        for sub in pending:
+            by_cfg.setdefault(L.lib.dsl_wgrad_multi_config(C.byref(sub[0])), []).append(sub)
+        on, self._multi_on = self._multi_on, False
+        for cfg, subs in by_cfg.items():
+            for lo in range(0, len(subs), L.MAX_MULTI):
+                chunk = subs[lo:lo + L.MAX_MULTI]
+                if cfg == 0 or len(chunk) == 1:
+                    for sub in chunk:
+                        self._wgrad_group(ol, sub, side=side, ws_name=ws_name)
+                else:
+                    ol.wgrad_multi(ops.WgradMulti(chunk, workspace=lambda need: self._wg_buf(need, ws_name)), side=side)
+        self._multi_on = on
 
     def _wg_ws(self, n, out_hw, in_hw, spec, cy):
         need = ops.wgrad_workspace_bytes(n=n, grid=out_hw, src_hw=in_hw, cs=256 if spec is None else spec.cin_store,
@@ -360,9 +394,15 @@ class Plan:
         # is left on the caller's stream to overlap their tail with ...
         GROUP_LAST = os.environ.get('DSL_GROUP_LAST', '1') != '0'
         GROUP = True       # same-geometry weight gradients (tower layers, the blocks of a stage) as one launch
+        # ... and all weight gradients of a segment that share a tile configuration as one multi launch
+        self._multi_on = SIDE and os.environ.get('DSL_WGRAD_MULTI', '1') != '0'
+        self._wg_pending = []
         g_feats = self.buf('g_feats', M, 256)
         # ================= segment 0: head + FPN =================
         ol = OpList()
+        ol.wait(L.SLOT_PACKS, stream=0)      # the data-gradient weight packs of the last optimizer step (ParamStore.repack_dgrad)
+        TOWER8 = os.environ.get('DSL_TOWER_GROUP8', '1') != '0'   # both towers' weight gradients as ONE launch of 8: half the pixel splits
+        tower_group = []
         for ti, tower in enumerate(('cls_convs', 'reg_convs')):
             lays = self.tower[tower]
             g_act = self.buf(f'g_{tower}_act3', M, 256)
@@ -374,7 +414,8 @@ class Plan:
                 self._wgrad(ol, None, lp.g_rc, lays[3]['act'], N, ls, ls, cy=64, cd=5, wregion='head.regctr_w',
                             bregion='head.regctr_b', side=SIDE)
                 ol.conv(self._dgrad('head.regctr', lp.g_rc, g_act, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1, cs_real=5))
-            tower_group = []
+            if not TOWER8:
+                tower_group = []
             for i in (3, 2, 1, 0):
                 lay = lays[i]
                 base = lay['gn']
@@ -394,8 +435,9 @@ class Plan:
                 else:
                     ol.conv(self._dgrad(lay['spec'].name, g_pre, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1,
                                         pad=1, addend=g_feats if ti == 1 else None))
-            if GROUP:
+            if GROUP and (ti == 1 or not TOWER8):
                 self._wgrad_group(ol, tower_group, side=SIDE)
+        self._flush_wgrads(ol, side=SIDE)          # towers + predictors: ready now, the FPN's follow below
         # ---- FPN backward ----
         cv = st.convs
         fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
@@ -448,16 +490,20 @@ class Plan:
         # data-gradient chain.  Named event slot s marks "side-stream work of segment s queued": once it has fired, gradient
         # bucket s is complete - the data-parallel wrapper's communication stream waits for exactly that
         # (dsl_stream_wait_slot) and starts the bucket's all-reduce, independent of the caller's stream.
+        self._flush_wgrads(ol, side=SIDE)
         ol.record(0)
         self.bwd_segments.append((ol, dict(bucket=buckets[0], slot=0, main=False)))
         # ================= backbone: layer4, layer3, layer2 =================
         if rla:
             from . import engine_rla
+            self._multi_on = False             # the recurrent path's side-stream ops depend on the order of the weight gradients
             engine_rla.build_backward(self, buckets, SIDE)
             return
         blocks_by_stage = {li: [b for b in self.blocks if b['stage'] == li] for li in (1, 2, 3)}
         for li in (3, 2, 1):
             ol = OpList()
+            if li == 1:
+                self._multi_on = False         # layer2: four tile configurations, and the caller's stream takes the tail group itself
             blks = blocks_by_stage[li]
             hw = blks[0]['out_hw']
             planes = blks[0]['planes']
@@ -499,6 +545,7 @@ class Plan:
                     # last segment: the caller's stream has nothing left to do, it takes the last group itself
                     self._wgrad_group(ol, grp_descs, side=SIDE and not (tail_main and grp_descs is g1),
                                       ws_name='wg_ws_main' if (tail_main and grp_descs is g1) else 'wg_ws')
+            self._flush_wgrads(ol, side=SIDE)
             seg = 4 - li                      # 1, 2, 3
             ol.record(seg)
             if li == 1:                       # last segment: everything must be complete when the list returns

@@ -95,6 +95,39 @@ def wgrad_group(descs, workspace=None):
     return arr
 
 
+class WgradMulti:
+    """Launch plan of dsl_conv2d_wgrad_multi: `subs` = list of same-geometry descriptor lists, all of one tile
+    configuration (lib.dsl_wgrad_multi_config).  Owns the host table, its device copy and references to the descriptors."""
+
+    def __init__(self, subs, workspace=None, device='cuda'):
+        assert 1 <= len(subs) <= L.MAX_MULTI and all(1 <= len(g) <= L.MAX_GROUP for g in subs)
+        flat = [d for g in subs for d in g]
+        self.descs = (L.WgradDesc * len(flat))()
+        for i, d in enumerate(flat):
+            C.memmove(C.addressof(self.descs[i]), C.addressof(d), C.sizeof(L.WgradDesc))
+            self.descs[i].splits = 0
+        self.counts = (C.c_int * len(subs))(*[len(g) for g in subs])
+        self.nsub = len(subs)
+        need = lib.dsl_wgrad_multi_workspace_bytes(self.descs, self.counts, self.nsub)
+        if need == 0:
+            L.check(-1, 'dsl_wgrad_multi_workspace_bytes')
+        self.workspace_bytes = need
+        if callable(workspace):                     # workspace(need) -> tensor: the caller's shared scratch buffer
+            workspace = workspace(need)
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        assert workspace.numel() * workspace.element_size() >= need
+        nb = lib.dsl_wgrad_multi_table_bytes()
+        self.host = torch.zeros(nb, dtype=torch.uint8)
+        L.check(lib.dsl_wgrad_multi_build(self.descs, self.counts, self.nsub, L.ptr(workspace), workspace.numel() * workspace.element_size(),
+                                          C.c_void_p(self.host.data_ptr()), nb), 'dsl_wgrad_multi_build')
+        self.dev = self.host.to(device)
+        self._keep = (flat, workspace)
+
+    def run(self, stream=None):
+        L.check(lib.dsl_conv2d_wgrad_multi(C.c_void_p(self.host.data_ptr()), L.ptr(self.dev), stream or L.stream_ptr()), 'dsl_conv2d_wgrad_multi')
+
+
 def conv2d_wgrad_group(descs, workspace=None):
     arr = wgrad_group(descs, workspace)
     L.check(lib.dsl_conv2d_wgrad_group(arr, len(descs), L.stream_ptr()), 'dsl_conv2d_wgrad_group')

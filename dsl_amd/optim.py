@@ -2,10 +2,15 @@
 paramwise rules (bias_lr_mult / bias_decay_mult), gradient-norm clipping and the bf16 re-pack in one
 pass.  Replaces torch.optim.SGD + mmcv OptimizerHook's clip_grad_norm_
 (mmdet/apis/train.py:111,157-166; configs/fcos_semi/*.py `optimizer`, `optimizer_config`)."""
+import os
+
 import torch
 
 from . import _lib as L
 from .registry import OPTIMIZERS
+
+
+_PACK_SIDE = os.environ.get('DSL_PACK_SIDE', '1') != '0'     # data-gradient weight packs off the caller's stream (measured: tools/exp_r2l.sh)
 
 
 @OPTIMIZERS.register_module(name='SGD')
@@ -53,7 +58,7 @@ class FlatSGD:
                                    L.ptr(st.group), st.n_train, lr, self.momentum, self.weight_decay, blr,
                                    self.bias_decay_mult, L.ptr(gptr), self.max_norm or 0.0, int(self.steps == 0), sp),
                 'dsl_sgd_step')
-        st.repack_dgrad(sp)
+        st.repack_dgrad(sp, side=_PACK_SIDE)
         self.steps += 1
 
     def state_dict(self):

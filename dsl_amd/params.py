@@ -369,13 +369,16 @@ class ParamStore:
         L.check(L.lib.dsl_cast_bf16(L.ptr(self.train), L.ptr(self.train16), self.n_train, sp), 'dsl_cast_bf16')
         self.repack_dgrad(sp)
 
-    def repack_dgrad(self, sp=None):
-        """All dgrad packs in ONE launch (dsl_pack_dgrad_batched) from a device-resident item table."""
+    def repack_dgrad(self, sp=None, side=False):
+        """All dgrad packs in ONE launch (dsl_pack_dgrad_batched) from a device-resident item table.
+        side=True: the launch goes to the library's side stream behind everything queued on `sp` so far and marks named
+        event SLOT_PACKS; only the backward pass reads these packs, it waits for that event (Engine: first backward op),
+        and the next forward pass starts without them."""
         import ctypes as C
         lay, total = self.wT_layout()
         if self.wT16 is None or self.wT16.device != self.device:
             self.wT16 = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
-            self._pack_tab = None
+            self._pack_tab = self._pack_ops = None
         sp = sp or L.stream_ptr()
         self.refold_bn(sp)          # the packs fold the BatchNorm scale: keep it current first
         if getattr(self, '_pack_tab', None) is None:
@@ -399,7 +402,17 @@ class ParamStore:
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
             self._pack_tab = (host.to(self.device), len(items), start)
         tab, n, blocks = self._pack_tab
-        L.check(L.lib.dsl_pack_dgrad_batched(L.ptr(tab), n, blocks, sp), 'dsl_pack_dgrad_batched')
+        if side:
+            ops_ = getattr(self, '_pack_ops', None)
+            if ops_ is None:
+                ops_ = (L.Op * 3)()
+                ops_[0].kind, ops_[0].i[0], ops_[0].i[1] = L.OP_FORK, 1, 0
+                ops_[1].kind, ops_[1].p[0], ops_[1].i[0], ops_[1].i[1], ops_[1].i[6] = L.OP_PACK_DGRAD, tab.data_ptr(), n, blocks, 1
+                ops_[2].kind, ops_[2].i[0], ops_[2].i[1] = L.OP_RECORD, 1, L.SLOT_PACKS
+                self._pack_ops = ops_
+            L.check(L.lib.dsl_run_ops(ops_, 3, sp), 'dsl_run_ops(pack_dgrad)')
+        else:
+            L.check(L.lib.dsl_pack_dgrad_batched(L.ptr(tab), n, blocks, sp), 'dsl_pack_dgrad_batched')
 
     def refresh(self):
         assert self.device.type == 'cuda', 'the HIP packs live on the GPU'

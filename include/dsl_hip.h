@@ -118,6 +118,26 @@ int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream);
 size_t dsl_wgrad_group_workspace_bytes(const dsl_wgrad_desc* descs, int count);
 int dsl_conv2d_wgrad_group(const dsl_wgrad_desc* descs, int count, void* stream);
 
+/* Multi launch: the weight gradients of up to DSL_MAX_MULTI sub-launches (sub-launch s = counts[s] consecutive descriptors
+ * of one geometry, as in dsl_conv2d_wgrad_group) that share one tile configuration (dsl_wgrad_multi_config: 1..4; 0 = has
+ * no multi form) as ONE grid and ONE reduce grid: the backward pass of a whole FPN or ResNet stage instead of one launch
+ * pair per layer.  Split factors are chosen for the launch as a whole (every workgroup gets about 1/DSL_WGRAD_SLOTS of its
+ * K iterations), sub-launches that end up with one split write dW directly and have no partial tiles or reduce pass.
+ * The launch plan is a table the caller owns: dsl_wgrad_multi_build fills `table_host` (dsl_wgrad_multi_table_bytes()
+ * bytes of host memory), the caller copies those bytes to device memory once and passes both to
+ * dsl_conv2d_wgrad_multi.  The table holds the descriptors' pointers and `workspace`
+ * (>= dsl_wgrad_multi_workspace_bytes): rebuild it when they change.  Results are bit-identical to the same sub-launches
+ * run through dsl_conv2d_wgrad_group with the same split factors; with different split factors they differ by fp32
+ * summation order only. */
+#define DSL_MAX_MULTI 16
+int dsl_wgrad_multi_config(const dsl_wgrad_desc* d);
+size_t dsl_wgrad_multi_table_bytes(void);
+size_t dsl_wgrad_multi_workspace_bytes(const dsl_wgrad_desc* descs, const int* counts, int nsub);
+int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* counts, int nsub, void* workspace, size_t workspace_bytes,
+                          void* table_host, size_t table_bytes);
+int dsl_conv2d_wgrad_multi(const void* table_host, const void* table_dev, void* stream);
+int dsl_wgrad_multi_info(const void* table_host, double* flops, double* bytes, int* blocks, int* red_blocks, int* nsub);
+
 /* ------------------------------------------------------------------------------------------
  * Memory-bound fused layers
  * ---------------------------------------------------------------------------------------- */
@@ -317,7 +337,9 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_WGRAD_GROUP = 14,  /* desc = dsl_wgrad_desc[i[0]] -> dsl_conv2d_wgrad_group */
        DSL_OP_RLA = 17,    /* desc = dsl_rla_desc -> dsl_rla_op */
        DSL_OP_RECORD = 15, /* mark "everything queued so far on stream i[0]" in named event slot i[1] (0..15); survives the call */
-       DSL_OP_WAIT = 16 }; /* stream i[0] waits for named event slot i[1] (no-op if the slot was never recorded) */
+       DSL_OP_WAIT = 16,   /* stream i[0] waits for named event slot i[1] (no-op if the slot was never recorded) */
+       DSL_OP_PACK_DGRAD = 18, /* dsl_pack_dgrad_batched(p[0] = item table, i[0] = items, i[1] = blocks) */
+       DSL_OP_WGRAD_MULTI = 19 }; /* dsl_conv2d_wgrad_multi(p[0] = table_host, p[1] = table_dev) */
 typedef struct dsl_op {
   int32_t kind;
   int32_t i[7];            /* small integer arguments for the simple ops; i[6] = s > 0: run this op on the library's

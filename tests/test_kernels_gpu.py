@@ -338,6 +338,75 @@ def test_wgrad_group(K, case, count):
             assert torch.allclose(db.cpu(), rdb, rtol=1e-3, atol=1e-2)
 
 
+MULTI_SETS = {
+    # every sub-launch: (members, N, Ci, Co, H, W, k, stride, pad); one tile configuration per set
+    'cfg1_256x256': [(3, 2, 256, 256, 40, 52, 3, 1, 1), (1, 2, 512, 256, 20, 26, 1, 1, 0), (2, 2, 256, 512, 5, 7, 1, 1, 0),
+                     (1, 1, 512, 256, 13, 21, 1, 2, 0), (1, 2, 256, 256, 2, 3, 3, 2, 1)],
+    'cfg3_128x256': [(1, 2, 256, 80, 30, 40, 3, 1, 1), (1, 2, 256, 5, 30, 40, 3, 1, 1), (2, 2, 512, 128, 9, 11, 1, 1, 0)],
+    'cfg4_128x128': [(2, 2, 128, 128, 12, 17, 3, 1, 1), (1, 2, 128, 64, 30, 31, 1, 1, 0)],
+    'cfg2_256x128': [(2, 2, 128, 512, 12, 17, 1, 1, 0), (1, 2, 128, 256, 40, 41, 3, 1, 1)],
+}
+
+
+@pytest.mark.parametrize('name', list(MULTI_SETS))
+def test_wgrad_multi(K, name):
+    """dsl_conv2d_wgrad_multi: sub-launches of different geometries as one grid + one reduce grid == autograd, and
+    bit-identical on repeat (no atomics in the weight sums); direct (one split) and reduced sub-launches both occur."""
+    L, ops = K
+    import ctypes as C
+    g = torch.Generator().manual_seed(3 + len(name))
+    subs, checks = [], []
+    for (cnt, N, Ci, Co, H, W, k, s, p) in MULTI_SETS[name]:
+        cy = (Co + 63) // 64 * 64
+        if cy == 64 and name.startswith('cfg3'):
+            cy = 64
+        grp = []
+        for m in range(cnt):
+            x = rnd(N, Ci, H, W, g=g)
+            w = rnd(Co, Ci, k, k, g=g).requires_grad_()
+            y = F.conv2d(x, w, None, s, p)
+            Ho, Wo = y.shape[2:]
+            dy = rnd(N, Co, Ho, Wo, g=g)
+            y.backward(dy)
+            scale = (torch.rand(Co, generator=g) + 0.5) if m % 2 == 0 else None
+            ref = w.grad if scale is None else w.grad * scale[:, None, None, None]
+            dyp = torch.cat([dy.permute(0, 2, 3, 1), torch.zeros(N, Ho, Wo, cy - Co)], -1).reshape(-1, cy).bfloat16().cuda()
+            dw = torch.full((Co, k, k, Ci), float('nan'), dtype=torch.float32, device='cuda')
+            db = torch.full((Co,), float('nan'), dtype=torch.float32, device='cuda') if m != 1 else None
+            grp.append(ops.wgrad_desc(dyp, nhwc(x), dw, n=N, grid=[(Ho, Wo)], src_hw=[(H, W)], cs=Ci, cy=cy, cd=Co, kh=k, kw=k,
+                                      stride=s, pad=p, scale=None if scale is None else scale.cuda(), db=db))
+            checks.append((ref.permute(0, 2, 3, 1), dy.sum((0, 2, 3)), dw, db))
+        subs.append(grp)
+    cfgs = {L.lib.dsl_wgrad_multi_config(C.byref(d)) for grp in subs for d in grp}
+    assert cfgs == {int(name[3])}, cfgs
+    plan = ops.WgradMulti(subs)
+    plan.run()
+    sync()
+    first = []
+    for ref, rdb, dw, db in checks:
+        got = dw.cpu()
+        assert torch.allclose(got, ref, rtol=1e-2, atol=2e-2 * float(ref.abs().max())), (name, (got - ref).abs().max())
+        if db is not None:
+            assert torch.allclose(db.cpu(), rdb, rtol=1e-3, atol=1e-2)
+        first.append(got.clone())
+        dw.fill_(float('nan'))
+    plan.run()
+    sync()
+    for (ref, rdb, dw, db), f in zip(checks, first):
+        assert torch.equal(dw.cpu(), f)
+
+
+def test_wgrad_multi_rejects_mixed_tile_configurations(K):
+    L, ops = K
+    z = lambda *s: torch.zeros(*s, device='cuda', dtype=torch.bfloat16)
+    a = ops.wgrad_desc(z(2 * 8 * 8, 256), z(2 * 8 * 8, 256), torch.zeros(256, 1, 1, 256, device='cuda'), n=2, grid=[(8, 8)],
+                       src_hw=[(8, 8)], cs=256, cy=256, cd=256, kh=1, kw=1)
+    b = ops.wgrad_desc(z(2 * 8 * 8, 128), z(2 * 8 * 8, 128), torch.zeros(128, 1, 1, 128, device='cuda'), n=2, grid=[(8, 8)],
+                       src_hw=[(8, 8)], cs=128, cy=128, cd=128, kh=1, kw=1)
+    with pytest.raises(RuntimeError, match='tile configuration'):
+        ops.WgradMulti([[a], [b]])
+
+
 def test_wgrad_group_rejects_mixed_geometry(K):
     L, ops = K
     a = ops.wgrad_desc(torch.zeros(2 * 8 * 8, 128, device='cuda', dtype=torch.bfloat16), torch.zeros(2 * 8 * 8, 128, device='cuda', dtype=torch.bfloat16),

@@ -4,9 +4,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 export TMPDIR=/tmp
 TAG=${1:-r2x}
-python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-prof > gpurun_out/${TAG}_bench.log 2>&1
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-prof --no-dsl > gpurun_out/${TAG}_bench.log 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof > $R/gpurun_out/${TAG}_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof --no-dsl > $R/gpurun_out/${TAG}_rocprof.log 2>&1
 cd $R
 DB=$(find gpurun_out/prof_${TAG} -name '*_results.db' | head -1)
 python tools/rocprof_summary.py $DB > gpurun_out/${TAG}_kernel_stats.txt

@@ -66,6 +66,20 @@ for lname, ol in lists:
             fl = 2.0 * px * d.cd * d.kh * d.kw * d.cs
             by = px * d.cy * 2 + spx * d.cs * 2 + d.cd * d.kh * d.kw * d.cs * 4
             desc = f"wgrad {d.kh}x{d.kw} s{d.stride}     {d.cs:4d}->{d.cd:4d} px{px:6d} nseg{d.nseg}"
+        elif op.kind == L.OP_WGRAD_GROUP:
+            cnt = op.i[0]
+            arr = C.cast(op.desc, C.POINTER(L.WgradDesc))
+            d = arr[0]
+            px = sum(d.n * d.gh[s] * d.gw[s] for s in range(d.nseg))
+            spx = sum(d.n * d.sh[s] * d.sw[s] for s in range(d.nseg))
+            fl = 2.0 * px * d.cd * d.kh * d.kw * d.cs * cnt
+            by = (px * d.cy * 2 + spx * d.cs * 2 + d.cd * d.kh * d.kw * d.cs * 4) * cnt
+            desc = f"wgrad {d.kh}x{d.kw} s{d.stride} x{cnt:<3d} {d.cs:4d}->{d.cd:4d} px{px:6d} nseg{d.nseg}"
+        elif op.kind == L.OP_WGRAD_MULTI:
+            f_, b_, nb, nr, ns = C.c_double(), C.c_double(), C.c_int(), C.c_int(), C.c_int()
+            L.lib.dsl_wgrad_multi_info(C.c_void_p(op.p[0]), C.byref(f_), C.byref(b_), C.byref(nb), C.byref(nr), C.byref(ns))
+            fl, by = f_.value, b_.value
+            desc = f"wgrad multi: {ns.value} sub-launches, {nb.value} + {nr.value} workgroups"
         elif op.kind in (L.OP_GN_FWD, L.OP_GN_BWD):
             d = C.cast(op.desc, C.POINTER(L.GnDesc)).contents
             px = sum(d.n * d.h[s] * d.w[s] for s in range(d.nseg))
