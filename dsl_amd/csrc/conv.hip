@@ -967,6 +967,12 @@ struct WgK {
   int totpx;                // = pxstart[nseg] (a runtime-indexed read would keep a table copy of this struct in scratch)
   float* dwv[DSL_MAX_GROUP];
   const float* scalev[DSL_MAX_GROUP];
+  // bias gradients db[co] = sum over pixels of dY[.][co], summed by the tap-0 / first-cin-tile workgroups from the dY stages
+  // they stream anyway: dbmask bit g = member g has a db; partial sums go to dbws[(split * group + member) * cyp + co]
+  // (direct launches: straight into dbv[member]).  Fixed summation order, no atomics.
+  int dbmask;
+  float* dbws;
+  float* dbv[DSL_MAX_GROUP];
 };
 
 template <int ROWBYTES>
@@ -1143,6 +1149,14 @@ __device__ __forceinline__ u32x2 lds_tr_read_b64(unsigned addr) {
 struct Frag {
   u32x2 lo, hi;
 };
+__device__ __forceinline__ unsigned lds_read_b32_asm(unsigned addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wait_lds4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
 // Wait for the outstanding transpose reads AND tell the compiler the fragment registers change here
 // ("+v"): otherwise it may copy an asm-loaded register before the data has landed (the destination of an
 // inline-asm load counts as written when the statement ends, not when the LDS returns).
@@ -1228,13 +1242,21 @@ __device__ __forceinline__ void wgrad_glds_body(const WgK& p, const int bid, uns
   // loop would make hipcc drain the DMA queue)
   const uint16_t* dy_p = p.dyv[0];
   const uint16_t* x_p = p.xv[0];
+  float* db_p = p.dbv[0];
 #pragma unroll
   for (int g = 1; g < DSL_MAX_GROUP; ++g) {
     dy_p = member == g ? p.dyv[g] : dy_p;
     x_p = member == g ? p.xv[g] : x_p;
+    db_p = member == g ? p.dbv[g] : db_p;
   }
   const int co0 = (rem_wg % p.gx) * BCO;
   const int colt = rem_wg / p.gx;
+  // column sums of dY (the bias gradient) ride along in the workgroups of column tile 0
+  const bool do_db = colt == 0 && ((p.dbmask >> member) & 1);
+  constexpr int DB_PAIRS = BCO / 2, DB_RG = 64 * NW / DB_PAIRS, DB_ROWS = KS / DB_RG;
+  static_assert(DB_ROWS % 4 == 0 && DB_RG * DB_PAIRS == 64 * NW, "bias-gradient thread mapping");
+  const int db_cp = tid % DB_PAIRS, db_rg = tid / DB_PAIRS;
+  float db_lo = 0.f, db_hi = 0.f;
   const int ctiles = p.cs / BCI;
   const int tap = colt / ctiles;
   const int ci0 = (colt - tap * ctiles) * BCI;
@@ -1405,6 +1427,24 @@ __device__ __forceinline__ void wgrad_glds_body(const WgK& p, const int bid, uns
       if (!(p.dbg & 2))
 #endif
       compute(slot_c);
+      if (do_db) {              // this stage's dY tile: rows db_rg * DB_ROWS .. of column pair db_cp (same swizzle as the DMA wrote)
+        const unsigned st = lds_base + slot_c * STAGE;
+#pragma unroll
+        for (int r4 = 0; r4 < DB_ROWS; r4 += 4) {
+          unsigned v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = db_rg * DB_ROWS + r4 + j;
+            v[j] = lds_read_b32_asm(st + row * YB + ((((db_cp * 4) >> 6) ^ (row & 3)) << 6) + ((db_cp * 4) & 63));
+          }
+          wait_lds4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            db_lo += __uint_as_float(v[j] << 16);
+            db_hi += __uint_as_float(v[j] & 0xffff0000u);
+          }
+        }
+      }
       slot_c = (slot_c + 1 == NST) ? 0 : slot_c + 1;
     }
   }
@@ -1412,6 +1452,24 @@ __device__ __forceinline__ void wgrad_glds_body(const WgK& p, const int bid, uns
   if (p.dbg & 4) return;
 #endif
 
+  if (do_db) {               // fold the row groups in a fixed order; one value per column leaves the workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    red[(db_rg * DB_PAIRS + db_cp) * 2] = db_lo;
+    red[(db_rg * DB_PAIRS + db_cp) * 2 + 1] = db_hi;
+    __syncthreads();
+    if (tid < BCO) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < DB_RG; ++r) sacc += red[(r * DB_PAIRS + (tid >> 1)) * 2 + (tid & 1)];
+      const int co = co0 + tid;
+      if (p.direct) {
+        if (co < p.cd) db_p[co] = sacc;
+      } else {
+        p.dbws[((long long)sp * p.group + member) * p.cyp + co] = sacc;
+      }
+    }
+  }
   const int frow = lane & 31, fhalf = lane >> 5;
   if (p.direct) {          // one split: this tile is the whole sum - scale and store it into dW, no partial / reduce pass
     float* dw_p = p.dwv[0];
@@ -1482,7 +1540,9 @@ struct RedEnt {
   const float* ws;         // this member's first partial: ws + member * cyp * krow
   float* dw;
   const float* scale;
-  float* db;               // cleared here for the column-sum pass that follows (or NULL)
+  float* db;               // bias gradient: the splits' column-sum partials dbws[sp * dbstride + c] folded in order (or NULL)
+  const float* dbws;
+  long long dbstride;
   long long krow, sstride;
   int splits, cd, blk_start, nblk;
 };
@@ -1492,7 +1552,11 @@ __global__ void wgrad_reduce_multi_kernel(const RedEnt* __restrict__ tab, int n)
   const RedEnt r = tab[e];
   const int lb = (int)blockIdx.x - r.blk_start;
   if (lb == 0 && r.db)
-    for (int c = threadIdx.x; c < r.cd; c += blockDim.x) r.db[c] = 0.f;
+    for (int c = threadIdx.x; c < r.cd; c += blockDim.x) {
+      float sacc = 0.f;
+      for (int sp = 0; sp < r.splits; ++sp) sacc += r.dbws[sp * r.dbstride + c];
+      r.db[c] = sacc;
+    }
   const long long total4 = (long long)r.cd * r.krow / 4;
   for (long long i = (long long)lb * blockDim.x + threadIdx.x; i < total4; i += (long long)r.nblk * blockDim.x) {
     const long long el = i * 4;
@@ -1516,7 +1580,8 @@ __global__ void wgrad_reduce_multi_kernel(const RedEnt* __restrict__ tab, int n)
 struct RedK {
   float* dw[DSL_MAX_GROUP];
   const float* scale[DSL_MAX_GROUP];
-  float* db[DSL_MAX_GROUP];        // bias-gradient vectors to clear for the column-sum kernel that follows (or NULL)
+  float* db[DSL_MAX_GROUP];        // bias-gradient vectors: summed from dbws, or cleared for the column-sum kernel that follows (or NULL)
+  const float* dbws;               // [split][member][cy] column-sum partials of the DMA kernels (NULL: v1 kernel)
 };
 
 // sums the split partials ws[split][member][cy][krow] of member blockIdx.y into its dW (x scale)
@@ -1535,7 +1600,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, const RedK r, 
 #pragma unroll
     for (int g = 1; g < DSL_MAX_GROUP; ++g) db = member == g ? r.db[g] : db;
     if (db)
-      for (int c = threadIdx.x; c < cd; c += blockDim.x) db[c] = 0.f;
+      for (int c = threadIdx.x; c < cd; c += blockDim.x) {
+        float sacc = 0.f;
+        if (r.dbws)                 // in-kernel column sums: fold the splits in order; else cleared for the column-sum pass
+          for (int sp = 0; sp < splits; ++sp) sacc += r.dbws[((long long)sp * group + member) * cy + c];
+        db[c] = sacc;
+      }
   }
   const long long total4 = (long long)cd * krow / 4;
   const long long sstride = (long long)group * cy * krow;
@@ -1917,13 +1987,13 @@ static size_t wgrad_cy_pad(const dsl_wgrad_desc* d) {       // rows of one parti
 
 extern "C" size_t dsl_wgrad_workspace_bytes(const dsl_wgrad_desc* d) {
   const int splits = d->splits > 0 ? d->splits : dsl_wgrad_splits(d);
-  return (size_t)splits * wgrad_cy_pad(d) * (size_t)d->kh * d->kw * d->cs * sizeof(float);
+  return (size_t)splits * wgrad_cy_pad(d) * ((size_t)d->kh * d->kw * d->cs + 1) * sizeof(float);    // + one row of column sums
 }
 
 extern "C" size_t dsl_wgrad_group_workspace_bytes(const dsl_wgrad_desc* descs, int count) {
   if (!descs || count < 1) return 0;
   if (count == 1) return dsl_wgrad_workspace_bytes(descs);
-  return (size_t)wgrad_splits_for(descs, count) * count * wgrad_cy_pad(descs) * (size_t)descs->kh * descs->kw * descs->cs * sizeof(float);
+  return (size_t)wgrad_splits_for(descs, count) * count * wgrad_cy_pad(descs) * ((size_t)descs->kh * descs->kw * descs->cs + 1) * sizeof(float);
 }
 
 extern "C" int dsl_colsum(const void* x, float* out, long rows, int c, int ld, void* stream);
@@ -1966,7 +2036,7 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
   }
   const int splits = count == 1 ? (d->splits > 0 ? d->splits : dsl_wgrad_splits(d)) : wgrad_splits_for(d, count);
   const int cyp = (int)wgrad_cy_pad(d);
-  const size_t need = (size_t)splits * count * cyp * (size_t)d->kh * d->kw * d->cs * sizeof(float);
+  const size_t need = (size_t)splits * count * cyp * ((size_t)d->kh * d->kw * d->cs + 1) * sizeof(float);
   DSL_CHECK(d->workspace_bytes >= need, "dsl_conv2d_wgrad: workspace too small (%zu < %zu)", d->workspace_bytes, need);
   WgK k;
   memset(&k, 0, sizeof(k));
@@ -2014,6 +2084,9 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     k.gx = cyp / bco;
     k.gy = d->kh * d->kw * d->cs / bci;
     k.splits = splits;
+    k.dbws = (float*)d->workspace + (size_t)splits * count * cyp * k.krow;      // behind the dW partials
+    for (int g = 0; g < count; ++g)
+      if (descs[g].db) k.dbmask |= 1 << g;
 #ifdef DSL_ABLATE_BUILD
     { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
 #endif
@@ -2066,6 +2139,7 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     r.scale[g] = descs[g < count ? g : 0].scale;
     r.db[g] = g < count ? descs[g].db : nullptr;
   }
+  r.dbws = cfg >= 1 ? k.dbws : nullptr;
   if (d->shared && count > 1) {
     // the members are applications of ONE convolution (weights shared along a recurrence): their partial tiles are just
     // more splits of the same dW - [split][member] pairs are contiguous in the workspace
@@ -2079,11 +2153,12 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb, count), dim3(256), 0, st, (const float*)d->workspace, r, splits, count,
                      cyp, d->cd, k.krow);
   DSL_LAUNCH_CHECK("wgrad_reduce_kernel");
-  for (int g = 0; g < count; ++g)
-    if (descs[g].db) {       // db was cleared by the reduce kernel above
-      const int rc = dsl_colsum_acc(descs[g].dy, descs[g].db, (long)px, d->cd, d->cy, stream);
-      if (rc) return rc;
-    }
+  if (cfg == 0)              // register-staged kernel: separate column-sum pass (db was cleared by the reduce kernel above)
+    for (int g = 0; g < count; ++g)
+      if (descs[g].db) {
+        const int rc = dsl_colsum_acc(descs[g].dy, descs[g].db, (long)px, d->cd, d->cy, stream);
+        if (rc) return rc;
+      }
   return 0;
 }
 
@@ -2138,6 +2213,8 @@ int wgrad_fill_k(const dsl_wgrad_desc* descs, int count, int splits, int cfg, Wg
     k.xv[g] = (const uint16_t*)m.x;
     k.dwv[g] = m.dw;
     k.scalev[g] = m.scale;
+    k.dbv[g] = m.db;
+    if (g < count && m.db) k.dbmask |= 1 << g;
   }
   k.dy = k.dyv[0]; k.x = k.xv[0];
   const int bcos[5] = {0, 256, 256, 128, 128}, bcis[5] = {0, 256, 128, 256, 128};
@@ -2223,7 +2300,7 @@ extern "C" size_t dsl_wgrad_multi_workspace_bytes(const dsl_wgrad_desc* descs, c
   int off = 0;
   for (int s = 0; s < nsub; ++s) {
     const dsl_wgrad_desc* d = &descs[off];
-    if (splits[s] > 1) need += (size_t)splits[s] * counts[s] * wgrad_cy_pad(d) * (size_t)d->kh * d->kw * d->cs * sizeof(float);
+    if (splits[s] > 1) need += (size_t)splits[s] * counts[s] * wgrad_cy_pad(d) * ((size_t)d->kh * d->kw * d->cs + 1) * sizeof(float);
     off += counts[s];
   }
   return need ? need : 16;
@@ -2274,12 +2351,14 @@ extern "C" int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* cou
     t->flops += 2.0 * counts[s] * px * (double)d->cd * d->kh * d->kw * d->cs;
     t->bytes += counts[s] * ((double)px * d->cd * 2.0 + (double)xo * d->cs * 2.0 + (double)d->cd * d->kh * d->kw * d->cs * 4.0);
     const long long sub_elems = (long long)counts[s] * k.cyp * k.krow;
+    k.dbws = (float*)ws + (size_t)splits[s] * sub_elems;       // behind this sub-launch's dW partials
     for (int g = 0; g < counts[s]; ++g) {
       if (!k.direct) {
         DSL_CHECK(t->n_red < kMaxRed, "dsl_wgrad_multi_build: more than %d reduce entries", kMaxRed);
         RedEnt& r = t->red[t->n_red++];
         r.ws = (const float*)ws + (long long)g * k.cyp * k.krow;
         r.dw = d[g].dw; r.scale = d[g].scale; r.db = d[g].db;
+        r.dbws = k.dbws + (long long)g * k.cyp; r.dbstride = (long long)counts[s] * k.cyp;
         r.krow = k.krow; r.sstride = sub_elems; r.splits = splits[s]; r.cd = d->cd;
         const long long total4 = (long long)d->cd * k.krow / 4;
         int nb = (int)((total4 + 1023) / 1024);        // ~4 f32x4 per thread
@@ -2288,13 +2367,8 @@ extern "C" int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* cou
         r.blk_start = red_blocks; r.nblk = nb;
         red_blocks += nb;
       }
-      if (d[g].db) {
-        DSL_CHECK(t->n_colsum < kMaxColsum, "dsl_wgrad_multi_build: more than %d bias gradients", kMaxColsum);
-        ColsumItem& c = t->colsum[t->n_colsum++];
-        c.x = d[g].dy; c.out = d[g].db; c.rows = px; c.c = d->cd; c.ld = d->cy; c.clear = k.direct;
-      }
     }
-    if (!k.direct) ws += (size_t)splits[s] * sub_elems * sizeof(float);
+    if (!k.direct) ws += (size_t)splits[s] * (sub_elems + (long long)counts[s] * k.cyp) * sizeof(float);
   }
   t->hdr.nsub = nsub;
   t->total_blocks = blocks;

@@ -388,12 +388,16 @@ def test_wgrad_multi(K, name):
         assert torch.allclose(got, ref, rtol=1e-2, atol=2e-2 * float(ref.abs().max())), (name, (got - ref).abs().max())
         if db is not None:
             assert torch.allclose(db.cpu(), rdb, rtol=1e-3, atol=1e-2)
-        first.append(got.clone())
+        first.append((got.clone(), None if db is None else db.cpu().clone()))
         dw.fill_(float('nan'))
+        if db is not None:
+            db.fill_(float('nan'))
     plan.run()
     sync()
-    for (ref, rdb, dw, db), f in zip(checks, first):
+    for (ref, rdb, dw, db), (f, fdb) in zip(checks, first):
         assert torch.equal(dw.cpu(), f)
+        if db is not None:                 # the bias gradients are summed inside the launch in a fixed order, too
+            assert torch.equal(db.cpu(), fdb)
 
 
 def test_wgrad_multi_rejects_mixed_tile_configurations(K):
