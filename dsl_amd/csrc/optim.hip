@@ -19,6 +19,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
+// deterministic form: block partials in block order, folded by one workgroup (the clip coefficient of every run is the same)
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long i = n4 * 4; i < n; ++i) s += x[i] * x[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* __restrict__ part, int nb, float* out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += part[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) *out = s;
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ m, uint16_t* __restrict__ p16,
                                                   const uint8_t* __restrict__ group, long long n, float lr,
@@ -138,6 +160,15 @@ extern "C" int dsl_sumsq(const float* x, long n, float* out, void* stream) {
   DSL_CHECK(x && out && n >= 0, "dsl_sumsq: bad arguments");
   hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n / 4, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
   DSL_LAUNCH_CHECK("sumsq_kernel");
+  return 0;
+}
+
+extern "C" int dsl_sumsq_det(const float* x, long n, float* out, float* workspace, void* stream) {
+  DSL_CHECK(x && out && workspace && n >= 0, "dsl_sumsq_det: bad arguments");
+  const int nb = nblocks(n / 4, 1024);
+  hipLaunchKernelGGL(sumsq_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, (long long)n, workspace);
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nb, out);
+  DSL_LAUNCH_CHECK("sumsq_part_kernel");
   return 0;
 }
 

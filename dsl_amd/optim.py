@@ -49,8 +49,9 @@ class FlatSGD:
         sp = L.stream_ptr()
         gptr = None
         if self.max_norm is not None:
-            self.gnorm_sq.zero_()
-            L.check(L.lib.dsl_sumsq(L.ptr(st.grad), st.n_train, L.ptr(self.gnorm_sq), sp), 'dsl_sumsq')
+            if getattr(self, '_sumsq_ws', None) is None or self._sumsq_ws.device != st.device:
+                self._sumsq_ws = torch.zeros(1024, device=st.device)
+            L.check(L.lib.dsl_sumsq_det(L.ptr(st.grad), st.n_train, L.ptr(self.gnorm_sq), L.ptr(self._sumsq_ws), sp), 'dsl_sumsq_det')
             gptr = self.gnorm_sq
         lr = float(self.param_groups[0]['lr'])
         blr = float(self.param_groups[1]['lr']) / lr if lr != 0 else self.bias_lr_mult

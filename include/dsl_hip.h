@@ -276,6 +276,8 @@ int dsl_fcos_loss(const dsl_fcos_desc* d, void* stream);
  * apis/train.py:111,157-166; EMA at runner/hooks/semi_epoch_based_runner.py:368-409)
  * ---------------------------------------------------------------------------------------- */
 int dsl_sumsq(const float* x, long n, float* out /* [1], accumulated */, void* stream);
+/* the same sum, overwritten (not accumulated), summed in a fixed order: workspace >= 1024 floats */
+int dsl_sumsq_det(const float* x, long n, float* out /* [1] */, float* workspace, void* stream);
 /* p -= lr*lr_mult[i] * (m = mom*m + (g*clip + wd*wd_mult[i]*p)); also writes bf16(p) to p16.
  * clip = min(max_norm/(sqrt(*gnorm_sq)+1e-6), 1) when gnorm_sq != NULL.  group[i] in {0,1}:
  * 1 = bias group (lr*bias_lr_mult, wd*bias_decay_mult). */

@@ -554,6 +554,13 @@ def test_sgd_ema_cast_packdgrad(K):
     sync()
     assert torch.allclose(p.cpu(), pr, rtol=1e-5, atol=1e-6)
     assert torch.equal(p16.cpu(), p.cpu().bfloat16())
+    # the optimizer's form of the squared norm: fixed summation order (bit-identical on repeat), overwrites its output
+    big = torch.randn(3_000_001, generator=g).cuda()
+    ws, o1, o2 = torch.zeros(1024, device='cuda'), torch.full((1,), 7.0, device='cuda'), torch.full((1,), -3.0, device='cuda')
+    L.check(L.lib.dsl_sumsq_det(L.ptr(big), big.numel(), L.ptr(o1), L.ptr(ws), L.stream_ptr()))
+    L.check(L.lib.dsl_sumsq_det(L.ptr(big), big.numel(), L.ptr(o2), L.ptr(ws), L.stream_ptr()))
+    sync()
+    assert float(o1) == float(o2) and float(o1) == pytest.approx(float(big.double().pow(2).sum()), rel=1e-5)
     t, s = torch.randn(n, generator=g), torch.randn(n, generator=g)
     td, sd_ = t.clone().cuda(), s.cuda()
     L.check(L.lib.dsl_ema_lerp(L.ptr(td), L.ptr(sd_), n, 0.99, L.stream_ptr()))

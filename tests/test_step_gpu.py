@@ -234,3 +234,32 @@ def test_plan_cache_is_bounded_and_reuses_shapes():
         assert len(eng.plans) <= 3
     shapes_cached = {k[-4:] for k in eng.plans}      # key = (store id, store generation, N, H, W, training)
     assert (1, 64, 96, True) in shapes_cached and (1, 96, 128, True) not in shapes_cached
+
+
+def test_training_step_is_bit_reproducible(golden):
+    """Same weights, same batch, twice (and on a second model instance): losses, every gradient element and the clipped SGD
+    update are bit-identical - GroupNorm, loss, weight- and bias-gradient and gradient-norm sums all run in a fixed order."""
+    from dsl_amd.optim import FlatSGD
+    d = golden('net_small_dsl.npz')
+    B = int(d['B'])
+    img = T(d['img']).cuda()
+    gtb, gtl, ig = [T(d[f'gt{i}']) for i in range(B)], [T(d[f'gl{i}']) for i in range(B)], [T(d[f'ig{i}']) for i in range(B)]
+    metas = [dict(img_shape=tuple(img.shape[2:]) + (3,), pad_shape=tuple(img.shape[2:]) + (3,), scale_factor=1.0)] * B
+    runs = []
+    for inst in range(2):
+        model = build(loss_weight=3.0, soft_weight=1.0, soft_warm_up=0)
+        model.bbox_head.cur_iter = 1
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
+                      grad_clip=dict(max_norm=1.0, norm_type=2))            # small enough that the clip is active
+        for rep in range(2 if inst == 0 else 1):
+            losses = model.forward_train(img, metas, gtb, gtl, ig)
+            sum(losses.values()).backward()
+            torch.cuda.synchronize()
+            runs.append(({k: float(v.detach()) for k, v in losses.items()}, model.store.grad.clone()))
+        opt.step()
+        torch.cuda.synchronize()
+        runs[-1] += (model.store.train.clone(), float(opt.gnorm_sq))
+    (l0, g0), (l1, g1, w1, n1), (l2, g2, w2, n2) = runs
+    assert l0 == l1 == l2
+    assert torch.equal(g0, g1) and torch.equal(g1, g2)
+    assert n1 == n2 and n1 > 1.0 and torch.equal(w1, w2)
