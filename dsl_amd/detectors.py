@@ -351,7 +351,7 @@ class FCOS(nn.Module):
         sw = head.effective_soft_weight(N)
         ws = self.world_size
         lp.configure(loss_weight=head.loss_weight, soft_weight=sw, grad_scale=self.loss_scale / ws, inv_world=1.0 / ws)
-        plan.img.copy_(img, non_blocking=True)
+        plan.bind_image(img)
         plan.assign_ops.run()
         work = None
         if ws > 1:      # reduce_mean of (num_pos, sum centerness targets): one 2-float all-reduce (fcos_head.py:264-274)

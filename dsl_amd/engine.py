@@ -175,6 +175,7 @@ class Plan:
         st, N, H, W, f = self.store, self.N, self.H, self.W, self.fwd
         cv = st.convs
         x8 = self.buf('x8', N, H, W, 8)
+        self._img_op = len(f.items)         # bind_image() points this op at the caller's tensor
         f.pack_image(self.img, x8, N, H, W)
         h1, w1 = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
         s1 = self.buf('stem', N, h1, w1, 64)
@@ -554,9 +555,23 @@ class Plan:
             self.bwd_segments.append((ol, dict(bucket=buckets[seg], slot=seg, main=(li == 1))))
 
     # ---------------------------------------------------------------------------------------------
+    def bind_image(self, img):
+        """The batch for the next fwd.run(): a dense fp32 tensor on this device is read in place by the layout kernel (it
+        must stay alive until that kernel has run - stream order on the caller's stream); anything else is staged in self.img."""
+        f = self.fwd
+        if f.arr is None:
+            f.arr = (L.Op * len(f.items))(*f.items)
+        if img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and img.device == self.img.device:
+            f.arr[self._img_op].p[0] = img.data_ptr()
+            self._img_ref = img
+        else:
+            self.img.copy_(img, non_blocking=True)
+            f.arr[self._img_op].p[0] = self.img.data_ptr()
+            self._img_ref = None
+
     def forward(self, img=None):
         if img is not None:
-            self.img.copy_(img, non_blocking=True)
+            self.bind_image(img)
         self.fwd.run()
 
 

@@ -62,7 +62,7 @@ def detect_device(det, img, img_metas, rescale=False, store=None):
     store = store or det.store
     N, _, H, W = img.shape
     plan = eng.plan(store, N, H, W, training=False)
-    plan.img.copy_(img, non_blocking=True)
+    plan.bind_image(img)
     plan.fwd.run()
     dp = getattr(plan, 'detplan', None)
     if dp is None:
