@@ -182,6 +182,10 @@ class Plan:
         f.conv(self._conv(cv['backbone.conv1'], x8, s1, N, [(H, W)], [(h1, w1)], relu=True, small_c=True))
         h, w = conv_out(h1, 3, 2, 1), conv_out(w1, 3, 2, 1)
         self.stage_out, self.stage_ld = [], []      # per stage: (tensor / pointer of the output's first channel, (h, w)), row stride
+        # independent branches of the forward graph (a stage's downsample conv next to conv1 -> conv2; P5 -> P6 -> P7 next to
+        # the P4 / P3 path) run on side stream 3: their kernels are too small to fill the chip alone
+        self.BR = 3 if (os.environ.get('DSL_SIDE', '1') != '0' and os.environ.get('DSL_FWD_BRANCH', '1') != '0') else 0
+        self.conv_ws_br = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
         if st.backbone == 'rla':
             from . import engine_rla
             engine_rla.build_forward(self, s1, h1, w1)
@@ -202,18 +206,30 @@ class Plan:
         lat = [self.buf(f'lat{i}', N, hw[0], hw[1], 256) for i, hw in enumerate((hw3, hw4, hw5))]
         lc = [cv[f'neck.lateral_convs.{i}.conv'] for i in range(3)]
         ld3, ld4, ld5 = self.stage_ld[1:4]       # RLA keeps a stage output as the x part of the next [C + 128]-wide block input
-        f.conv(self._conv(lc[2], c5, lat[2], N, [hw5], [hw5], lds=ld5))
-        f.conv(self._conv(lc[1], c4, lat[1], N, [hw4], [hw4], addend=lat[2], add_hw=[hw5], lds=ld4))
-        f.conv(self._conv(lc[0], c3, lat[0], N, [hw3], [hw3], addend=lat[1], add_hw=[hw4], lds=ld3))
+        BR = self.BR if st.backbone != 'rla' else 0
+
+        def br(cd_):        # a conv of the side branch: its own split-K scratch
+            if BR:
+                cd_.workspace, cd_.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
+            return cd_
         feats = self.buf('feats', self.M, 256)
         self.feat_seg = [feats.data_ptr() + self.seg_off[i] * 256 * 2 for i in range(5)]
         fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
-        for i, hw in enumerate((hw3, hw4, hw5)):
-            f.conv(self._conv(fc[i], lat[i], self.feat_seg[i], N, [hw], [hw]))
-        f.conv(self._conv(fc[3], self.feat_seg[2], self.feat_seg[3], N, [hw5], [hw6]))          # P6 (no relu)
         p6r = self.buf('p6r', N, hw6[0], hw6[1], 256)
-        f.conv(self._conv(fc[3], self.feat_seg[2], p6r, N, [hw5], [hw6], relu=True))            # relu(P6)
-        f.conv(self._conv(fc[4], p6r, self.feat_seg[4], N, [hw6], [hw7]))                       # P7
+        f.conv(self._conv(lc[2], c5, lat[2], N, [hw5], [hw5], lds=ld5))
+        if BR:
+            f.fork(BR)
+        # P5 -> P6 -> P7: five tiny launches, beside the P4 / P3 path
+        f.conv(br(self._conv(fc[2], lat[2], self.feat_seg[2], N, [hw5], [hw5])), side=BR)
+        f.conv(br(self._conv(fc[3], self.feat_seg[2], self.feat_seg[3], N, [hw5], [hw6])), side=BR)      # P6 (no relu)
+        f.conv(br(self._conv(fc[3], self.feat_seg[2], p6r, N, [hw5], [hw6], relu=True)), side=BR)        # relu(P6)
+        f.conv(br(self._conv(fc[4], p6r, self.feat_seg[4], N, [hw6], [hw7])), side=BR)                   # P7
+        f.conv(self._conv(lc[1], c4, lat[1], N, [hw4], [hw4], addend=lat[2], add_hw=[hw5], lds=ld4))
+        f.conv(self._conv(lc[0], c3, lat[0], N, [hw3], [hw3], addend=lat[1], add_hw=[hw4], lds=ld3))
+        for i, hw in enumerate((hw3, hw4)):
+            f.conv(self._conv(fc[i], lat[i], self.feat_seg[i], N, [hw], [hw]))
+        if BR:
+            f.join(BR)
         # ---- head: shared weights, all 5 levels per launch ----
         ls = self.level_sizes
         self.tower = {}
@@ -267,12 +283,18 @@ class Plan:
                 a1 = self.buf(p + '.a1', N, oh, ow, planes)
                 a2 = self.buf(p + '.a2', N, oh, ow, planes)
                 out = self.buf(p + '.out', N, oh, ow, planes * 4)
+                idt = x
+                if b == 0:      # the downsample conv only meets the main branch at conv3's residual add
+                    idt = self.buf(p + '.idt', N, oh, ow, planes * 4)
+                    dd = self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)])
+                    if self.BR:
+                        dd.workspace, dd.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
+                        f.fork(self.BR)
+                    f.conv(dd, side=self.BR)
                 f.conv(self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True))
                 f.conv(self._conv(c2, a1, a2, N, [(oh, ow)], [(oh, ow)], relu=True))
-                idt = x
-                if b == 0:
-                    idt = self.buf(p + '.idt', N, oh, ow, planes * 4)
-                    f.conv(self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)]))
+                if b == 0 and self.BR:
+                    f.join(self.BR)
                 f.conv(self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt))
                 self.blocks.append(dict(prefix=p, xin=x, a1=a1, a2=a2, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
                                         stage=li, b=b, planes=planes))
