@@ -82,8 +82,8 @@ class OpList:
     def gn_fwd(self, d, side=False):
         self._add(L.OP_GN_FWD, d, i=(0, 0, 0, 0, 0, 0, int(side)))
 
-    def gn_bwd(self, d):
-        self._add(L.OP_GN_BWD, d)
+    def gn_bwd(self, d, side=False):
+        self._add(L.OP_GN_BWD, d, i=(0, 0, 0, 0, 0, 0, int(side)))
 
     def assign(self, d):
         self._add(L.OP_ASSIGN, d)
@@ -426,17 +426,29 @@ class Plan:
         ol.wait(L.SLOT_PACKS, stream=0)      # the data-gradient weight packs of the last optimizer step (ParamStore.repack_dgrad)
         TOWER8 = os.environ.get('DSL_TOWER_GROUP8', '1') != '0'   # both towers' weight gradients as ONE launch of 8: half the pixel splits
         tower_group = []
-        for ti, tower in enumerate(('cls_convs', 'reg_convs')):
+        # the two towers' backward chains are independent until both have added into g_feats: the regression tower's runs on
+        # side stream 2 (as in the forward pass); its last data gradient - the one that adds into g_feats - waits for the
+        # classification tower's
+        BT = 2 if (SIDE and os.environ.get('DSL_BWD_TOWERS', '1') != '0') else 0
+        if BT:
+            ol.fork(BT)
+
+        def side_ws(cd_):
+            cd_.workspace, cd_.workspace_bytes = L.ptr(self.conv_ws_side), self.conv_ws_side.numel()
+            return cd_
+        for ti, tower in ((1, 'reg_convs'), (0, 'cls_convs')) if BT else ((0, 'cls_convs'), (1, 'reg_convs')):
+            sd = BT if tower == 'reg_convs' else 0
+            wsf = side_ws if sd else (lambda c: c)
             lays = self.tower[tower]
             g_act = self.buf(f'g_{tower}_act3', M, 256)
             if tower == 'cls_convs':
                 self._wgrad(ol, None, lp.g_cls, lays[3]['act'], N, ls, ls, cy=128, cd=80, wregion='head.cls_w',
                             bregion='head.cls_b', side=SIDE)
-                ol.conv(self._dgrad('head.cls', lp.g_cls, g_act, N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1, cs_real=80))
+                ol.conv(wsf(self._dgrad('head.cls', lp.g_cls, g_act, N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1, cs_real=80)), side=sd)
             else:
                 self._wgrad(ol, None, lp.g_rc, lays[3]['act'], N, ls, ls, cy=64, cd=5, wregion='head.regctr_w',
                             bregion='head.regctr_b', side=SIDE)
-                ol.conv(self._dgrad('head.regctr', lp.g_rc, g_act, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1, cs_real=5))
+                ol.conv(wsf(self._dgrad('head.regctr', lp.g_rc, g_act, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1, cs_real=5)), side=sd)
             if not TOWER8:
                 tower_group = []
             for i in (3, 2, 1, 0):
@@ -446,20 +458,32 @@ class Plan:
                 # the GroupNorm backward also yields the conv bias gradient (sum over pixels of g_pre) from its block
                 # records: the weight gradient below runs without its column-sum pass
                 gd = ops.gn_desc(lay['pre'], lay['act'], st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'),
-                                 lay['stats'], self._gn_workspace('main'), n=N, hw=ls, dy=g_act, dx=g_pre,
+                                 lay['stats'], self._gn_workspace('side' if sd else 'main'), n=N, hw=ls, dy=g_act, dx=g_pre,
                                  dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad),
                                  dbias=st.t32_ptr(lay['spec'].name + '.bias', st.grad))
-                ol.gn_bwd(gd)
+                ol.gn_bwd(gd, side=sd)
                 tower_group.append(self._wgrad(ol, lay['spec'], g_pre, lay['xin'], N, ls, ls, side=SIDE, emit=not GROUP,
                                                no_db=True))
                 if i > 0:
                     g_act = self.buf(f'g_{tower}_act{i - 1}', M, 256)
-                    ol.conv(self._dgrad(lay['spec'].name, g_pre, g_act, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
+                    ol.conv(wsf(self._dgrad(lay['spec'].name, g_pre, g_act, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1)), side=sd)
+                elif BT:
+                    if sd:          # issued first, runs second: everything the caller's stream has queued (the other tower) first
+                        self._reg_tail = (lay, g_pre)
+                    else:
+                        ol.conv(self._dgrad(lay['spec'].name, g_pre, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
+                        rl, rg = self._reg_tail
+                        ol.fork(BT)
+                        ol.conv(side_ws(self._dgrad(rl['spec'].name, rg, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1,
+                                                    pad=1, addend=g_feats)), side=BT)
+                        ol.join(BT)
                 else:
                     ol.conv(self._dgrad(lay['spec'].name, g_pre, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1,
                                         pad=1, addend=g_feats if ti == 1 else None))
-            if GROUP and (ti == 1 or not TOWER8):
+            if GROUP and not TOWER8:
                 self._wgrad_group(ol, tower_group, side=SIDE)
+        if GROUP and TOWER8:
+            self._wgrad_group(ol, tower_group, side=SIDE)
         self._flush_wgrads(ol, side=SIDE)          # towers + predictors: ready now, the FPN's follow below
         # ---- FPN backward ----
         cv = st.convs
