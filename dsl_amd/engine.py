@@ -94,8 +94,8 @@ class OpList:
     def maxpool(self, x, y, n, h, w, c):
         self._add(L.OP_MAXPOOL, i=(n, h, w, c), p=(x, y))
 
-    def sum2x2(self, g, out, n, h, w, ch, cw, c):
-        self._add(L.OP_SUM2X2, i=(n, h, w, ch, cw, c), p=(g, out))
+    def sum2x2(self, g, out, n, h, w, ch, cw, c, side=False):
+        self._add(L.OP_SUM2X2, i=(n, h, w, ch, cw, c, int(side)), p=(g, out))
 
     def memset(self, ptr, nbytes, value=0):
         self._add(L.OP_MEMSET, i=(value,), p=(ptr,), l=(nbytes,))
@@ -498,29 +498,42 @@ class Plan:
         g_lat = [self.buf(f'g_lat{i}', N, hw[0], hw[1], 256) for i, hw in enumerate((hw3, hw4, hw5))]
         s0 = self.buf('s0', N, hw4[0], hw4[1], 256)
         s1 = self.buf('s1', N, hw5[0], hw5[1], 256)
-        # P7 = fpn4(relu(P6))
+        # independent chains of this part of the graph run on side stream 3 beside the caller's (small launches, as in the
+        # forward pass): the P3 / P4 output convs next to P7 -> P6 -> P5; the C3 / C4 laterals next to layer4's backward
+        rla = st.backbone == 'rla'
+        BB = 3 if (SIDE and not rla and os.environ.get('DSL_BWD_BRANCH', '1') != '0') else 0
+
+        def br_ws(cd_):
+            if BB:
+                cd_.workspace, cd_.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
+            return cd_
         self._wgrad(ol, fc[4], gseg[4], p6r, N, [hw7], [hw6], side=SIDE)
-        ol.conv(self._dgrad(fc[4].name, gseg[4], g_p6, N, [hw7], [hw6], cs=256, cd=256, k=3, stride=2, pad=1,
-                            addend=gseg[3], mask=p6r, mask_first=True))
-        # P6 = fpn3(P5)
         self._wgrad(ol, fc[3], g_p6, self.feat_seg[2], N, [hw6], [hw5], side=SIDE)
-        ol.conv(self._dgrad(fc[3].name, g_p6, g_p5, N, [hw6], [hw5], cs=256, cd=256, k=3, stride=2, pad=1,
-                            addend=gseg[2]))
-        # P3..P5 = fpn_i(lat_i)
         self._wgrad(ol, fc[2], g_p5, lat[2], N, [hw5], [hw5], side=SIDE)
         self._wgrad(ol, fc[1], gseg[1], lat[1], N, [hw4], [hw4], side=SIDE)
         self._wgrad(ol, fc[0], gseg[0], lat[0], N, [hw3], [hw3], side=SIDE)
-        ol.conv(self._dgrad(fc[0].name, gseg[0], g_lat[0], N, [hw3], [hw3], cs=256, cd=256, k=3, stride=1, pad=1))
-        ol.sum2x2(g_lat[0], s0, N, hw4[0], hw4[1], hw3[0], hw3[1], 256)
-        ol.conv(self._dgrad(fc[1].name, gseg[1], g_lat[1], N, [hw4], [hw4], cs=256, cd=256, k=3, stride=1, pad=1,
-                            addend=s0))
-        ol.sum2x2(g_lat[1], s1, N, hw5[0], hw5[1], hw4[0], hw4[1], 256)
+        if BB:
+            ol.fork(BB)
+        # P3, P4 = fpn_i(lat_i); the top-down path's nearest upsampling is a 2x2 sum in the backward direction
+        ol.conv(br_ws(self._dgrad(fc[0].name, gseg[0], g_lat[0], N, [hw3], [hw3], cs=256, cd=256, k=3, stride=1, pad=1)), side=BB)
+        ol.sum2x2(g_lat[0], s0, N, hw4[0], hw4[1], hw3[0], hw3[1], 256, side=BB)
+        ol.conv(br_ws(self._dgrad(fc[1].name, gseg[1], g_lat[1], N, [hw4], [hw4], cs=256, cd=256, k=3, stride=1, pad=1,
+                                  addend=s0)), side=BB)
+        ol.sum2x2(g_lat[1], s1, N, hw5[0], hw5[1], hw4[0], hw4[1], 256, side=BB)
+        # P7 = fpn4(relu(P6))
+        ol.conv(self._dgrad(fc[4].name, gseg[4], g_p6, N, [hw7], [hw6], cs=256, cd=256, k=3, stride=2, pad=1,
+                            addend=gseg[3], mask=p6r, mask_first=True))
+        # P6 = fpn3(P5)
+        ol.conv(self._dgrad(fc[3].name, g_p6, g_p5, N, [hw6], [hw5], cs=256, cd=256, k=3, stride=2, pad=1,
+                            addend=gseg[2]))
+        if BB:
+            ol.join(BB)
         ol.conv(self._dgrad(fc[2].name, g_p5, g_lat[2], N, [hw5], [hw5], cs=256, cd=256, k=3, stride=1, pad=1,
                             addend=s1))
         # laterals -> gradients w.r.t. C3, C4, C5 (masked by the ReLU that produced them)
         self.g_stage = {}
-        rla = st.backbone == 'rla'
-        for i, (li, hw) in enumerate(((1, hw3), (2, hw4), (3, hw5))):
+        self._br_pending = False        # side-stream-3 work the next segment must join before it touches g_stage[1], g_stage[2]
+        for i, (li, hw) in ((2, (3, hw5)), (1, (2, hw4)), (0, (1, hw3))):
             cfeat = self.stage_out[li][0]
             cch = STAGE_PLANES[li] * 4
             ldc = self.stage_ld[li]
@@ -530,8 +543,14 @@ class Plan:
             # ResNet: the gradient w.r.t. the stage output is masked by its ReLU here.  RLA: the outputs of stages 1, 2 also
             # feed the recurrent path; their mask is applied once every contribution has arrived (engine_rla)
             masked = not rla or li == 3
-            ol.conv(self._dgrad(lc[i].name, g_lat[i], g0b, N, [hw], [hw], cs=256, cd=cch, k=1, stride=1, pad=0,
-                                mask=cfeat if masked else None, mask_first=masked, ldm=ldc))
+            sd = BB if li < 3 else 0        # layer4's backward starts from the C5 lateral alone; C4, C3 are needed at its end
+            if sd and not self._br_pending:
+                ol.fork(BB)
+                self._br_pending = True
+            ol.conv(br_ws(self._dgrad(lc[i].name, g_lat[i], g0b, N, [hw], [hw], cs=256, cd=cch, k=1, stride=1, pad=0,
+                                      mask=cfeat if masked else None, mask_first=masked, ldm=ldc)) if sd else
+                    self._dgrad(lc[i].name, g_lat[i], g0b, N, [hw], [hw], cs=256, cd=cch, k=1, stride=1, pad=0,
+                                mask=cfeat if masked else None, mask_first=masked, ldm=ldc), side=sd)
         buckets = st.grad_buckets()
         # no JOIN here: this segment's weight gradients keep running on the side stream under the next segment's
         # data-gradient chain.  Named event slot s marks "side-stream work of segment s queued": once it has fired, gradient
@@ -562,6 +581,13 @@ class Plan:
                 gA2 = self.buf(p + '.g_a2', N, hw[0], hw[1], planes)
                 gA1 = self.buf(p + '.g_a1', N, hw[0], hw[1], planes)
                 grp = GROUP and (li > 1 or GROUP_LAST)
+                ds_early = BB and blk['b'] == 0 and li > 1
+                if ds_early:        # the downsample path's scatter into the previous stage's gradient, beside conv3 -> conv2 -> conv1
+                    ds = cv[p + '.downsample.0']
+                    tgt, ihw = self.g_stage[li - 1], blk['in_hw']
+                    ol.fork(BB)          # (stream 3 is in order: the lateral that initialised tgt is already queued there)
+                    ol.conv(br_ws(self._dgrad(ds.name, g_pre, tgt, N, [hw], [ihw], cs=ds.cout, cd=ds.cin, k=1, stride=1, pad=0,
+                                              os=2, addend=tgt, mask=blk['xin'], mask_first=True)), side=BB)
                 g3.append(self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw], side=SIDE, emit=not grp))
                 ol.conv(self._dgrad(c3.name, g_pre, gA2, N, [hw], [hw], cs=c3.cout, cd=c3.cin, k=1, stride=1, pad=0,
                                     mask=blk['a2'], mask_last=True))
@@ -583,7 +609,9 @@ class Plan:
                     if li > 1:      # data gradient into the previous stage's output (stride-2 scatter)
                         tgt = self.g_stage[li - 1]
                         ihw = blk['in_hw']
-                        for spec, dy in ((ds, g_pre), (c1, gA1)):
+                        if BB:          # the laterals / the early downsample scatter on stream 3 wrote tgt first
+                            ol.join(BB)
+                        for spec, dy in ((c1, gA1),) if ds_early else ((ds, g_pre), (c1, gA1)):
                             ol.conv(self._dgrad(spec.name, dy, tgt, N, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
             if GROUP and (li > 1 or GROUP_LAST):
