@@ -44,8 +44,9 @@ class OpList:
         """side: False/0 = the caller's stream, True/1..3 = that side stream of the library."""
         self._add(L.OP_CONV, d, i=(0, 0, 0, 0, 0, 0, int(side)))
 
-    def fork(self, side=1):
-        self._add(L.OP_FORK, i=(side,))
+    def fork(self, side=1, other=0):
+        """Side stream `side` waits for everything queued so far on stream `other` (0 = the caller's)."""
+        self._add(L.OP_FORK, i=(side, other))
 
     def wgrad(self, d, side=False):
         """side=True: on the library's side stream, after a FORK (the weight gradient only depends on tensors
@@ -424,7 +425,6 @@ class Plan:
         # ================= segment 0: head + FPN =================
         ol = OpList()
         ol.wait(L.SLOT_PACKS, stream=0)      # the data-gradient weight packs of the last optimizer step (ParamStore.repack_dgrad)
-        TOWER8 = os.environ.get('DSL_TOWER_GROUP8', '1') != '0'   # both towers' weight gradients as ONE launch of 8: half the pixel splits
         tower_group = []
         # the two towers' backward chains are independent until both have added into g_feats: the regression tower's runs on
         # side stream 2 (as in the forward pass); its last data gradient - the one that adds into g_feats - waits for the
@@ -436,54 +436,63 @@ class Plan:
         def side_ws(cd_):
             cd_.workspace, cd_.workspace_bytes = L.ptr(self.conv_ws_side), self.conv_ws_side.numel()
             return cd_
-        for ti, tower in ((1, 'reg_convs'), (0, 'cls_convs')) if BT else ((0, 'cls_convs'), (1, 'reg_convs')):
-            sd = BT if tower == 'reg_convs' else 0
+        towers = (('reg_convs', BT), ('cls_convs', 0)) if BT else (('cls_convs', 0), ('reg_convs', 0))
+        # the predictors' weight gradients need nothing from this pass but the loss gradients: first thing on the side stream
+        self._wgrad(ol, None, lp.g_cls, self.tower['cls_convs'][3]['act'], N, ls, ls, cy=128, cd=80, wregion='head.cls_w',
+                    bregion='head.cls_b', side=SIDE)
+        self._wgrad(ol, None, lp.g_rc, self.tower['reg_convs'][3]['act'], N, ls, ls, cy=64, cd=5, wregion='head.regctr_w',
+                    bregion='head.regctr_b', side=SIDE)
+        # (measured, tools/exp_r2t.sh / exp_r2u.sh: weight gradients that start while the head's large data-gradient launches
+        # still run cost more than the idle side stream saves - predictors first: 5.97 vs 5.94 ms, tower halves: 6.10 vs 6.05)
+        if os.environ.get('DSL_PRED_EARLY', '0') != '0':
+            self._flush_wgrads(ol, side=SIDE)
+        g_act = {}
+        for tower, sd in towers:
             wsf = side_ws if sd else (lambda c: c)
-            lays = self.tower[tower]
-            g_act = self.buf(f'g_{tower}_act3', M, 256)
+            g_act[tower] = self.buf(f'g_{tower}_act3', M, 256)
             if tower == 'cls_convs':
-                self._wgrad(ol, None, lp.g_cls, lays[3]['act'], N, ls, ls, cy=128, cd=80, wregion='head.cls_w',
-                            bregion='head.cls_b', side=SIDE)
-                ol.conv(wsf(self._dgrad('head.cls', lp.g_cls, g_act, N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1, cs_real=80)), side=sd)
+                ol.conv(wsf(self._dgrad('head.cls', lp.g_cls, g_act[tower], N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1, cs_real=80)), side=sd)
             else:
-                self._wgrad(ol, None, lp.g_rc, lays[3]['act'], N, ls, ls, cy=64, cd=5, wregion='head.regctr_w',
-                            bregion='head.regctr_b', side=SIDE)
-                ol.conv(wsf(self._dgrad('head.regctr', lp.g_rc, g_act, N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1, cs_real=5)), side=sd)
-            if not TOWER8:
-                tower_group = []
-            for i in (3, 2, 1, 0):
-                lay = lays[i]
+                ol.conv(wsf(self._dgrad('head.regctr', lp.g_rc, g_act[tower], N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1, cs_real=5)), side=sd)
+        # layer by layer, both towers: their weight gradients go out in two groups of four (layers 3, 2 and layers 1, 0 of
+        # both towers) as soon as the GroupNorm backward passes that produce their dY are queued - the side stream works from
+        # the first quarter of this segment on instead of waiting for its end
+        HALVES = os.environ.get('DSL_TOWER_HALVES', '0') != '0'
+        for i in (3, 2, 1, 0):
+            g_pre = {}
+            for tower, sd in towers:
+                lay = self.tower[tower][i]
                 base = lay['gn']
-                g_pre = self.buf(f'g_{tower}_pre{i}', M, 256)
+                g_pre[tower] = self.buf(f'g_{tower}_pre{i}', M, 256)
                 # the GroupNorm backward also yields the conv bias gradient (sum over pixels of g_pre) from its block
                 # records: the weight gradient below runs without its column-sum pass
                 gd = ops.gn_desc(lay['pre'], lay['act'], st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'),
-                                 lay['stats'], self._gn_workspace('side' if sd else 'main'), n=N, hw=ls, dy=g_act, dx=g_pre,
+                                 lay['stats'], self._gn_workspace('side' if sd else 'main'), n=N, hw=ls, dy=g_act[tower], dx=g_pre[tower],
                                  dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad),
                                  dbias=st.t32_ptr(lay['spec'].name + '.bias', st.grad))
                 ol.gn_bwd(gd, side=sd)
-                tower_group.append(self._wgrad(ol, lay['spec'], g_pre, lay['xin'], N, ls, ls, side=SIDE, emit=not GROUP,
-                                               no_db=True))
-                if i > 0:
-                    g_act = self.buf(f'g_{tower}_act{i - 1}', M, 256)
-                    ol.conv(wsf(self._dgrad(lay['spec'].name, g_pre, g_act, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1)), side=sd)
-                elif BT:
-                    if sd:          # issued first, runs second: everything the caller's stream has queued (the other tower) first
-                        self._reg_tail = (lay, g_pre)
-                    else:
-                        ol.conv(self._dgrad(lay['spec'].name, g_pre, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
-                        rl, rg = self._reg_tail
-                        ol.fork(BT)
-                        ol.conv(side_ws(self._dgrad(rl['spec'].name, rg, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1,
-                                                    pad=1, addend=g_feats)), side=BT)
-                        ol.join(BT)
-                else:
-                    ol.conv(self._dgrad(lay['spec'].name, g_pre, g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1,
-                                        pad=1, addend=g_feats if ti == 1 else None))
-            if GROUP and not TOWER8:
+                tower_group.append(self._wgrad(ol, lay['spec'], g_pre[tower], lay['xin'], N, ls, ls, side=SIDE, emit=False, no_db=True))
+            if (HALVES and i in (2, 0)) or i == 0:
+                if BT and SIDE:
+                    ol.fork(1, other=BT)       # the weight-gradient stream also waits for the regression tower's stream
                 self._wgrad_group(ol, tower_group, side=SIDE)
-        if GROUP and TOWER8:
-            self._wgrad_group(ol, tower_group, side=SIDE)
+                self._flush_wgrads(ol, side=SIDE)
+                tower_group = []
+            if i > 0:
+                for tower, sd in towers:
+                    wsf = side_ws if sd else (lambda c: c)
+                    lay = self.tower[tower][i]
+                    g_act[tower] = self.buf(f'g_{tower}_act{i - 1}', M, 256)
+                    ol.conv(wsf(self._dgrad(lay['spec'].name, g_pre[tower], g_act[tower], N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1)), side=sd)
+            else:
+                cl, rl = self.tower['cls_convs'][0], self.tower['reg_convs'][0]
+                ol.conv(self._dgrad(cl['spec'].name, g_pre['cls_convs'], g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
+                if BT:      # the regression tower's last data gradient adds into g_feats: after the classification tower's
+                    ol.fork(BT)
+                ol.conv((side_ws if BT else (lambda c: c))(self._dgrad(rl['spec'].name, g_pre['reg_convs'], g_feats, N, ls, ls, cs=256,
+                                                                       cd=256, k=3, stride=1, pad=1, addend=g_feats)), side=BT)
+                if BT:
+                    ol.join(BT)
         self._flush_wgrads(ol, side=SIDE)          # towers + predictors: ready now, the FPN's follow below
         # ---- FPN backward ----
         cv = st.convs

@@ -11,6 +11,7 @@ cd $R
 DB=$(find gpurun_out/prof_${TAG} -name '*_results.db' | head -1)
 python tools/rocprof_summary.py $DB > gpurun_out/${TAG}_kernel_stats.txt
 python tools/stream_timeline.py $DB 5 > gpurun_out/${TAG}_timeline.txt
+python tools/step_sequence.py $DB > gpurun_out/${TAG}_sequence.txt
 rm -rf gpurun_out/prof_${TAG}
 grep -h '"value"' gpurun_out/${TAG}_bench.log | python -c "
 import sys, json
