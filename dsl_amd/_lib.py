@@ -50,7 +50,7 @@ class WgradDesc(C.Structure):
                 ('splits', C.c_int32),
                 ('dy', C.c_void_p), ('x', C.c_void_p), ('scale', C.c_void_p), ('dw', C.c_void_p),
                 ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
-                ('ldx', C.c_int32), ('shared', C.c_int32)]
+                ('ldx', C.c_int32), ('shared', C.c_int32), ('slots', C.c_int32), ('pad_', C.c_int32)]
 
 
 class GnDesc(C.Structure):

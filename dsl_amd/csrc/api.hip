@@ -45,6 +45,15 @@ void side_init(int dev) {
       if (hipExtStreamCreateWithCUMask(&g_side[dev][i], 8, mask) == hipSuccess) continue;
       (void)hipGetLastError();
     }
+    // DSL_SIDE_PRIO: a = lowest priority for side stream 1 (weight gradients), b = lowest for all side streams; the caller's
+    // stream keeps its own (normal) priority, so its kernels' workgroups win the dispatcher when slots free up
+    static const char prio = [] { const char* e = getenv("DSL_SIDE_PRIO"); return e ? e[0] : '0'; }();
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);        // lo = numerically greatest = least priority
+    if ((prio == 'a' && i == 0) || prio == 'b') {
+      if (hipStreamCreateWithPriority(&g_side[dev][i], hipStreamNonBlocking, lo) == hipSuccess) continue;
+      (void)hipGetLastError();
+    }
     hipStreamCreateWithFlags(&g_side[dev][i], hipStreamNonBlocking);
   }
   for (int i = 0; i < kEvRing; ++i) hipEventCreateWithFlags(&g_ev[dev][i], hipEventDisableTiming);

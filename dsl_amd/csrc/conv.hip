@@ -1966,7 +1966,8 @@ static int wgrad_splits_for(const dsl_wgrad_desc* d, int count) {
     // small convolutions, and a full round of 128 KB-LDS workgroups that live for 100-250 us would leave those
     // kernels only the handful of CUs the round did not cover
     // (measured, bench.py N = 2: 256 -> 305, 224 -> 306, 192 -> 309, 160 -> 313, 128 -> 310 img/s)
-    static const int slots = [] { const char* e = getenv("DSL_WGRAD_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 160; }();
+    static const int slots_env = [] { const char* e = getenv("DSL_WGRAD_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 160; }();
+    const int slots = d->slots > 0 ? d->slots : slots_env;
     splits = slots * per_cu / tiles;
   }
   static const int forced_splits = [] { const char* e = getenv("DSL_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();   // tuning knob

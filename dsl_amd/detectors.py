@@ -269,6 +269,7 @@ class FCOS(nn.Module):
         # backward instead of sitting between forward and backward).  For loops that always call loss.backward()
         # once per train_step, as mmcv's OptimizerHook does.
         self.eager_backward = False
+        self._in_train_step, self._deferred_plan = False, None
         self.loss_scale = 1.0         # constant factor on every gradient (gradient accumulation: 1/k); the reported losses stay unscaled
         self._pending = []
         self._comm_stream = None
@@ -347,21 +348,31 @@ class FCOS(nn.Module):
         if head.loss_weight != 1.0 and gt_bboxes_ignore is None:
             raise TypeError('loss_weight != 1.0 needs gt_bboxes_ignore (fcos_head.py:223 iterates ig_labels)')
         lp = plan.lossplan
-        lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
         sw = head.effective_soft_weight(N)
         ws = self.world_size
         lp.configure(loss_weight=head.loss_weight, soft_weight=sw, grad_scale=self.loss_scale / ws, inv_world=1.0 / ws)
         plan.bind_image(img)
-        plan.assign_ops.run()
         work = None
-        if ws > 1:      # reduce_mean of (num_pos, sum centerness targets): one 2-float all-reduce (fcos_head.py:264-274)
+        if ws > 1:
+            # target assignment first: the reduce_mean of (num_pos, sum centerness targets) - one 2-float all-reduce
+            # (fcos_head.py:264-274) - then runs under the forward pass
+            lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
+            plan.assign_ops.run()
             work = dist.all_reduce(lp.stats[:2], group=self.dist_group, async_op=True)
-        plan.fwd.run()
-        if work is not None:
+            plan.fwd.run()
             work.wait()
+        else:
+            # one process: target upload + assignment go behind the forward pass on the caller's stream, into the time it
+            # would otherwise spend waiting for the regression tower on the side stream
+            plan.fwd.run()
+            lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
+            plan.assign_ops.run()
         plan.loss_ops.run()
         if self.eager_backward and torch.is_grad_enabled():
-            self._run_backward(plan)
+            if self._in_train_step:       # train_step queues it behind its log-variable ops (they only need the loss kernel)
+                self._deferred_plan = plan
+            else:
+                self._run_backward(plan)
         out = _TrainStepFn.apply(self._anchor, self, plan)
         losses = _LossDict(loss_cls=out[0], loss_bbox=out[1], loss_centerness=out[2])
         if sw != 0.0:
@@ -449,8 +460,17 @@ class FCOS(nn.Module):
 
     def train_step(self, data, optimizer):
         """detectors/base.py:210-243."""
-        losses = self(**data)
+        self._in_train_step, self._deferred_plan = True, None
+        try:
+            losses = self(**data)
+        finally:
+            self._in_train_step = False
         loss, log_vars = self._parse_losses(losses)
+        if self._deferred_plan is not None:
+            # eager backward: its kernels go behind the handful of small device ops above instead of in front of them, where
+            # those would sit between the last weight gradient and the optimizer step
+            plan, self._deferred_plan = self._deferred_plan, None
+            self._run_backward(plan)
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
 
     def val_step(self, data, optimizer=None):

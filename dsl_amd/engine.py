@@ -144,6 +144,8 @@ class Plan:
             # scale gradients go straight into the flat gradient buffer
             self.lossplan.desc.g_scales = store.t32_ptr('head.scales', store.grad)
             self.assign_ops.assign(self.lossplan.desc)
+            if self._fside:             # the regression tower's side stream: joined here, not at the end of the forward list,
+                self.loss_ops.join(self._fside)       # so that target upload + assignment run while it finishes
             self.loss_ops.loss(self.lossplan.desc)
             self._build_backward()
 
@@ -268,8 +270,9 @@ class Plan:
                              src_hw=ls, dst_hw=ls, cs=256, cd=5, cd_pad=64, ldd=8, kh=3, kw=3, stride=1, pad=1,
                              flags=L.CONV_OUT_F32, bias=st.t32_ptr('head.regctr_b'), workspace=self.conv_ws_side),
                side=FSIDE)
-        if FSIDE:
-            f.join(FSIDE)
+        self._fside = FSIDE
+        if FSIDE and not self.training:
+            f.join(FSIDE)               # (training plans: the loss op list starts with this join, see __init__)
 
     def _fwd_resnet(self, x, h, w):
         st, N, f = self.store, self.N, self.fwd
@@ -314,7 +317,7 @@ class Plan:
 
     # ---------------------------------------------------------------------------------------------
     def _wgrad(self, ol, spec, dy, x, n, out_hw, in_hw, cy=None, cd=None, wregion=None, bregion=None, side=False,
-               emit=True, no_db=False, ldx=0, shared=0, raw=False, db_ptr=None):
+               emit=True, no_db=False, ldx=0, shared=0, raw=False, db_ptr=None, slots=0):
         """emit=False: only build the descriptor (for a later grouped launch).  raw=True: no BatchNorm scale on the rows (the
         BN post-pass derives dgamma from the unscaled gradient and scales it afterwards); db_ptr: where the column sum of dy
         goes (that BatchNorm's dbeta)."""
@@ -331,7 +334,7 @@ class Plan:
         d = ops.wgrad_desc(dy, x, st.t32_ptr(name, st.grad), n=n, grid=out_hw, src_hw=in_hw,
                            cs=cs, cy=cy or spec.cout_pad, cd=cd or spec.cout,
                            kh=k, kw=k, stride=1 if spec is None else spec.stride, pad=1 if spec is None else spec.pad,
-                           scale=scale, db=db, workspace=self._wg_ws(n, out_hw, in_hw, spec, cy), ldx=ldx, shared=shared)
+                           scale=scale, db=db, workspace=self._wg_ws(n, out_hw, in_hw, spec, cy), ldx=ldx, shared=shared, slots=slots)
         if emit:
             if side and self._multi_on:
                 self._wg_pending.append([d])        # goes out with the next _flush_wgrads
@@ -417,6 +420,7 @@ class Plan:
         # tuning knobs (both measured: on is better): group the last segment's weight gradients too, although nothing
         # is left on the caller's stream to overlap their tail with ...
         GROUP_LAST = os.environ.get('DSL_GROUP_LAST', '1') != '0'
+        TAIL_SLOTS = int(os.environ.get('DSL_TAIL_SLOTS', '256'))
         GROUP = True       # same-geometry weight gradients (tower layers, the blocks of a stage) as one launch
         # ... and all weight gradients of a segment that share a tile configuration as one multi launch
         self._multi_on = SIDE and os.environ.get('DSL_WGRAD_MULTI', '1') != '0'
@@ -590,6 +594,7 @@ class Plan:
                 gA2 = self.buf(p + '.g_a2', N, hw[0], hw[1], planes)
                 gA1 = self.buf(p + '.g_a1', N, hw[0], hw[1], planes)
                 grp = GROUP and (li > 1 or GROUP_LAST)
+                tsl = TAIL_SLOTS if li == 1 else 0      # last segment: nothing else is left to run beside these launches
                 ds_early = BB and blk['b'] == 0 and li > 1
                 if ds_early:        # the downsample path's scatter into the previous stage's gradient, beside conv3 -> conv2 -> conv1
                     ds = cv[p + '.downsample.0']
@@ -597,14 +602,14 @@ class Plan:
                     ol.fork(BB)          # (stream 3 is in order: the lateral that initialised tgt is already queued there)
                     ol.conv(br_ws(self._dgrad(ds.name, g_pre, tgt, N, [hw], [ihw], cs=ds.cout, cd=ds.cin, k=1, stride=1, pad=0,
                                               os=2, addend=tgt, mask=blk['xin'], mask_first=True)), side=BB)
-                g3.append(self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw], side=SIDE, emit=not grp))
+                g3.append(self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw], side=SIDE, emit=not grp, slots=tsl))
                 ol.conv(self._dgrad(c3.name, g_pre, gA2, N, [hw], [hw], cs=c3.cout, cd=c3.cin, k=1, stride=1, pad=0,
                                     mask=blk['a2'], mask_last=True))
-                g2.append(self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw], side=SIDE, emit=not grp))
+                g2.append(self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw], side=SIDE, emit=not grp, slots=tsl))
                 ol.conv(self._dgrad(c2.name, gA2, gA1, N, [hw], [hw], cs=c2.cout, cd=c2.cin, k=3, stride=1, pad=1,
                                     mask=blk['a1'], mask_last=True))
                 d1 = self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE,
-                                 emit=not (grp and blk['b'] > 0))
+                                 emit=not (grp and blk['b'] > 0), slots=tsl)
                 if blk['b'] > 0:
                     g1.append(d1)
                 if blk['b'] > 0:
@@ -614,7 +619,7 @@ class Plan:
                     g_pre = g_prev
                 else:
                     ds = cv[p + '.downsample.0']
-                    self._wgrad(ol, ds, g_pre, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE)
+                    self._wgrad(ol, ds, g_pre, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, slots=tsl)
                     if li > 1:      # data gradient into the previous stage's output (stride-2 scatter)
                         tgt = self.g_stage[li - 1]
                         ihw = blk['in_hw']
@@ -624,11 +629,11 @@ class Plan:
                             ol.conv(self._dgrad(spec.name, dy, tgt, N, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
             if GROUP and (li > 1 or GROUP_LAST):
-                tail_main = (li == 1) and os.environ.get('DSL_TAIL_MAIN', '1') != '0'
-                for grp_descs in (g3, g2, g1):
-                    # last segment: the caller's stream has nothing left to do, it takes the last group itself
-                    self._wgrad_group(ol, grp_descs, side=SIDE and not (tail_main and grp_descs is g1),
-                                      ws_name='wg_ws_main' if (tail_main and grp_descs is g1) else 'wg_ws')
+                # last segment: the caller's stream has nothing left to do, it takes part of the groups itself
+                on_main = os.environ.get('DSL_TAIL_MAIN', '2') if li == 1 else '0'     # measured: tools/exp_r2w.sh
+                for gi, grp_descs in ((3, g3), (2, g2), (1, g1)):
+                    mine = str(gi) in on_main
+                    self._wgrad_group(ol, grp_descs, side=SIDE and not mine, ws_name='wg_ws_main' if mine else 'wg_ws')
             self._flush_wgrads(ol, side=SIDE)
             seg = 4 - li                      # 1, 2, 3
             ol.record(seg)

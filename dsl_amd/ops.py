@@ -47,13 +47,13 @@ def conv2d(*a, **k):
 
 
 def wgrad_desc(dy, x, dw, *, n, grid, src_hw, cs, cy, cd, kh, kw, stride=1, pad=0, scale=None, db=None,
-               workspace=None, force_cfg=None, ldx=0, shared=0):
+               workspace=None, force_cfg=None, ldx=0, shared=0, slots=0):
     d = L.WgradDesc()
     d.nseg, d.n = len(grid), n
     d.gh, d.gw = _segs(grid)
     d.sh, d.sw = _segs(src_hw)
     d.cs, d.cy, d.cd, d.kh, d.kw, d.stride, d.pad = cs, cy, cd, kh, kw, stride, pad
-    d.ldx, d.shared = ldx, shared
+    d.ldx, d.shared, d.slots = ldx, shared, slots
     d.splits = 0 if force_cfg is None else -(force_cfg + 1)     # negative: test hook forcing a tile config
     if force_cfg is None:
         d.splits = lib.dsl_wgrad_splits(C.byref(d))

@@ -105,6 +105,10 @@ typedef struct dsl_wgrad_desc {
   int32_t ldx;                                       /* 0 = cs; else X's pixel stride in elements (X is a channel slice of wider rows) */
   int32_t shared;                                    /* group launches: 1 = the members are applications of ONE convolution (same dw):
                                                       * their gradients are summed into dw (RLA's recurrent / conv_out layers) */
+  int32_t slots;                                     /* 0 = default (env DSL_WGRAD_SLOTS, 160); else the workgroup budget the split factor
+                                                      * is chosen for: launches that run beside the caller's stream leave it CUs, the
+                                                      * ones at the very end of a pass can take the chip (group launches: descs[0]'s) */
+  int32_t pad_;
 } dsl_wgrad_desc;
 
 int dsl_wgrad_splits(const dsl_wgrad_desc* d);
