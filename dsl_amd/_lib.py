@@ -107,6 +107,12 @@ class BnPostItem(C.Structure):
                 ('pad_', C.c_int32)]
 
 
+class ImagePrepItem(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('src_h', C.c_int32), ('src_w', C.c_int32), ('new_h', C.c_int32), ('new_w', C.c_int32),
+                ('flip', C.c_int32), ('ps_mode', C.c_int32), ('ps_crop', C.c_int32), ('to_rgb', C.c_int32),
+                ('mean', C.c_float * 3), ('inv_std', C.c_float * 3)]
+
+
 class Op(C.Structure):
     _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 7), ('desc', C.c_void_p),
                 ('p', C.c_void_p * 4), ('l', C.c_int64 * 2)]
@@ -134,6 +140,7 @@ _SIGS = {
     'dsl_wgrad_workspace_bytes': [_vp], 'dsl_wgrad_group_workspace_bytes': [_vp, _i], 'dsl_conv2d_wgrad_group': [_vp, _i, _vp],
     'dsl_wgrad_multi_config': [_vp], 'dsl_wgrad_multi_table_bytes': [], 'dsl_wgrad_multi_workspace_bytes': [_vp, _vp, _i],
     'dsl_wgrad_multi_build': [_vp, _vp, _i, _vp, C.c_size_t, _vp, C.c_size_t], 'dsl_conv2d_wgrad_multi': [_vp, _vp, _vp], 'dsl_wgrad_multi_info': [_vp, _vp, _vp, _vp, _vp, _vp],
+    'dsl_image_prep': [_vp, _i, _vp, _i, _i, _vp],
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
     'dsl_maxpool3x3s2_ld': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_avgpool2x2': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

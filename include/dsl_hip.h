@@ -143,6 +143,25 @@ int dsl_conv2d_wgrad_multi(const void* table_host, const void* table_dev, void* 
 int dsl_wgrad_multi_info(const void* table_host, double* flops, double* bytes, int* blocks, int* red_blocks, int* nsub);
 
 /* ------------------------------------------------------------------------------------------
+ * GPU data path
+ * ---------------------------------------------------------------------------------------- */
+/* One image of a batch: decoded uint8 HWC (BGR, as mmcv.imread yields) on the device and the parameters the reference's CPU
+ * pipeline draws per sample - Resize(keep_ratio) target size, PatchShuffle mode / split, RandomFlip, Normalize
+ * (mmdet/datasets/pipelines/transforms.py:218-247, 2143-2248, 334-470, 652-690). */
+typedef struct dsl_image_prep_item {
+  const unsigned char* src;      /* [src_h][src_w][3] */
+  int32_t src_h, src_w;
+  int32_t new_h, new_w;          /* size after Resize (= src size: no resampling) */
+  int32_t flip;                  /* horizontal */
+  int32_t ps_mode, ps_crop;      /* PatchShuffle: 0 none, 1 'flip' (columns [crop, w) first), 2 'flop' (rows [crop, h) first) */
+  int32_t to_rgb;
+  float mean[3], inv_std[3];     /* in output channel order */
+} dsl_image_prep_item;
+/* dst[n][3][hc][wc] fp32 <- resize (OpenCV's 8-bit fixed-point bilinear) -> PatchShuffle -> flip -> normalise, zero padded to the
+ * canvas (Pad(size_divisor) and the loader's merge/pad, datasets/builder.py:236-267).  items_dev: device array of n items. */
+int dsl_image_prep(const dsl_image_prep_item* items_dev, int n, float* dst, int hc, int wc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Memory-bound fused layers
  * ---------------------------------------------------------------------------------------- */
 /* NCHW fp32 image -> NHWC8 bf16 (channels 3..7 zero).  Replaces the implicit layout of

@@ -444,7 +444,58 @@ def gen_rla():
     print('wrote rla_tiny.npz', [tuple(o.shape) for o in outs], len(tk), 'trainable tensors')
 
 
+def gen_patch_shuffle():
+    """PatchShuffle (mmdet/datasets/pipelines/transforms.py:2143-2248) run from the reference file itself: the class and its
+    helper are compiled out of the module's source (the module imports cv2 / torchvision / imgaug, none installed) with numpy
+    stand-ins for the three image calls it makes (mmcv.imcrop with inclusive corners, cv2.hconcat / vconcat)."""
+    import ast
+    import json
+    import random
+    import types
+    path = '/root/reference/mmdet/datasets/pipelines/transforms.py'
+    src = open(path).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name == 'get_bbox_fields') or
+            (isinstance(n, ast.ClassDef) and n.name == 'PatchShuffle')]
+    for n in keep:
+        n.decorator_list = []
+    mod = ast.Module(body=keep, type_ignores=[])
+    mmcv = types.SimpleNamespace(imcrop=lambda img, b: img[int(b[1]):int(b[3]) + 1, int(b[0]):int(b[2]) + 1])
+    cv2 = types.SimpleNamespace(hconcat=lambda xs: np.concatenate(xs, 1), vconcat=lambda xs: np.concatenate(xs, 0))
+    g = dict(np=np, random=random, mmcv=mmcv, cv2=cv2)
+    exec(compile(mod, path, 'exec'), g)
+    PS = g['PatchShuffle']
+    cases = []
+    rng = np.random.RandomState(77)
+    for ci in range(24):
+        np.random.seed(1000 + ci)
+        random.seed(2000 + ci)
+        h, w = int(rng.randint(12, 40)), int(rng.randint(12, 40))
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        n, k = int(rng.randint(0, 6)), int(rng.randint(0, 3))
+        def boxes(m):
+            x1, y1 = rng.uniform(0, w - 2, m), rng.uniform(0, h - 2, m)
+            x2, y2 = x1 + rng.uniform(1, w / 2, m), y1 + rng.uniform(1, h / 2, m)
+            return np.stack([x1, y1, np.minimum(x2, w), np.minimum(y2, h)], 1).astype(np.float32).reshape(-1, 4)
+        res = dict(img=img.copy(), gt_bboxes=boxes(n), gt_labels=rng.randint(0, 80, n).astype(np.int64),
+                   gt_bboxes_ignore=boxes(k), bbox_fields=['gt_bboxes_ignore'])
+        inp = {kk: (v.tolist() if isinstance(v, np.ndarray) else v) for kk, v in res.items() if kk not in ('bbox_fields', 'img')}
+        inp['img_shape'], inp['img_hex'] = [h, w, 3], img.tobytes().hex()
+        t = PS(ratio=0.9 if ci % 6 else 1.0, ranges=[0.0, 1.0] if ci % 3 else [0.2, 0.8], mode=['flip', 'flop'])
+        out = t(res)
+        cases.append(dict(seed=(1000 + ci, 2000 + ci), ratio=t.ratio, ranges=t.ranges, input=inp,
+                          output=dict(PS=bool(out['PS']), PS_place=None if out['PS_place'] is None else float(out['PS_place']),
+                                      PS_mode=out['PS_mode'], img_hex=np.ascontiguousarray(out['img']).tobytes().hex(), gt_bboxes=np.asarray(out['gt_bboxes']).reshape(-1, 4).tolist(),
+                                      gt_labels=np.asarray(out['gt_labels']).tolist(),
+                                      gt_bboxes_ignore=np.asarray(out['gt_bboxes_ignore']).reshape(-1, 4).tolist())))
+    json.dump(cases, open(os.path.join(HERE, 'patch_shuffle.json'), 'w'))
+    print('wrote patch_shuffle.json', len(cases), 'cases,', sum(c['output']['PS'] for c in cases), 'shuffled')
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['ps']:
+        gen_patch_shuffle()
+        sys.exit(0)
     if sys.argv[1:] == ['parse_dets']:
         gen_parse_dets()
         sys.exit(0)
