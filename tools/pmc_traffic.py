@@ -1,7 +1,9 @@
 """HBM traffic per launch of the dominant kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
 bench.py, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: FETCH_SIZE counts
 128-byte read requests at 64 B -> doubled; both counters are in KiB.  WRITE_SIZE is uncalibrated (used as is).
-Usage: python tools/pmc_traffic.py fetch_results.db write_results.db out.json"""
+A bench.py log (its JSON line) given as 4th argument adds the ALGORITHMIC bytes per launch bench.py derives for its kernel
+classes next to the measured ones (traffic well above the algorithmic bytes = wasted re-reads).
+Usage: python tools/pmc_traffic.py fetch_results.db write_results.db out.json [bench.log]"""
 import json
 import re
 import sqlite3
@@ -31,8 +33,31 @@ for k in fetch:
         _, w = write[k]
         out[k] = dict(launches=n, fetch_size_kib=round(f, 1), write_size_kib=round(w, 1),
                       hbm_bytes_per_launch=round((2 * f + w) * 1024))
+algo = {}
+if len(sys.argv) > 4:
+    for line in open(sys.argv[4]):
+        if line.startswith('{') and '"roofline"' in line:
+            r = json.loads(line)['roofline']
+            algo['conv_pipe_kernel<128, 128, 2, 4, 2, false>'] = r.get('algorithmic_bytes_per_launch')
+            for key, kn in (('head_tile_256x192', 'conv_pipe_kernel<256, 192, 4, 2, 2, false>'),):
+                if key in r:
+                    algo[kn] = round(r[key]['algorithmic_mb_per_launch'] * 1e6)
+            if 'wgrad_kernels' in r:
+                algo['wgrad (all launches, average)'] = round(r['wgrad_kernels']['algorithmic_mb_per_launch'] * 1e6)
+for k, v in out.items():
+    if k in algo and algo[k]:
+        v['algorithmic_bytes_per_launch'] = algo[k]
+        v['measured_over_algorithmic'] = round(v['hbm_bytes_per_launch'] / algo[k], 2)
+wg = [(v['launches'], v['hbm_bytes_per_launch']) for k, v in out.items() if k.startswith('wgrad')]
+if wg and algo.get('wgrad (all launches, average)'):
+    tot = sum(n * b for n, b in wg)
+    nl = sum(n for k, v in out.items() if k.startswith('wgrad_glds') for n in [v['launches']])
+    out['wgrad (all launches, average)'] = dict(launches=nl, hbm_bytes_per_launch=round(tot / max(nl, 1)),
+                                                algorithmic_bytes_per_launch=algo['wgrad (all launches, average)'],
+                                                measured_over_algorithmic=round(tot / max(nl, 1) / algo['wgrad (all launches, average)'], 2),
+                                                note='main + reduce kernels of the weight gradients per main launch')
 json.dump(dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 3 '
-                      '--warmup 2 --no-prof`; read bytes = 2 x FETCH_SIZE (gfx950 correction), KiB units',
+                      '--warmup 2 --no-prof --no-dsl`; read bytes = 2 x FETCH_SIZE (gfx950 correction), KiB units',
                kernels=out), open(sys.argv[3], 'w'), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:8]:
     print(k, v)
