@@ -228,9 +228,11 @@ class Plan:
         f.conv(br(self._conv(fc[3], self.feat_seg[2], p6r, N, [hw5], [hw6], relu=True)), side=BR)        # relu(P6)
         f.conv(br(self._conv(fc[4], p6r, self.feat_seg[4], N, [hw6], [hw7])), side=BR)                   # P7
         f.conv(self._conv(lc[1], c4, lat[1], N, [hw4], [hw4], addend=lat[2], add_hw=[hw5], lds=ld4))
+        if BR:
+            f.fork(BR)          # P4's output conv joins the side chain once its lateral exists: the caller's stream keeps C3 -> P3
+        f.conv(br(self._conv(fc[1], lat[1], self.feat_seg[1], N, [hw4], [hw4])), side=BR)
         f.conv(self._conv(lc[0], c3, lat[0], N, [hw3], [hw3], addend=lat[1], add_hw=[hw4], lds=ld3))
-        for i, hw in enumerate((hw3, hw4)):
-            f.conv(self._conv(fc[i], lat[i], self.feat_seg[i], N, [hw], [hw]))
+        f.conv(self._conv(fc[0], lat[0], self.feat_seg[0], N, [hw3], [hw3]))
         if BR:
             f.join(BR)
         # ---- head: shared weights, all 5 levels per launch ----
@@ -475,7 +477,8 @@ class Plan:
                                  dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad),
                                  dbias=st.t32_ptr(lay['spec'].name + '.bias', st.grad))
                 ol.gn_bwd(gd, side=sd)
-                tower_group.append(self._wgrad(ol, lay['spec'], g_pre[tower], lay['xin'], N, ls, ls, side=SIDE, emit=False, no_db=True))
+                tower_group.append(self._wgrad(ol, lay['spec'], g_pre[tower], lay['xin'], N, ls, ls, side=SIDE, emit=False, no_db=True,
+                                               slots=int(os.environ.get('DSL_TOWER_SLOTS', '96'))))     # measured: tools/exp_r2z.sh (48-128: 5.84 ms, 160-192: 5.89)
             if (HALVES and i in (2, 0)) or i == 0:
                 if BT and SIDE:
                     ol.fork(1, other=BT)       # the weight-gradient stream also waits for the regression tower's stream
