@@ -24,6 +24,7 @@ CONV_RELU_OUT, CONV_RELU_IN, CONV_OUT_F32, CONV_MASK_FIRST, CONV_MASK_LAST, CONV
 OP_RLA = 17
 OP_PACK_DGRAD = 18
 OP_WGRAD_MULTI = 19
+OP_PAIR = 20
 MAX_MULTI = 16
 SLOT_PACKS = 15      # named event: the data-gradient weight packs of the last optimizer step are complete
 (RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST) = range(2, 8)
@@ -107,6 +108,14 @@ class BnPostItem(C.Structure):
                 ('pad_', C.c_int32)]
 
 
+class PairDesc(C.Structure):
+    _fields_ = [('m', C.c_int32), ('p', C.c_int32), ('a', C.c_void_p), ('lda', C.c_int32), ('relu1', C.c_int32), ('wa', C.c_void_p),
+                ('scale1', C.c_void_p), ('bias1', C.c_void_p), ('addend', C.c_void_p), ('ldadd', C.c_int32), ('ldm1', C.c_int32),
+                ('mask1', C.c_void_p), ('mid', C.c_void_p), ('ldmid', C.c_int32), ('relu2', C.c_int32), ('wb', C.c_void_p),
+                ('scale2', C.c_void_p), ('bias2', C.c_void_p), ('mask2', C.c_void_p), ('ldm2', C.c_int32), ('ldo', C.c_int32),
+                ('out', C.c_void_p)]
+
+
 class ImagePrepItem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('src_h', C.c_int32), ('src_w', C.c_int32), ('new_h', C.c_int32), ('new_w', C.c_int32),
                 ('flip', C.c_int32), ('ps_mode', C.c_int32), ('ps_crop', C.c_int32), ('to_rgb', C.c_int32),
@@ -140,7 +149,7 @@ _SIGS = {
     'dsl_wgrad_workspace_bytes': [_vp], 'dsl_wgrad_group_workspace_bytes': [_vp, _i], 'dsl_conv2d_wgrad_group': [_vp, _i, _vp],
     'dsl_wgrad_multi_config': [_vp], 'dsl_wgrad_multi_table_bytes': [], 'dsl_wgrad_multi_workspace_bytes': [_vp, _vp, _i],
     'dsl_wgrad_multi_build': [_vp, _vp, _i, _vp, C.c_size_t, _vp, C.c_size_t], 'dsl_conv2d_wgrad_multi': [_vp, _vp, _vp], 'dsl_wgrad_multi_info': [_vp, _vp, _vp, _vp, _vp, _vp],
-    'dsl_image_prep': [_vp, _i, _vp, _i, _i, _vp],
+    'dsl_image_prep': [_vp, _i, _vp, _i, _i, _vp], 'dsl_conv1x1_pair': [_vp, _vp],
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
     'dsl_maxpool3x3s2_ld': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_avgpool2x2': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

@@ -70,6 +70,9 @@ class OpList:
         self._add(L.OP_WGRAD_MULTI, i=(0, 0, 0, 0, 0, 0, 1 if side else 0), p=(plan.host.data_ptr(), plan.dev.data_ptr()))
         self.keep.append(plan)
 
+    def pair(self, d):
+        self._add(L.OP_PAIR, d)
+
     def join(self, side=1):
         self._add(L.OP_JOIN, i=(side,))
 
@@ -280,13 +283,15 @@ class Plan:
         st, N, f = self.store, self.N, self.fwd
         cv = st.convs
         self.blocks = []        # per block: dict(xin, a1, a2, out, idt, in_hw, out_hw, prefix, stride)
+        PAIR_FWD = os.environ.get('DSL_PAIR_FWD', '')      # stages (layer numbers) whose conv3 -> next conv1 pairs run fused, e.g. '23'
+        pair_done = False
         for li, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
             for b in range(nb):
                 p = f'backbone.layer{li + 1}.{b}'
                 c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
                 s = c1.stride
                 oh, ow = conv_out(h, 1, s, 0), conv_out(w, 1, s, 0)
-                a1 = self.buf(p + '.a1', N, oh, ow, planes)
+                a1 = self.bufs[p + '.a1'] if pair_done else self.buf(p + '.a1', N, oh, ow, planes)
                 a2 = self.buf(p + '.a2', N, oh, ow, planes)
                 out = self.buf(p + '.out', N, oh, ow, planes * 4)
                 idt = x
@@ -297,11 +302,23 @@ class Plan:
                         dd.workspace, dd.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
                         f.fork(self.BR)
                     f.conv(dd, side=self.BR)
-                f.conv(self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True))
+                if not pair_done:       # (else: computed by the previous block's pair launch)
+                    f.conv(self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True))
                 f.conv(self._conv(c2, a1, a2, N, [(oh, ow)], [(oh, ow)], relu=True))
                 if b == 0 and self.BR:
                     f.join(self.BR)
-                f.conv(self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt))
+                pair_done = False
+                if PAIR_FWD and b + 1 < nb and planes in (128, 256) and str(li + 1) in PAIR_FWD:
+                    # this block's expand conv + the next block's reduce conv as one launch (csrc/pair.hip)
+                    nxt = cv[f'backbone.layer{li + 1}.{b + 1}.conv1']
+                    a1n = self.buf(f'backbone.layer{li + 1}.{b + 1}.a1', N, oh, ow, planes)
+                    s3, b3 = st.bn_ptrs(c3.bn)
+                    s1n, b1n = st.bn_ptrs(nxt.bn)
+                    f.pair(ops.pair_desc(a2, st.w16_ptr(c3), out, st.w16_ptr(nxt), a1n, m=N * oh * ow, p=planes, scale1=s3, bias1=b3,
+                                         addend=idt, ldadd=planes * 4, relu1=True, scale2=s1n, bias2=b1n, relu2=True))
+                    pair_done = True
+                else:
+                    f.conv(self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt))
                 self.blocks.append(dict(prefix=p, xin=x, a1=a1, a2=a2, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
                                         stage=li, b=b, planes=planes))
                 x, h, w = out, oh, ow

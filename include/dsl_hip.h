@@ -142,6 +142,27 @@ int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* counts, int ns
 int dsl_conv2d_wgrad_multi(const void* table_host, const void* table_dev, void* stream);
 int dsl_wgrad_multi_info(const void* table_host, double* flops, double* bytes, int* blocks, int* red_blocks, int* nsub);
 
+/* Two back-to-back 1x1 convolutions as one launch (csrc/pair.hip): a bottleneck's expand conv and the next bottleneck's reduce
+ * conv in the forward pass (resnet.py:262-301), the reduce conv's and the expand conv's data gradients in the backward pass.
+ *   mid[m][4p] = epi1( a[m][p] . wa[4p][p]^T )      epi1: x scale1 + bias1, + addend, x (mask1 > 0), relu1   (each optional)
+ *   out[m][p]  = epi2( mid[m][4p] . wb[p][4p]^T )   epi2: x scale2 + bias2, x (mask2 > 0), relu2
+ * bf16 tensors, fp32 accumulation; `mid` is written (bf16) and consumed from LDS, never read back.  Bit-identical to two
+ * dsl_conv2d launches with the same epilogues.  p = 128 or 256; row strides in elements, multiples of 8. */
+typedef struct dsl_pair_desc {
+  int32_t m, p;
+  const void* a; int32_t lda; int32_t relu1;
+  const void* wa;
+  const float* scale1; const float* bias1;
+  const void* addend; int32_t ldadd; int32_t ldm1;
+  const void* mask1;
+  void* mid; int32_t ldmid; int32_t relu2;
+  const void* wb;
+  const float* scale2; const float* bias2;
+  const void* mask2; int32_t ldm2; int32_t ldo;
+  void* out;
+} dsl_pair_desc;
+int dsl_conv1x1_pair(const dsl_pair_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GPU data path
  * ---------------------------------------------------------------------------------------- */
@@ -364,7 +385,8 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_RECORD = 15, /* mark "everything queued so far on stream i[0]" in named event slot i[1] (0..15); survives the call */
        DSL_OP_WAIT = 16,   /* stream i[0] waits for named event slot i[1] (no-op if the slot was never recorded) */
        DSL_OP_PACK_DGRAD = 18, /* dsl_pack_dgrad_batched(p[0] = item table, i[0] = items, i[1] = blocks) */
-       DSL_OP_WGRAD_MULTI = 19 }; /* dsl_conv2d_wgrad_multi(p[0] = table_host, p[1] = table_dev) */
+       DSL_OP_WGRAD_MULTI = 19, /* dsl_conv2d_wgrad_multi(p[0] = table_host, p[1] = table_dev) */
+       DSL_OP_PAIR = 20 };      /* desc = dsl_pair_desc -> dsl_conv1x1_pair */
 typedef struct dsl_op {
   int32_t kind;
   int32_t i[7];            /* small integer arguments for the simple ops; i[6] = s > 0: run this op on the library's

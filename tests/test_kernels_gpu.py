@@ -273,6 +273,52 @@ def test_conv_dgrad_1x1_s2_scatter(K):
     assert torch.allclose(from_nhwc(dx), ref, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize('P,M', [(128, 64 * 7), (128, 1000), (256, 64 * 3 + 16), (256, 8400)])
+@pytest.mark.parametrize('mode', ['forward', 'backward'])
+def test_conv1x1_pair_equals_two_launches(K, P, M, mode):
+    """dsl_conv1x1_pair == the expand conv followed by the next block's reduce conv as two dsl_conv2d launches, bit for bit
+    (forward: BN fold + residual + ReLU, then BN fold + ReLU; backward: residual gradient + ReLU mask, then ReLU mask)."""
+    L, ops = K
+    g = torch.Generator().manual_seed(P + M)
+    a = rnd(M, P, g=g).bfloat16().cuda()
+    wa = (rnd(4 * P, P, g=g) * (P ** -0.5)).bfloat16().cuda()
+    wb = (rnd(P, 4 * P, g=g) * ((4 * P) ** -0.5)).bfloat16().cuda()
+    addend = rnd(M, 4 * P, g=g).bfloat16().cuda()
+    fwd = mode == 'forward'
+    s1 = (torch.rand(4 * P, generator=g) + 0.5).cuda() if fwd else None
+    b1 = rnd(4 * P, g=g).cuda() if fwd else None
+    s2 = (torch.rand(P, generator=g) + 0.5).cuda() if fwd else None
+    b2 = rnd(P, g=g).cuda() if fwd else None
+    m1 = None if fwd else rnd(M, 4 * P, g=g).bfloat16().cuda()
+    m2 = None if fwd else rnd(M, P, g=g).bfloat16().cuda()
+    mid = torch.full((M, 4 * P), float('nan'), dtype=torch.bfloat16, device='cuda')
+    out = torch.full((M, P), float('nan'), dtype=torch.bfloat16, device='cuda')
+    ops.conv1x1_pair(a, wa, mid, wb, out, m=M, p=P, scale1=s1, bias1=b1, addend=addend, ldadd=4 * P, mask1=m1, ldm1=4 * P,
+                     relu1=fwd, scale2=s2, bias2=b2, mask2=m2, ldm2=P, relu2=fwd)
+    # the same as two launches of the conv kernel (1 x M "image")
+    mid_r = torch.empty_like(mid)
+    out_r = torch.empty_like(out)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
+    f1 = (L.CONV_RELU_OUT if fwd else 0) | (0 if fwd else L.CONV_MASK_LAST)
+    ops.conv2d(a, wa, mid_r, n=1, grid=[(1, M)], src_hw=[(1, M)], dst_hw=[(1, M)], cs=P, cd=4 * P, cd_pad=4 * P, ldd=4 * P, kh=1, kw=1,
+               flags=f1, scale=s1, bias=b1, addend=addend, lda=4 * P, mask=m1, ldm=4 * P, workspace=ws)
+    ops.conv2d(mid_r, wb, out_r, n=1, grid=[(1, M)], src_hw=[(1, M)], dst_hw=[(1, M)], cs=4 * P, cd=P, cd_pad=P, ldd=P, kh=1, kw=1,
+               flags=f1, scale=s2, bias=b2, mask=m2, ldm=P, workspace=ws)
+    sync()
+    assert torch.equal(mid.view(torch.int16), mid_r.view(torch.int16))
+    assert torch.equal(out.view(torch.int16), out_r.view(torch.int16))
+    # and it is the right function (fp32 reference on the same bf16 inputs)
+    x = a.float().cpu() @ wa.float().cpu().t()
+    if fwd:
+        x = x * s1.cpu() + b1.cpu()
+    x = x + addend.float().cpu()
+    if not fwd:
+        x = x * (m1.float().cpu() > 0)
+    if fwd:
+        x = x.relu()
+    assert torch.allclose(mid.float().cpu(), x, rtol=2e-2, atol=2e-2)
+
+
 WG_CASES = [('3x3_s1', 2, 128, 128, 12, 17, 3, 1, 1), ('1x1_s2', 2, 256, 128, 14, 18, 1, 2, 0), ('3x3_256', 2, 256, 256, 9, 13, 3, 1, 1),
             ('3x3_s2', 1, 128, 256, 13, 21, 3, 2, 1), ('1x1_s1_co64', 2, 128, 64, 9, 10, 1, 1, 0)]
 
