@@ -3,6 +3,9 @@ missing, importing this module raises."""
 import ctypes as C
 import os
 
+import torch  # noqa: F401  - FIRST: the library must bind to the HIP runtime torch ships (torch/lib/libamdhip64), not pull the system's
+#                             copy into the process ahead of it: two runtimes in one process leave the second without a device
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DSL_HIP_LIB') or os.path.join(HERE, 'lib', 'libdsl_hip.so')   # override: kernel ablation builds (tools/)
 MAX_SEG = 5
