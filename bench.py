@@ -180,6 +180,7 @@ def main():
     model = build_detector(model_cfg()).cuda()      # random init, reference style, same seed on every rank
     model.lazy_log = True
     model.eager_backward = True      # backward kernels are queued right behind the loss kernel (see FCOS.eager_backward)
+    model.pipeline_prefix = os.environ.get('DSL_BENCH_PIPE', '1') != '0'     # inputs are resident: see FCOS.pipeline_prefix
     if world > 1:
         model = HipDistributedDataParallel(model)
     det = model.module if world > 1 else model

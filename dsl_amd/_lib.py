@@ -29,6 +29,7 @@ OP_PACK_DGRAD = 18
 OP_WGRAD_MULTI = 19
 OP_PAIR = 20
 MAX_MULTI = 16
+SLOT_TAIL, SLOT_PREFIX = 13, 14     # pipelined frozen prefix: 'previous backward's data-gradient chain done', 'prefix of this step done'
 SLOT_PACKS = 15      # named event: the data-gradient weight packs of the last optimizer step are complete
 (RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST) = range(2, 8)
 MAX_GROUP = 8

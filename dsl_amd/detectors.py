@@ -270,6 +270,11 @@ class FCOS(nn.Module):
         # once per train_step, as mmcv's OptimizerHook does.
         self.eager_backward = False
         self._in_train_step, self._deferred_plan = False, None
+        # True: the caller guarantees that a batch's image tensor is complete before the PREVIOUS step's backward pass was queued
+        # (resident inputs, a loader on its own synchronised stream): the frozen prefix of the forward pass - image layout, stem,
+        # pool, layer1 - then runs on its own stream under the tail of that backward pass and the optimizer step (bench.py sets it)
+        self.pipeline_prefix = False
+        self._prefix_stream = None
         self.loss_scale = 1.0         # constant factor on every gradient (gradient accumulation: 1/k); the reported losses stay unscaled
         self._pending = []
         self._comm_stream = None
@@ -351,7 +356,22 @@ class FCOS(nn.Module):
         sw = head.effective_soft_weight(N)
         ws = self.world_size
         lp.configure(loss_weight=head.loss_weight, soft_weight=sw, grad_scale=self.loss_scale / ws, inv_world=1.0 / ws)
-        plan.bind_image(img)
+        pipe = self.pipeline_prefix and plan.prefix is not None
+        if pipe:
+            # frozen prefix of THIS step on its own stream: it waits for the previous backward's data-gradient chain only (named
+            # event), not for that step's weight-gradient tail / optimizer step; layer1's output alternates between two buffers
+            plan.set_parity(plan._parity ^ 1)
+            plan.bind_image(img)
+            if self._prefix_stream is None:
+                self._prefix_stream = torch.cuda.Stream()
+            if img.is_cuda:
+                img.record_stream(self._prefix_stream)
+            with torch.cuda.stream(self._prefix_stream):
+                plan.prefix.run()
+            fwd = plan.fwd_rest
+        else:
+            plan.bind_image(img)
+            fwd = plan.fwd
         work = None
         if ws > 1:
             # target assignment first: the reduce_mean of (num_pos, sum centerness targets) - one 2-float all-reduce
@@ -359,12 +379,12 @@ class FCOS(nn.Module):
             lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
             plan.assign_ops.run()
             work = dist.all_reduce(lp.stats[:2], group=self.dist_group, async_op=True)
-            plan.fwd.run()
+            fwd.run()
             work.wait()
         else:
             # one process: target upload + assignment go behind the forward pass on the caller's stream, into the time it
             # would otherwise spend waiting for the regression tower on the side stream
-            plan.fwd.run()
+            fwd.run()
             lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
             plan.assign_ops.run()
         plan.loss_ops.run()

@@ -141,6 +141,9 @@ class Plan:
         self.conv_ws = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
         self._gn_ws = {}          # GroupNorm block-record workspaces, one per stream that runs GroupNorm launches
         self._build_forward()
+        self.prefix = None
+        if training and store.backbone != 'rla' and os.environ.get('DSL_PIPE_PREFIX', '1') != '0' and os.environ.get('DSL_SIDE', '1') != '0':
+            self._split_prefix()
         if training:
             self.lossplan = FcosLossPlan(N, self.level_sizes, dev, max_gt=max_gt)
             self.lossplan.bind_outputs(self.bufs['cls_logits'], self.bufs['regctr'], store.t32_ptr('head.scales'))
@@ -283,6 +286,7 @@ class Plan:
         st, N, f = self.store, self.N, self.fwd
         cv = st.convs
         self.blocks = []        # per block: dict(xin, a1, a2, out, idt, in_hw, out_hw, prefix, stride)
+        self._pp = {}           # descriptors that touch layer1's output (pipelined prefix: two buffers, patched per step)
         PAIR_FWD = os.environ.get('DSL_PAIR_FWD', '')      # stages (layer numbers) whose conv3 -> next conv1 pairs run fused, e.g. '23'
         pair_done = False
         for li, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
@@ -302,8 +306,13 @@ class Plan:
                         dd.workspace, dd.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
                         f.fork(self.BR)
                     f.conv(dd, side=self.BR)
+                if li == 1 and b == 0:
+                    self._pp['ds'] = dd
                 if not pair_done:       # (else: computed by the previous block's pair launch)
-                    f.conv(self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True))
+                    d1 = self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True)
+                    if li == 1 and b == 0:
+                        self._pp['c1'] = d1
+                    f.conv(d1)
                 f.conv(self._conv(c2, a1, a2, N, [(oh, ow)], [(oh, ow)], relu=True))
                 if b == 0 and self.BR:
                     f.join(self.BR)
@@ -318,12 +327,17 @@ class Plan:
                                          addend=idt, ldadd=planes * 4, relu1=True, scale2=s1n, bias2=b1n, relu2=True))
                     pair_done = True
                 else:
-                    f.conv(self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt))
+                    d3 = self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt)
+                    if li == 0 and b == nb - 1:
+                        self._pp['c3'], self._pp['out'] = d3, out
+                    f.conv(d3)
                 self.blocks.append(dict(prefix=p, xin=x, a1=a1, a2=a2, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
                                         stage=li, b=b, planes=planes))
                 x, h, w = out, oh, ow
             self.stage_out.append((x, (h, w)))
             self.stage_ld.append(planes * 4)
+            if li == 0:
+                self._prefix_end = len(f.items)        # pack + stem + pool + layer1: frozen weights, a function of the image alone
 
     def _gn_workspace(self, key):
         """Launches on one stream run one after the other and may share the block-record scratch."""
@@ -630,6 +644,8 @@ class Plan:
                                     mask=blk['a1'], mask_last=True))
                 d1 = self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE,
                                  emit=not (grp and blk['b'] > 0), slots=tsl)
+                if li == 1 and blk['b'] == 0:
+                    self._pp['wg_c1'] = d1
                 if blk['b'] > 0:
                     g1.append(d1)
                 if blk['b'] > 0:
@@ -639,7 +655,9 @@ class Plan:
                     g_pre = g_prev
                 else:
                     ds = cv[p + '.downsample.0']
-                    self._wgrad(ol, ds, g_pre, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, slots=tsl)
+                    dwd = self._wgrad(ol, ds, g_pre, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, slots=tsl)
+                    if li == 1:
+                        self._pp['wg_ds'] = dwd
                     if li > 1:      # data gradient into the previous stage's output (stride-2 scatter)
                         tgt = self.g_stage[li - 1]
                         ihw = blk['in_hw']
@@ -648,6 +666,8 @@ class Plan:
                         for spec, dy in ((c1, gA1),) if ds_early else ((ds, g_pre), (c1, gA1)):
                             ol.conv(self._dgrad(spec.name, dy, tgt, N, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
+            if li == 1:
+                ol.record(L.SLOT_TAIL, stream=0)       # the data-gradient chain is done: the next step's frozen prefix may start
             if GROUP and (li > 1 or GROUP_LAST):
                 # last segment: the caller's stream has nothing left to do, it takes part of the groups itself
                 on_main = os.environ.get('DSL_TAIL_MAIN', '2') if li == 1 else '0'     # measured: tools/exp_r2w.sh
@@ -663,19 +683,64 @@ class Plan:
             self.bwd_segments.append((ol, dict(bucket=buckets[seg], slot=seg, main=(li == 1))))
 
     # ---------------------------------------------------------------------------------------------
+    def _split_prefix(self):
+        """Pipelined frozen prefix (FCOS.pipeline_prefix): image layout + stem + pool + layer1 have frozen weights, so the next
+        step's can run on its own stream from the moment the previous backward's data-gradient chain is done - beside the tail
+        of the weight gradients, the log-variable ops and SGD, when the caller's stream has little to do.  The prefix is its
+        own op list (run with that stream as the list's 'caller'); layer1's output has two buffers, alternating per step,
+        because the previous step's last weight gradients (layer2.0's conv1 / downsample) still read theirs."""
+        f, end = self.fwd, self._prefix_end
+        pre, rest = OpList(), OpList()
+        pre.items, rest.items = f.items[:end], f.items[end:]
+        pre.keep = rest.keep = f.keep
+        ws = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)      # the prefix runs beside the caller's convs: own split-K scratch
+        for o in pre.items:
+            if o.kind == L.OP_CONV and o.i[6] == 0:
+                d = C.cast(o.desc, C.POINTER(L.ConvDesc)).contents
+                if d.workspace:
+                    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        pre.keep.append(ws)
+        w0 = L.Op()
+        w0.kind, w0.i[0], w0.i[1] = L.OP_WAIT, 0, L.SLOT_TAIL
+        r0 = L.Op()
+        r0.kind, r0.i[0], r0.i[1] = L.OP_RECORD, 0, L.SLOT_PREFIX
+        pre.items = [w0] + pre.items + [r0]
+        self._img_op += 1
+        w1 = L.Op()
+        w1.kind, w1.i[0], w1.i[1] = L.OP_WAIT, 0, L.SLOT_PREFIX
+        self.fwd_inline = f                     # the whole forward pass as one list on the caller's stream (pipeline_prefix off)
+        self.fwd_rest = rest
+        rest.items = [w1] + rest.items
+        self.prefix = pre
+        out = self._pp['out']
+        self._l1out = [out, torch.empty_like(out)]
+        self._parity = 0
+
+    def set_parity(self, p):
+        """Points the five descriptors that touch layer1's output at buffer p."""
+        ptr = self._l1out[p].data_ptr()
+        self._pp['c3'].dst = ptr
+        self._pp['c1'].src = ptr
+        self._pp['ds'].src = ptr
+        self._pp['wg_c1'].x = ptr
+        self._pp['wg_ds'].x = ptr
+        self._parity = p
+
     def bind_image(self, img):
         """The batch for the next fwd.run(): a dense fp32 tensor on this device is read in place by the layout kernel (it
         must stay alive until that kernel has run - stream order on the caller's stream); anything else is staged in self.img."""
-        f = self.fwd
-        if f.arr is None:
-            f.arr = (L.Op * len(f.items))(*f.items)
-        if img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and img.device == self.img.device:
-            f.arr[self._img_op].p[0] = img.data_ptr()
-            self._img_ref = img
-        else:
+        direct = img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and img.device == self.img.device
+        if not direct:
             self.img.copy_(img, non_blocking=True)
-            f.arr[self._img_op].p[0] = self.img.data_ptr()
-            self._img_ref = None
+        ptr = img.data_ptr() if direct else self.img.data_ptr()
+        self._img_ref = img if direct else None
+        lists = [(self.fwd, self._img_op - (1 if self.prefix is not None else 0))]
+        if self.prefix is not None:
+            lists.append((self.prefix, self._img_op))
+        for f, idx in lists:
+            if f.arr is None:
+                f.arr = (L.Op * len(f.items))(*f.items)
+            f.arr[idx].p[0] = ptr
 
     def forward(self, img=None):
         if img is not None:

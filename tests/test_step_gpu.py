@@ -263,3 +263,31 @@ def test_training_step_is_bit_reproducible(golden):
     assert l0 == l1 == l2
     assert torch.equal(g0, g1) and torch.equal(g1, g2)
     assert n1 == n2 and n1 > 1.0 and torch.equal(w1, w2)
+
+
+def test_pipelined_prefix_equals_inline_forward(golden):
+    """FCOS.pipeline_prefix (frozen stem + layer1 of step i+1 on its own stream under the tail of step i's backward, layer1's
+    output double-buffered) trains to bit-identical weights as the single-stream order, also when the images change per step."""
+    from dsl_amd.optim import FlatSGD
+    d = golden('net_tiny.npz')
+    B = int(d['B'])
+    gtb, gtl = [T(d[f'gt{i}']) for i in range(B)], [T(d[f'gl{i}']) for i in range(B)]
+    g = torch.Generator().manual_seed(3)
+    imgs = [(T(d['img']) + 0.5 * k * torch.randn(T(d['img']).shape, generator=g)).cuda() for k in range(4)]
+    metas = [dict(img_shape=tuple(imgs[0].shape[2:]) + (3,), pad_shape=tuple(imgs[0].shape[2:]) + (3,), scale_factor=1.0)] * B
+    finals = []
+    for pipe in (False, True):
+        model = build()
+        model.eager_backward, model.pipeline_prefix, model.lazy_log = True, pipe, True
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+        losses = []
+        for img in imgs:
+            out = model.train_step(dict(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl), opt)
+            out['loss'].backward()
+            opt.step()
+            losses.append(out['loss'].detach().clone())
+        torch.cuda.synchronize()
+        plan = [p for p in model._engine.plans.values() if p.training][0]
+        assert (plan.prefix is not None) and (plan._parity == (0 if not pipe else len(imgs) % 2))
+        finals.append((torch.stack(losses).cpu(), model.store.train.clone().cpu()))
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
