@@ -13,6 +13,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -25,7 +26,7 @@ PEAK_HBM_GBS = 8000.0              # HBM3E spec (same guide; ~6.3 TB/s achievabl
 DOMINANT = 'conv_pipe_kernel<128, 128, 2, 4, 2>'    # the kernel class 0 of dsl_prof_* brackets (largest share of the step)
 
 
-def model_cfg(dsl=False):
+def model_cfg(dsl=False, rla=False):
     head = dict(type='FCOSHead', num_classes=80, in_channels=256, stacked_convs=4, feat_channels=256,
                 strides=[8, 16, 32, 64, 128], norm_on_bbox=True, centerness_on_reg=True, dcn_on_last_conv=False,
                 center_sampling=True, conv_bias=True,
@@ -34,9 +35,12 @@ def model_cfg(dsl=False):
                 loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0))
     if dsl:
         head.update(loss_weight=3.0, soft_weight=1.0, soft_warm_up=5000)
+    backbone = dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                    norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='caffe')
+    if rla:     # the backbone the reference's DSL config names (configs/fcos_semi/RLA_*.py:3-13)
+        backbone = dict(type='RLA_ResNet', layers=[3, 4, 6, 3], frozen_stages=1, norm_eval=True, style='pytorch')
     return dict(type='FCOS',
-                backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
-                              norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='caffe'),
+                backbone=backbone,
                 neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
                           add_extra_convs='on_output', num_outs=5, relu_before_extra_convs=True),
                 bbox_head=head,
@@ -105,8 +109,15 @@ def dsl_iteration_timing(steps=10, warm=4):
     from dsl_amd.registry import build_detector
     from dsl_amd.runner import EMAOWNHook, OptimizerHook, SemiEpochBasedRunner, UnlabelPredHook
     out = {}
-    for refresh in (False, True):
-        student, teacher = build_detector(model_cfg(dsl=True)).cuda(), build_detector(model_cfg(dsl=True)).cuda()
+    for refresh, rla in ((False, False), (True, False), (True, True)):
+        student, teacher = build_detector(model_cfg(dsl=True, rla=rla)).cuda(), build_detector(model_cfg(dsl=True, rla=rla)).cuda()
+        if rla:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')       # no pretrained checkpoint on the box: random init (reference style)
+                student.init_weights()
+                teacher.init_weights()
+                teacher.load_state_dict(student.state_dict())
         student.lazy_log = True
         student.eager_backward = True
         opt = FlatSGD(student, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
@@ -139,13 +150,16 @@ def dsl_iteration_timing(steps=10, warm=4):
         runner.run([loader], max_epochs=1)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - marks['t0']) / steps
-        out['ms_per_iter_with_teacher_refresh' if refresh else 'ms_per_iter'] = round(dt * 1e3, 3)
+        if os.environ.get('DSL_BENCH_VERBOSE'):
+            print(f'dsl_iteration refresh={refresh} rla={rla}: {dt * 1e3:.3f} ms', file=sys.stderr, flush=True)
+        out[('ms_per_iter_with_teacher_refresh_rla_backbone' if rla else 'ms_per_iter_with_teacher_refresh') if refresh else 'ms_per_iter'] = round(dt * 1e3, 3)
         del student, teacher, runner, opt, loader
         torch.cuda.empty_cache()
     out['imgs_per_iter'] = 2
     out['note'] = ('N = 3 student step (labeled + unlabeled + half-scale copy, ignore boxes, loss_weight 3, sisoft, clip 35) + SGD + '
                    'EMA teacher every iteration; refresh = teacher sweep + fuse of the next unlabeled image every iteration; '
-                   'images resident in HBM, the loader reads the refreshed labels back from the GPU before each batch')
+                   'images resident in HBM, the loader reads the refreshed labels back from the GPU before each batch; *_rla_backbone: the '
+                   'same iteration with the RLA_ResNet backbone of configs/fcos_semi/RLA_*.py')
     return out
 
 

@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.hpp"
 
 static thread_local char g_err[512] = "";
@@ -77,6 +80,16 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
     const dsl_op& o = ops[k];
     int rc = 0;
     hipStream_t st = main_st;
+    static const bool dbg_pre = [] { const char* e = getenv("DSL_DEBUG_SYNC"); return e && e[0] == '1'; }();
+    if (dbg_pre) {
+      fprintf(stderr, "[dsl_run_ops] start op %d/%d kind %d stream %d desc %p p0 %p p1 %p\n", k, n_ops, o.kind, o.i[6], o.desc, o.p[0], o.p[1]);
+      if (o.kind == DSL_OP_CONV && o.desc) {
+        const dsl_conv_desc* d = (const dsl_conv_desc*)o.desc;
+        fprintf(stderr, "    conv src %p wgt %p dst %p addend %p mask %p n %d nseg %d g %dx%d s %dx%d cs %d cd %d lds %d ldd %d lda %d k %d stride %d mode %d flags %d ws %p\n",
+                d->src, d->wgt, d->dst, d->addend, d->mask, d->n, d->nseg, d->gh[0], d->gw[0], d->sh[0], d->sw[0], d->cs, d->cd, d->lds, d->ldd, d->lda, d->kh, d->stride, d->mode, d->flags, d->workspace);
+      }
+      fflush(stderr);
+    }
     if (o.kind == DSL_OP_RECORD || o.kind == DSL_OP_WAIT) {
       side_init(dev);
       DSL_CHECK(o.i[1] >= 0 && o.i[1] < 16, "dsl_run_ops: event slot %d out of range", o.i[1]);
@@ -129,6 +142,13 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
         return -1;
     }
     if (rc != 0) return rc;
+    // DSL_DEBUG_SYNC=1: drain the device after every op and name it - a faulting launch is then the last line on stderr
+    static const bool dbg_sync = [] { const char* e = getenv("DSL_DEBUG_SYNC"); return e && e[0] == '1'; }();
+    if (dbg_sync) {
+      const hipError_t e = hipDeviceSynchronize();
+      fprintf(stderr, "[dsl_run_ops] op %d/%d kind %d stream %d -> %s\n", k, n_ops, o.kind, o.i[6], hipGetErrorString(e));
+      fflush(stderr);
+    }
   }
   return 0;
 }

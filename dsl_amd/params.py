@@ -162,6 +162,12 @@ class ParamStore:
             if not tr:
                 for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
                     foff = add(self.frozen_regions, foff, f'{n}.{leaf}', (RLA_C,))
+        # the conv kernels fetch whole weight tiles: cout_pad rows, of which a 32-channel conv stores 32.  Inside the buffers
+        # the extra rows are whatever follows (their outputs are dropped); the LAST conv of the frozen buffer would read past
+        # the allocation (RLA's recurrent_convs.0 did, when the next page happened to be unmapped): zero rows behind it
+        over = max([(s.cout_pad - s.cout) * s.k * s.k * s.cin_store for s in self.convs.values() if not s.trainable] + [0])
+        if over:
+            foff = add(self.frozen_regions, foff, '_tail_pad', (over,))
         for tower in ('cls_convs', 'reg_convs'):
             for i in range(4):
                 toff = add(self.train_regions, toff, f'bbox_head.{tower}.{i}.gn.weight', (256,))

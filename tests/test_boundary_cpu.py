@@ -155,3 +155,18 @@ def test_adaptive_thresholds_and_split():
     gt, gl, ig = split_pseudo_labels(np.array([[0, 0, 10, 10], [5, 5, 30, 30], [1, 1, 1.5, 9]]), [0, 0, 1], [0.5, 0.2, 0.9],
                                      {0: 0.32})
     assert gt.shape == (1, 4) and gl.tolist() == [0] and ig.shape == (1, 4)
+
+
+@pytest.mark.parametrize('backbone', ['resnet', 'rla'])
+def test_weight_tiles_never_read_past_the_buffers(backbone):
+    """The conv kernels fetch cout_pad rows of a weight; a 32-channel conv stores 32.  Every such tile must end inside the
+    flat buffer it lives in (the frozen buffer of RLA_ResNet once ended 61 KB behind recurrent_convs.0: a GPU memory fault
+    whenever the following page was unmapped)."""
+    from dsl_amd.params import ParamStore
+    st = ParamStore(80, 'cpu', backbone=backbone)
+    for s in st.convs.values():
+        regions, total = (st.train_regions, st.n_train) if s.trainable else (st.frozen_regions, st.n_frozen)
+        off = regions[s.name + '.weight'][0]
+        assert off + s.cout_pad * s.k * s.k * s.cin_store <= total, s.name
+    for name, rows in (('head.cls_w', 128), ('head.regctr_w', 64)):
+        assert st.train_regions[name][0] + rows * 9 * 256 <= st.n_train
