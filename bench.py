@@ -235,6 +235,15 @@ def main():
     if not args.no_prof:
         if world > 1:
             dist.barrier()
+        # (2a) phases only: two event pairs per step around the head's forward / backward data path (both towers on two streams);
+        # the step is otherwise unperturbed
+        NC = L.PROF_CLASSES
+        L.lib.dsl_prof_reset()
+        L.lib.dsl_prof_enable(3)
+        timed(args.steps)
+        L.lib.dsl_prof_enable(0)
+        ph = [(C.c_int64 * NC)(), (C.c_double * NC)(), (C.c_double * NC)(), (C.c_double * NC)()]
+        L.lib.dsl_prof_read2(*ph)
         L.lib.dsl_prof_reset()
         L.lib.dsl_prof_enable(1 if args.prof_light else 2)
         dt_prof, _ = timed(args.steps)
@@ -259,7 +268,6 @@ def main():
             traffic = tj['kernels'][hit[0]]['hbm_bytes_per_launch']
             traffic_src = 'profiles/traffic.json: ' + tj.get('source', '')
     if not args.no_prof:
-        NC = 4
         launches = (C.c_int64 * NC)()
         ms = (C.c_double * NC)()
         fl = (C.c_double * NC)()
@@ -291,6 +299,13 @@ def main():
                         mfma_tflops=round(ach, 1), mfma_frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         hbm_gbs_algorithmic=round(gbs, 1), hbm_frac_algorithmic=round(gbs / PEAK_HBM_GBS, 4),
                         head_tile_256x192=cls(1), other_conv_kernels=cls(2), wgrad_kernels=cls(3),
+                        head_phases={name: dict(tflops=round(ph[2][c] / (ph[1][c] * 1e-3) / 1e12, 1), ms_per_step=round(ph[1][c] / args.steps, 3),
+                                                frac_of_mfma_peak=round(ph[2][c] / (ph[1][c] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                gflop_per_step=round(ph[2][c] / args.steps / 1e9, 1))
+                                     for name, c in (('forward', 4), ('backward_data_path', 5)) if ph[0][c]} or None,
+                        head_phases_note='wall time on the caller\'s stream of the head (16 tower convs + 2 predictors + 8 GroupNorm '
+                                         'passes per direction, the two towers side by side on two streams), uninstrumented kernels; '
+                                         'the per-launch figures above stretch when two launches overlap',
                         whole_step_frac=round(value / world * GFLOP_PER_IMAGE_STEP / 1e3 / PEAK_BF16_TFLOPS, 4))
     cpu = extra = None
     if rank == 0 and world == 1 and not args.no_dsl:

@@ -28,6 +28,8 @@ OP_RLA = 17
 OP_PACK_DGRAD = 18
 OP_WGRAD_MULTI = 19
 OP_PAIR = 20
+OP_PROF = 21
+PROF_CLASSES = 8
 MAX_MULTI = 16
 SLOT_TAIL, SLOT_PREFIX = 13, 14     # pipelined frozen prefix: 'previous backward's data-gradient chain done', 'prefix of this step done'
 SLOT_PACKS = 15      # named event: the data-gradient weight packs of the last optimizer step are complete

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -69,6 +70,8 @@ hipEvent_t next_event(int dev) {
 }
 }  // namespace
 
+void dsl_prof_phase(int cls, int end, long long flops_bits, long long bytes_bits, hipStream_t st);
+
 extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
   DSL_CHECK(ops || n_ops == 0, "dsl_run_ops: null op list");
   hipStream_t main_st = (hipStream_t)stream;
@@ -89,6 +92,10 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
                 d->src, d->wgt, d->dst, d->addend, d->mask, d->n, d->nseg, d->gh[0], d->gw[0], d->sh[0], d->sw[0], d->cs, d->cd, d->lds, d->ldd, d->lda, d->kh, d->stride, d->mode, d->flags, d->workspace);
       }
       fflush(stderr);
+    }
+    if (o.kind == DSL_OP_PROF) {
+      dsl_prof_phase(o.i[0], o.i[1], o.l[0], o.l[1], pick(o.i[6]));
+      continue;
     }
     if (o.kind == DSL_OP_RECORD || o.kind == DSL_OP_WAIT) {
       side_init(dev);
@@ -179,6 +186,7 @@ bool dsl_prof_active() { return g_prof_on != 0; }
 int dsl_prof_begin(int cls, double flops, hipStream_t st, double bytes) {
   if (!g_prof_on || g_nrec >= kMaxRec) return -1;
   if (g_prof_on == 1 && cls != 0) return -1;
+  if ((g_prof_on == 3) != (cls >= 4)) return -1;          // phases only in mode 3, kernels only in modes 1, 2
   if (!g_rec) g_rec = (ProfRec*)calloc(kMaxRec, sizeof(ProfRec));
   if (g_nrec >= g_nevents) {
     hipEventCreate(&g_rec[g_nrec].a);
@@ -194,6 +202,20 @@ int dsl_prof_begin(int cls, double flops, hipStream_t st, double bytes) {
 
 void dsl_prof_end(int id, hipStream_t st) {
   if (id >= 0) hipEventRecord(g_rec[id].b, st);
+}
+
+void dsl_prof_phase(int cls, int end, long long flops_bits, long long bytes_bits, hipStream_t st) {
+  static int open_id[DSL_PROF_CLASSES];
+  if (g_prof_on != 3 || cls < 4 || cls >= DSL_PROF_CLASSES) return;
+  if (!end) {
+    double fl, by;
+    memcpy(&fl, &flops_bits, 8);
+    memcpy(&by, &bytes_bits, 8);
+    open_id[cls] = dsl_prof_begin(cls, fl, st, by);
+  } else {
+    dsl_prof_end(open_id[cls], st);
+    open_id[cls] = -1;
+  }
 }
 
 extern "C" int dsl_prof_enable(int on) {

@@ -73,6 +73,12 @@ class OpList:
     def pair(self, d):
         self._add(L.OP_PAIR, d)
 
+    def prof(self, cls, end, flops=0.0, nbytes=0.0):
+        """Phase mark on the caller's stream (a no-op unless dsl_prof_enable(3))."""
+        import struct
+        bits = lambda x: struct.unpack('<q', struct.pack('<d', float(x)))[0]
+        self._add(L.OP_PROF, i=(cls, int(end)), l=(bits(flops), bits(nbytes)))
+
     def join(self, side=1):
         self._add(L.OP_JOIN, i=(side,))
 
@@ -152,6 +158,7 @@ class Plan:
             self.assign_ops.assign(self.lossplan.desc)
             if self._fside:             # the regression tower's side stream: joined here, not at the end of the forward list,
                 self.loss_ops.join(self._fside)       # so that target upload + assignment run while it finishes
+            self.loss_ops.prof(4, 1)
             self.loss_ops.loss(self.lossplan.desc)
             self._build_backward()
 
@@ -247,6 +254,10 @@ class Plan:
         # the two towers are independent chains: the regression tower (+ its predictor) runs on the side stream
         self.conv_ws_side = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
         FSIDE = 2 if os.environ.get('DSL_SIDE', '1') != '0' else 0      # side stream 1 carries the weight gradients (and may be CU-masked)
+        # phase marks for bench.py: 8 tower convs + 2 predictors over all M locations, 8 GroupNorm+ReLU passes
+        self._head_flops = 2.0 * self.M * (8 * 256 * 2304 + (80 + 5) * 2304)
+        self._head_bytes = self.M * 256 * 2.0 * (8 * 2 + 8 * 3 + 2) + self.M * (80 + 8) * 4.0
+        f.prof(4, 0, self._head_flops, self._head_bytes)
         if FSIDE:
             f.fork(FSIDE)
         for tower in ('cls_convs', 'reg_convs'):
@@ -281,6 +292,8 @@ class Plan:
         self._fside = FSIDE
         if FSIDE and not self.training:
             f.join(FSIDE)               # (training plans: the loss op list starts with this join, see __init__)
+        if not self.training:
+            f.prof(4, 1)
 
     def _fwd_resnet(self, x, h, w):
         st, N, f = self.store, self.N, self.fwd
@@ -462,6 +475,7 @@ class Plan:
         # ================= segment 0: head + FPN =================
         ol = OpList()
         ol.wait(L.SLOT_PACKS, stream=0)      # the data-gradient weight packs of the last optimizer step (ParamStore.repack_dgrad)
+        ol.prof(5, 0, self._head_flops, self.M * 256 * 2.0 * (8 * 2 + 8 * 5 + 2))       # same FLOPs as the forward phase: data gradients
         tower_group = []
         # the two towers' backward chains are independent until both have added into g_feats: the regression tower's runs on
         # side stream 2 (as in the forward pass); its last data gradient - the one that adds into g_feats - waits for the
@@ -531,6 +545,7 @@ class Plan:
                                                                        cd=256, k=3, stride=1, pad=1, addend=g_feats)), side=BT)
                 if BT:
                     ol.join(BT)
+                ol.prof(5, 1)
         self._flush_wgrads(ol, side=SIDE)          # towers + predictors: ready now, the FPN's follow below
         # ---- FPN backward ----
         cv = st.convs

@@ -386,7 +386,9 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_WAIT = 16,   /* stream i[0] waits for named event slot i[1] (no-op if the slot was never recorded) */
        DSL_OP_PACK_DGRAD = 18, /* dsl_pack_dgrad_batched(p[0] = item table, i[0] = items, i[1] = blocks) */
        DSL_OP_WGRAD_MULTI = 19, /* dsl_conv2d_wgrad_multi(p[0] = table_host, p[1] = table_dev) */
-       DSL_OP_PAIR = 20 };      /* desc = dsl_pair_desc -> dsl_conv1x1_pair */
+       DSL_OP_PAIR = 20,       /* desc = dsl_pair_desc -> dsl_conv1x1_pair */
+       DSL_OP_PROF = 21 };     /* phase mark (dsl_prof_enable(3) only, else a no-op): i[0] = class >= 4, i[1] = 0 begin | 1 end, l[0] / l[1] =
+                                * algorithmic FLOPs / bytes of the phase as IEEE doubles' bit patterns (begin only) */
 typedef struct dsl_op {
   int32_t kind;
   int32_t i[7];            /* small integer arguments for the simple ops; i[6] = s > 0: run this op on the library's
@@ -409,9 +411,13 @@ int dsl_stream_wait_slot(int slot, void* stream);
  * weight-gradient kernels.
  * dsl_prof_enable(1) brackets only class 0 (cheap enough for a timed region), dsl_prof_enable(2) every class
  * (event pairs on concurrently running streams perturb the overlap).
+ * dsl_prof_enable(3) brackets no kernel, only PHASES: DSL_OP_PROF ops in an op list mark begin / end of a stretch of the caller's
+ * stream (classes 4.. : 4 = head forward - both towers, their GroupNorms and predictors, on two streams -, 5 = head backward data
+ * path); with two streams running the same kernel class side by side, a launch's own duration says little about the rate the
+ * phase achieves.
  * dsl_prof_read synchronises the events and returns per class: launches, total ms, algorithmic FLOPs.
  * ---------------------------------------------------------------------------------------- */
-#define DSL_PROF_CLASSES 4
+#define DSL_PROF_CLASSES 8
 int dsl_prof_enable(int on);
 int dsl_prof_reset(void);
 int dsl_prof_read(int64_t* launches, double* ms, double* flops);
