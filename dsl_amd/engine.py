@@ -39,6 +39,16 @@ class OpList:
             self.keep.append(desc)
         self.items.append(o)
         self.arr = None
+        # has the caller's stream queued work since side stream 1 last waited for it?  (a FORK costs the recording stream
+        # ~6 us, tools/microbench/sync_cost.hip: consecutive side launches with nothing new on the caller's stream share one)
+        if kind == L.OP_FORK and (o.i[0] or 1) == 1 and o.i[1] == 0:
+            self._fork1_fresh = True
+        elif o.i[6] == 0 and kind not in (L.OP_FORK, L.OP_JOIN, L.OP_RECORD, L.OP_WAIT, L.OP_PROF):
+            self._fork1_fresh = False
+
+    def _fork1(self):
+        if not getattr(self, '_fork1_fresh', False):
+            self._add(L.OP_FORK)
 
     def conv(self, d, side=False):
         """side: False/0 = the caller's stream, True/1..3 = that side stream of the library."""
@@ -52,7 +62,7 @@ class OpList:
         """side=True: on the library's side stream, after a FORK (the weight gradient only depends on tensors
         that are complete at this point and are never overwritten within the step)."""
         if side:
-            self._add(L.OP_FORK)
+            self._fork1()
             self._add(L.OP_WGRAD, d, i=(0, 0, 0, 0, 0, 0, 1))
         else:
             self._add(L.OP_WGRAD, d)
@@ -60,13 +70,13 @@ class OpList:
     def wgrad_group(self, arr, side=False):
         """arr: ops.wgrad_group(...) array (same-geometry convolutions, one launch)."""
         if side:
-            self._add(L.OP_FORK)
+            self._fork1()
         self._add(L.OP_WGRAD_GROUP, arr, i=(len(arr), 0, 0, 0, 0, 0, 1 if side else 0))
 
     def wgrad_multi(self, plan, side=False):
         """plan: ops.WgradMulti (sub-launches of one tile configuration as one grid)."""
         if side:
-            self._add(L.OP_FORK)
+            self._fork1()
         self._add(L.OP_WGRAD_MULTI, i=(0, 0, 0, 0, 0, 0, 1 if side else 0), p=(plan.host.data_ptr(), plan.dev.data_ptr()))
         self.keep.append(plan)
 
@@ -539,11 +549,18 @@ class Plan:
             else:
                 cl, rl = self.tower['cls_convs'][0], self.tower['reg_convs'][0]
                 ol.conv(self._dgrad(cl['spec'].name, g_pre['cls_convs'], g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))
-                if BT:      # the regression tower's last data gradient adds into g_feats: after the classification tower's
+                # the regression tower's last data gradient adds into g_feats, after the classification tower's: on the caller's
+                # stream behind a JOIN of the tower stream (a FORK -> side launch -> JOIN round trip with nothing else to do on the
+                # caller's stream costs ~27 us, tools/microbench/sync_cost.hip)
+                RFM = os.environ.get('DSL_REG_FINAL_MAIN', '1') != '0'
+                if BT and not RFM:
                     ol.fork(BT)
-                ol.conv((side_ws if BT else (lambda c: c))(self._dgrad(rl['spec'].name, g_pre['reg_convs'], g_feats, N, ls, ls, cs=256,
-                                                                       cd=256, k=3, stride=1, pad=1, addend=g_feats)), side=BT)
-                if BT:
+                if BT and RFM:
+                    ol.join(BT)
+                sd_f = BT if (BT and not RFM) else 0
+                ol.conv((side_ws if sd_f else (lambda c: c))(self._dgrad(rl['spec'].name, g_pre['reg_convs'], g_feats, N, ls, ls, cs=256,
+                                                                         cd=256, k=3, stride=1, pad=1, addend=g_feats)), side=sd_f)
+                if BT and not RFM:
                     ol.join(BT)
                 ol.prof(5, 1)
         self._flush_wgrads(ol, side=SIDE)          # towers + predictors: ready now, the FPN's follow below
@@ -686,7 +703,8 @@ class Plan:
             if GROUP and (li > 1 or GROUP_LAST):
                 # last segment: the caller's stream has nothing left to do, it takes part of the groups itself
                 on_main = os.environ.get('DSL_TAIL_MAIN', '2') if li == 1 else '0'     # measured: tools/exp_r2w.sh
-                for gi, grp_descs in ((3, g3), (2, g2), (1, g1)):
+                order = sorted(((3, g3), (2, g2), (1, g1)), key=lambda t: str(t[0]) in on_main)     # side-stream groups first: one FORK
+                for gi, grp_descs in order:
                     mine = str(gi) in on_main
                     self._wgrad_group(ol, grp_descs, side=SIDE and not mine, ws_name='wg_ws_main' if mine else 'wg_ws')
             self._flush_wgrads(ol, side=SIDE)
