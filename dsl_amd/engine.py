@@ -641,7 +641,8 @@ class Plan:
         # ================= backbone: layer4, layer3, layer2 =================
         if rla:
             from . import engine_rla
-            self._multi_on = False             # the recurrent path's side-stream ops depend on the order of the weight gradients
+            # (the recurrent path's BatchNorm post-pass runs on the weight-gradient stream behind the stage's flush)
+            self._multi_on = SIDE and os.environ.get('DSL_WGRAD_MULTI', '1') != '0' and os.environ.get('DSL_RLA_MULTI', '1') != '0'
             engine_rla.build_backward(self, buckets, SIDE)
             return
         blocks_by_stage = {li: [b for b in self.blocks if b['stage'] == li] for li in (1, 2, 3)}

@@ -127,6 +127,12 @@ def build_backward(plan, buckets, SIDE):
         co, rc = cv[f'backbone.conv_outs.{s_}'], cv[f'backbone.recurrent_convs.{s_}']
         gx = plan.g_stage[s_]                 # gradient w.r.t. the stage's last output (FPN lateral + next stage), unmasked for s < 3
         g3, g2, g1, g_co, g_rc, post = [], [], [], [], [], []
+
+        def emit(d):            # a single weight gradient: with the stage's multi launch (Plan._flush_wgrads) or on its own
+            if plan._multi_on and SIDE:
+                plan._wg_pending.append([d])
+            else:
+                ol.wgrad(d, side=SIDE)
         for blk in reversed(blks):
             p, b = blk['prefix'], blk['b']
             c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
@@ -168,19 +174,19 @@ def build_backward(plan, buckets, SIDE):
             if stride == 1:
                 g2.append(d2)                # the stage's stride-1 3x3 convolutions share a geometry
             else:
-                ol.wgrad(d2, side=SIDE)
+                emit(d2)
             ol.conv(plan._dgrad(c2.name, gA2, gA1, N, [(oh, ow)], [(h, w)], cs=planes, cd=planes, k=3, stride=stride, pad=1,
                                 mask=blk['a1'], mask_last=True))
             d1 = plan._wgrad(ol, c1, gA1, blk['xh'], N, [(h, w)], [(h, w)], emit=False, raw=True, db_ptr=bn_g(c1.bn, 'bias'))
             if b > 0:
                 g1.append(d1)
             else:
-                ol.wgrad(d1, side=SIDE)
+                emit(d1)
             # ---- gradient w.r.t. the block input (x part) and w.r.t. the incoming h
             if b == 0:
                 ds = cv[p + '.downsample.0']
-                ol.wgrad(plan._wgrad(ol, ds, g_pre, blk['xh'], N, [(oh, ow)], [(h, w)], emit=False, raw=True,
-                                     db_ptr=bn_g(ds.bn, 'bias'), ldx=ldx), side=SIDE)
+                emit(plan._wgrad(ol, ds, g_pre, blk['xh'], N, [(oh, ow)], [(h, w)], emit=False, raw=True,
+                                 db_ptr=bn_g(ds.bn, 'bias'), ldx=ldx))
             if not first:
                 wT = st.wT_ptr(c1.name)                      # CRSK rows = input channels of conv1: [x (cx) | h (32) | zeros]
                 if b > 0:
@@ -215,6 +221,7 @@ def build_backward(plan, buckets, SIDE):
         for grp in (g_co, g_rc):
             if grp:
                 plan._wgrad_group(ol, grp, side=SIDE, ws_name='wg_ws_shared')
+        plan._flush_wgrads(ol, side=SIDE)         # everything deferred above: one multi launch per tile configuration
         items, rows = [], 0
         for spec in post_specs:
             it = L.BnPostItem()
