@@ -47,7 +47,7 @@ __global__ void det_key_kernel(const DetK p) {
 
 // Block-wide radix select over non-negative floats (bit pattern is monotonic): returns the bit pattern
 // of the k-th largest value and how many elements equal to it belong to the top k.  11 + 11 + 10 bits.
-__device__ void radix_select_block(const float* keys, int P, int k, unsigned* hist /*2048*/, unsigned* s_tmp /*2*/,
+__device__ void radix_select_block(const float* keys, int P, int k, unsigned* hist /*2048 + 1024, blockDim 1024*/, unsigned* s_tmp /*2*/,
                                    unsigned& prefix_out, unsigned& need_out) {
   unsigned prefix = 0, mask = 0, need = (unsigned)k;
   const int shifts[3] = {21, 10, 0};
@@ -59,18 +59,30 @@ __device__ void radix_select_block(const float* keys, int P, int k, unsigned* hi
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
       const float f = keys[i];
       const unsigned u = f > 0.f ? __float_as_uint(f) : 0u;
-      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & (nb - 1)], 1u);
+      // (non-positive keys all fall into bin 0 of the first pass: hundreds of thousands of atomics on one LDS word for the
+      // dense pair scores; the callers only select among positive keys, so they are left out of the histogram)
+      if (u != 0u && (u & mask) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & (nb - 1)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned acc = 0;
-      int b = nb - 1;
-      for (; b > 0; --b) {
-        if (acc + hist[b] >= need) break;
-        acc += hist[b];
+    // the bin that holds the need-th largest key: suffix sums over the bins, in parallel (a single thread walking 2 048 LDS
+    // words took ~80 us per pass).  Thread t owns bins 2t, 2t+1; Hillis-Steele suffix scan over the 1 024 pair sums in place.
+    {
+      unsigned* pair = hist + 2048;                  // caller provides 2048 + 1024 words
+      const int t = threadIdx.x;
+      const unsigned h0 = hist[2 * t], h1 = hist[2 * t + 1];
+      pair[t] = h0 + h1;
+      __syncthreads();
+      for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned add = t + d < 1024 ? pair[t + d] : 0u;
+        __syncthreads();
+        pair[t] += add;
+        __syncthreads();
       }
-      s_tmp[0] = prefix | ((unsigned)b << shifts[pass]);
-      s_tmp[1] = need - acc;
+      // pair[t] = number of keys in bins >= 2t; above bin 2t+1: pair[t] - h0 - h1
+      const unsigned above1 = pair[t] - h0 - h1, above0 = above1 + h1;       // keys in bins > 2t+1, > 2t
+      if (above1 < need && above1 + h1 >= need) { s_tmp[0] = prefix | ((unsigned)(2 * t + 1) << shifts[pass]); s_tmp[1] = need - above1; }
+      if (above0 < need && above0 + h0 >= need) { s_tmp[0] = prefix | ((unsigned)(2 * t) << shifts[pass]); s_tmp[1] = need - above0; }
+      if (t == 0 && pair[0] < need) { s_tmp[0] = prefix; s_tmp[1] = need - (pair[0] - h0); }     // fewer keys than asked for: bin 0 (as before)
     }
     __syncthreads();
     prefix = s_tmp[0];
@@ -91,14 +103,24 @@ template <typename Take, typename Tie, typename Emit>
 __device__ void ordered_compact(int P, unsigned need, unsigned* s_wave /* >= 2 * 16 + 2 */, Take take, Tie tie, Emit emit,
                                 unsigned* total_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int seg = ((P + nw - 1) / nw + 63) / 64 * 64;          // elements per wave, multiple of 64
+  constexpr int U = 4;                                           // 64-element groups per iteration: U predicate loads in flight
+  const int seg = ((P + nw - 1) / nw + 64 * U - 1) / (64 * U) * (64 * U);      // elements per wave, multiple of 64 * U
   const int lo = wave * seg, hi = min(P, lo + seg);
   unsigned ntake = 0, ntie = 0;
-  for (int i0 = lo; i0 < hi; i0 += 64) {
-    const int i = i0 + lane;
-    const bool in = i < hi;
-    ntake += __popcll(__ballot(in && take(i)));
-    ntie += __popcll(__ballot(in && tie(i)));
+  for (int i0 = lo; i0 < hi; i0 += 64 * U) {
+    bool tk[U], ti[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 64 + lane;
+      const bool in = i < hi;
+      tk[u] = in && take(i);
+      ti[u] = in && tie(i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ntake += __popcll(__ballot(tk[u]));
+      ntie += __popcll(__ballot(ti[u]));
+    }
   }
   if (lane == 0) {
     s_wave[wave] = ntake;
@@ -115,17 +137,26 @@ __device__ void ordered_compact(int P, unsigned need, unsigned* s_wave /* >= 2 *
   }
   unsigned out = out_before, tr = tie_before;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int i0 = lo; i0 < hi; i0 += 64) {
-    const int i = i0 + lane;
-    const bool in = i < hi;
-    const bool tk = in && take(i), ti = in && tie(i);
-    const unsigned long long bt = __ballot(ti);
-    const unsigned my_tr = tr + (unsigned)__popcll(bt & lt);
-    const bool sel = tk || (ti && my_tr < need);
-    const unsigned long long bs = __ballot(sel);
-    if (sel) emit(i, out + (unsigned)__popcll(bs & lt));
-    out += (unsigned)__popcll(bs);
-    tr += (unsigned)__popcll(bt);
+  for (int i0 = lo; i0 < hi; i0 += 64 * U) {
+    bool tk[U], ti[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 64 + lane;
+      const bool in = i < hi;
+      tk[u] = in && take(i);
+      ti[u] = in && tie(i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                   // index order: group u before group u + 1
+      const int i = i0 + u * 64 + lane;
+      const unsigned long long bt = __ballot(ti[u]);
+      const unsigned my_tr = tr + (unsigned)__popcll(bt & lt);
+      const bool sel = tk[u] || (ti[u] && my_tr < need);
+      const unsigned long long bs = __ballot(sel);
+      if (sel) emit(i, out + (unsigned)__popcll(bs & lt));
+      out += (unsigned)__popcll(bs);
+      tr += (unsigned)__popcll(bt);
+    }
   }
   if (total_out) {
     __syncthreads();
@@ -136,7 +167,7 @@ __device__ void ordered_compact(int P, unsigned need, unsigned* s_wave /* >= 2 *
 
 // one block per (image, level): indices of the top nms_pre keys (all of them when the level is smaller), in index order
 __global__ __launch_bounds__(1024) void det_select_kernel(const DetK p) {
-  __shared__ unsigned hist[2048];
+  __shared__ unsigned hist[2048 + 1024];
   __shared__ unsigned s_tmp[2], s_wave[34], s_total;
   const int lvl = blockIdx.x, img = blockIdx.y;
   const int P = p.h[lvl] * p.w[lvl];
@@ -182,7 +213,7 @@ __global__ void det_pairscore_kernel(const DetK p) {
 // slots are assigned in (level, slot, class) index order (ordered_compact), so the score-tie order of the NMS below -
 // and with it the whole result - is reproducible
 __global__ __launch_bounds__(1024) void det_compact_kernel(const DetK p) {
-  __shared__ unsigned hist[2048];
+  __shared__ unsigned hist[2048 + 1024];
   __shared__ unsigned s_tmp[2], s_valid, s_wave[34], s_total;
   const int img = blockIdx.x;
   const int per_img = p.nlvl * p.nms_pre * p.num_classes;
