@@ -109,7 +109,7 @@ def dsl_iteration_timing(steps=10, warm=4):
     from dsl_amd.registry import build_detector
     from dsl_amd.runner import EMAOWNHook, OptimizerHook, SemiEpochBasedRunner, UnlabelPredHook
     out = {}
-    for refresh, rla in ((False, False), (True, False), (True, True)):
+    for refresh, rla, asyn in ((False, False, False), (True, False, False), (True, False, True), (True, True, False)):
         student, teacher = build_detector(model_cfg(dsl=True, rla=rla)).cuda(), build_detector(model_cfg(dsl=True, rla=rla)).cuda()
         if rla:
             import warnings
@@ -129,7 +129,9 @@ def dsl_iteration_timing(steps=10, warm=4):
         runner.register_hook(OptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)), priority=40)
         runner.register_hook(EMAOWNHook(interval=1, mode='iteration', ratio=0.99, start_point=0), priority=45)
         if refresh:
-            hook = UnlabelPredHook(dict(infer_score_thre=0.1, use_ema=True, start_point=0, eval_config=dict(iou=[0.6]),
+            if asyn:       # the loader asks one batch ahead (the reference: `preload` batches): the sweep runs beside the next step
+                loader.unlabeled.prefetch_depth = 1
+            hook = UnlabelPredHook(dict(infer_score_thre=0.1, use_ema=True, start_point=0, eval_config=dict(iou=[0.6]), async_sweep=asyn,
                                         eval_checkpoint_config=dict(interval=1, mode='iteration')), None, 'Det',
                                    interval_mode='iteration', interval=1, bank=bank)
             hook.iter_fuse_flag = True          # steady state: the initial full sweep is not part of an iteration's cost
@@ -151,14 +153,16 @@ def dsl_iteration_timing(steps=10, warm=4):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - marks['t0']) / steps
         if os.environ.get('DSL_BENCH_VERBOSE'):
-            print(f'dsl_iteration refresh={refresh} rla={rla}: {dt * 1e3:.3f} ms', file=sys.stderr, flush=True)
-        out[('ms_per_iter_with_teacher_refresh_rla_backbone' if rla else 'ms_per_iter_with_teacher_refresh') if refresh else 'ms_per_iter'] = round(dt * 1e3, 3)
+            print(f'dsl_iteration refresh={refresh} rla={rla} async={asyn}: {dt * 1e3:.3f} ms', file=sys.stderr, flush=True)
+        key = 'ms_per_iter' if not refresh else ('ms_per_iter_with_teacher_refresh' + ('_async' if asyn else '') + ('_rla_backbone' if rla else ''))
+        out[key] = round(dt * 1e3, 3)
         del student, teacher, runner, opt, loader
         torch.cuda.empty_cache()
     out['imgs_per_iter'] = 2
     out['note'] = ('N = 3 student step (labeled + unlabeled + half-scale copy, ignore boxes, loss_weight 3, sisoft, clip 35) + SGD + '
                    'EMA teacher every iteration; refresh = teacher sweep + fuse of the next unlabeled image every iteration; '
-                   'images resident in HBM, the loader reads the refreshed labels back from the GPU before each batch; *_rla_backbone: the '
+                   'images resident in HBM, the loader reads the refreshed labels back from the GPU before each batch; *_async: the loader asks one '
+                   'batch ahead and the sweep runs on its own stream beside the next student step; *_rla_backbone: the '
                    'same iteration with the RLA_ResNet backbone of configs/fcos_semi/RLA_*.py')
     return out
 

@@ -138,8 +138,11 @@ def conv_out(h, k, s, p):
 class Plan:
     """All buffers + op lists for one (N, H, W) and one ParamStore."""
 
-    def __init__(self, store, N, H, W, training=True, max_gt=1024):
-        assert store.device.type == 'cuda'
+    def __init__(self, store, N, H, W, training=True, max_gt=1024, single_stream=False):
+        """single_stream: every op on the caller's stream (a teacher sweep that runs beside the student's step must not queue
+        work on the library's side streams, which the student's op lists use in order)."""
+        assert store.device.type == 'cuda' and not (training and single_stream)
+        self.single_stream = single_stream
         if store.dirty:
             store.refresh()
         self.store, self.N, self.H, self.W, self.training = store, N, H, W, training
@@ -210,7 +213,7 @@ class Plan:
         self.stage_out, self.stage_ld = [], []      # per stage: (tensor / pointer of the output's first channel, (h, w)), row stride
         # independent branches of the forward graph (a stage's downsample conv next to conv1 -> conv2; P5 -> P6 -> P7 next to
         # the P4 / P3 path) run on side stream 3: their kernels are too small to fill the chip alone
-        self.BR = 3 if (os.environ.get('DSL_SIDE', '1') != '0' and os.environ.get('DSL_FWD_BRANCH', '1') != '0') else 0
+        self.BR = 3 if (os.environ.get('DSL_SIDE', '1') != '0' and os.environ.get('DSL_FWD_BRANCH', '1') != '0' and not self.single_stream) else 0
         self.conv_ws_br = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
         if st.backbone == 'rla':
             from . import engine_rla
@@ -263,7 +266,7 @@ class Plan:
         self.tower = {}
         # the two towers are independent chains: the regression tower (+ its predictor) runs on the side stream
         self.conv_ws_side = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
-        FSIDE = 2 if os.environ.get('DSL_SIDE', '1') != '0' else 0      # side stream 1 carries the weight gradients (and may be CU-masked)
+        FSIDE = 2 if (os.environ.get('DSL_SIDE', '1') != '0' and not self.single_stream) else 0      # side stream 1 carries the weight gradients (and may be CU-masked)
         # phase marks for bench.py: 8 tower convs + 2 predictors over all M locations, 8 GroupNorm+ReLU passes
         self._head_flops = 2.0 * self.M * (8 * 256 * 2304 + (80 + 5) * 2304)
         self._head_bytes = self.M * 256 * 2.0 * (8 * 2 + 8 * 3 + 2) + self.M * (80 + 8) * 4.0
@@ -791,16 +794,16 @@ class Engine:
     def __init__(self):
         self.plans = {}         # insertion-ordered: least recently used first
 
-    def plan(self, store, N, H, W, training=True):
+    def plan(self, store, N, H, W, training=True, single_stream=False):
         if store.dirty:
             store.refresh()           # in place where the packs exist; a re-allocation bumps store.generation
-        key = (id(store), getattr(store, 'generation', 0), N, H, W, training)
+        key = (id(store), getattr(store, 'generation', 0), single_stream, N, H, W, training)
         p = self.plans.pop(key, None)
         if p is None:
             stale = [k for k in self.plans if k[0] == id(store) and k[1] != key[1]]
             while stale or len(self.plans) >= self.MAX_PLANS:
                 torch.cuda.synchronize()                    # the evicted plan's buffers may still be in use on a stream
                 self.plans.pop(stale.pop() if stale else next(iter(self.plans)))
-            p = Plan(store, N, H, W, training)
+            p = Plan(store, N, H, W, training, single_stream=single_stream)
         self.plans[key] = p
         return p

@@ -209,6 +209,10 @@ class SemiEpochBasedRunner:
         s, t = self._det(self.model).store, self._det(self.ema_model).store
         if t.device != s.device:
             t.to(s.device)
+        ev = getattr(self, '_sweep_event', None)          # an asynchronous teacher sweep (UnlabelPredHook.async_sweep) still reads the
+        if ev is not None:                                # teacher's weights: the update waits for it
+            torch.cuda.current_stream().wait_event(ev)
+            self._sweep_event = None
         L.check(L.lib.dsl_ema_lerp(L.ptr(t.train), L.ptr(s.train), s.n_train, float(keep_rate), L.stream_ptr()), 'dsl_ema_lerp')
         if t.train16 is None or t.dirty:
             t.refresh()
@@ -467,6 +471,8 @@ class UnlabelPredHook(Hook):
         self.export_dir = k.get('anno_root_path') if export else k.get('export_dir')
         self.iter_fuse_flag = False
         self.n_refreshed = 0
+        self.async_sweep = bool(k.get('async_sweep', False))        # not a key of the reference: see refresh()
+        self._sweep_stream = None
         self._buf = {}
 
     # -- schedule (:439-469) ------------------------------------------------------------------------------
@@ -542,7 +548,25 @@ class UnlabelPredHook(Hook):
         det = runner._det(runner.model)
         teacher = runner._det(runner.ema_model) if (self.use_ema and runner.ema_flag and runner.ema_model is not None) else det
         thr = self.infer_score_thre if thr is None else thr
-        dets, labels, count = detect_device(det, imgs, img_metas, rescale=True, store=teacher.store)
+        if self.async_sweep and self.iter_fuse_flag:
+            # the sweep of an image the loader hands out `prefetch_depth` batches from now runs on its own stream beside the
+            # student's next step (the reference refreshes `preload` iterations ahead of the loader for the same reason); it
+            # starts behind everything queued so far (the teacher's EMA update included), the next EMA update waits for it
+            if self._sweep_stream is None:
+                self._sweep_stream = torch.cuda.Stream()
+            ss = self._sweep_stream
+            ss.wait_stream(torch.cuda.current_stream())
+            imgs.record_stream(ss)
+            with torch.cuda.stream(ss):
+                out = self._sweep(runner, det, teacher, imgs, img_metas, names, thr, single_stream=True)
+                runner._sweep_event = torch.cuda.Event()
+                runner._sweep_event.record()
+            return out
+        return self._sweep(runner, det, teacher, imgs, img_metas, names, thr)
+
+    def _sweep(self, runner, det, teacher, imgs, img_metas, names, thr, single_stream=False):
+        from .sweep import detect_device
+        dets, labels, count = detect_device(det, imgs, img_metas, rescale=True, store=teacher.store, single_stream=single_stream)
         n, maxk = dets.shape[0], dets.shape[1]
         # fresh output buffers per call: the bank reads them lazily (a ring would need the events below to bound reuse)
         ob = torch.empty(n, maxk, 4, device=dets.device)

@@ -56,12 +56,12 @@ class DetectPlan:
         L.check(L.lib.dsl_fcos_detect(C.byref(self.desc), L.stream_ptr()), 'dsl_fcos_detect')
 
 
-def detect_device(det, img, img_metas, rescale=False, store=None):
+def detect_device(det, img, img_metas, rescale=False, store=None, single_stream=False):
     """Forward + post-processing; returns (dets [N,100,5], labels [N,100], count [N]) on the GPU."""
     eng = det._get_engine()
     store = store or det.store
     N, _, H, W = img.shape
-    plan = eng.plan(store, N, H, W, training=False)
+    plan = eng.plan(store, N, H, W, training=False, single_stream=single_stream)
     plan.bind_image(img)
     plan.fwd.run()
     dp = getattr(plan, 'detplan', None)
