@@ -209,3 +209,42 @@ def test_self_scheduled_refresh_feeds_the_next_batch():
     assert len(later) == 3 and sum(len(b[1]) + len(b[2]) for b in later) > 0
     for name, gt, ig in later:
         assert name in bank
+
+
+def test_async_sweep_gives_the_same_labels():
+    """UnlabelPredHook(async_sweep=True): the teacher sweep on its own stream (single-stream eval plan, EMA update waiting for
+    it) refreshes with exactly the teacher weights the synchronous hook uses - same pseudo labels, same student weights."""
+    from dsl_amd.data import SyntheticSemiLoader
+    from dsl_amd.optim import FlatSGD
+    from dsl_amd.pseudo import PseudoLabelBank
+    from dsl_amd.runner import EMAOWNHook, OptimizerHook, SemiEpochBasedRunner, UnlabelPredHook
+    outs = []
+    for asyn in (False, True):
+        head = dict(loss_weight=3.0, soft_weight=1.0, soft_warm_up=0)
+        student, teacher = build(**head), build(**head)
+        for m in (student, teacher):
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            sd['bbox_head.conv_cls.bias'].fill_(0.0)
+            m.load_state_dict(sd)
+        opt = FlatSGD(student, lr=0.001, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
+                      grad_clip=dict(max_norm=35, norm_type=2))
+        bank = PseudoLabelBank(num_classes=80, thres='adathres.json')
+        loader = SyntheticSemiLoader(bank, n_labeled=3, n_unlabeled=4, iters_per_epoch=6, H=128, W=192, W_img=190, img_std=30.0)
+        loader.unlabeled.prefetch_depth = 1
+        runner = SemiEpochBasedRunner(student, optimizer=opt, max_epochs=1, ema_model=teacher, scale_invariant=True)
+        runner.register_hook(OptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)), priority=30)
+        runner.register_hook(EMAOWNHook(interval=1, mode='iteration', ratio=0.9, start_point=0), priority=40)
+        hook = UnlabelPredHook(dict(infer_score_thre=0.1, use_ema=True, start_point=0, eval_config=dict(iou=[0.6]), async_sweep=asyn,
+                                    eval_checkpoint_config=dict(interval=1, mode='iteration')), None, 'Det',
+                               interval_mode='iteration', interval=1, bank=bank)
+        runner.register_hook(hook, priority=50)
+        runner.run([loader], max_epochs=1)
+        torch.cuda.synchronize()
+        labels = {n: [np.asarray(x).copy() for x in bank.ann_info(n, img_wh=(190, 128))] for n in sorted(bank.names())}
+        outs.append((labels, student.store.train.clone().cpu(), hook.n_refreshed))
+    (la, wa, na), (lb, wb, nb) = outs
+    assert na == nb and na > 4 and la.keys() == lb.keys()
+    for n in la:
+        for x, y in zip(la[n], lb[n]):
+            assert np.array_equal(x, y), n
+    assert torch.equal(wa, wb)
