@@ -198,12 +198,15 @@ def main():
     model = build_detector(model_cfg()).cuda()      # random init, reference style, same seed on every rank
     model.lazy_log = True
     model.eager_backward = True      # backward kernels are queued right behind the loss kernel (see FCOS.eager_backward)
-    model.pipeline_prefix = os.environ.get('DSL_BENCH_PIPE', '1') != '0'     # inputs are resident: see FCOS.pipeline_prefix
+    if os.environ.get('DSL_BENCH_PIPE', '1') == '0':      # A/B knob; the product default (on) is what the headline uses
+        model.pipeline_prefix = False
     if world > 1:
         model = HipDistributedDataParallel(model)
     det = model.module if world > 1 else model
     opt = FlatSGD(det, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
     batch = synth_batch(rank, args.imgs_per_gpu)
+    from dsl_amd.data import mark_ready
+    mark_ready(batch['img'])         # inputs are resident in HBM before the timed region: the producer's event is this one
 
     def step():
         out = model.train_step(batch, opt)

@@ -12,7 +12,9 @@
 // stores into NHWC.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "common.hpp"
 
@@ -973,6 +975,10 @@ struct WgK {
   int dbmask;
   float* dbws;
   float* dbv[DSL_MAX_GROUP];
+  // v3 (wgrad_pipe): per-pixel gather descriptors of this geometry (PixDesc, one per dY pixel, built once per geometry)
+  const void* pixtab;
+  unsigned pixtab_bytes;
+  unsigned ybytes;          // extent of one member's dY in bytes (= totpx * cy * 2): rows past it read as zeros
 };
 
 template <int ROWBYTES>
@@ -1511,6 +1517,375 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_kernel(const WgK p)
   wgrad_glds_body<BCO, BCI, WCO, WCI, KS, NST>(p, (int)blockIdx.x, smem);
 }
 
+// ================================================================================================
+// v3 weight gradient ("wgrad_pipe"): the same tiles, operands and outputs as wgrad_glds_body, re-scheduled so that nothing
+// but the MFMA stream is on the critical path (v2 measured on the head shape, tools/ablate_wgrad.py: DMA-only 50 us +
+// MFMA-only 53 us = 87 us together - the two did not overlap at all: every wave issued its whole DMA burst, then decoded
+// the next stage's pixels, then waited for its first fragments with an idle matrix pipe):
+//   * no per-stage pixel decode: a per-geometry table of 8-byte pixel descriptors {source pixel of tap (0,0), row pitch,
+//     per-axis tap validity bits} (PixDesc, built once per geometry on the host, cached by the library) is itself DMA'd
+//     into a small LDS ring a few stages ahead; a gather row's offset is then 5 VALU instructions, a dY row's offset is a
+//     running counter (dY rows are contiguous in the pixel index); padding, ragged tails and dead stages are the buffer
+//     out-of-range rule (zeros land in LDS), so every stage issues the same number of DMA instructions;
+//   * KS-pixel stages in an NST-deep ring (32-pixel stages: 4 x 32 KB for the 256x256 tile), stage s+NST-1 is fetched while
+//     stage s feeds the MFMAs: its DMA instructions are issued ONE AT A TIME between the MFMAs of the stage (a burst blocks
+//     the wave on issue for ~1000 cycles with an empty matrix pipe);
+//   * fragment reads of k-step kk+1 are in flight during the MFMAs of step kk, the next stage's first fragments are issued
+//     right behind the stage's single barrier, in front of its last MFMA block: the barrier sits inside the MFMA stream.
+// vmcnt bookkeeping (P DMA instructions per wave per stage, returned in order): at the barrier that ends stage s, stage
+// s+1 must have landed; it was issued during stage s-NST+2, so (NST-3) whole stages plus the Pa pieces of stage s issued so
+// far may stay in flight.  Everything issued during stage s-NST+2 or earlier has then landed, including the descriptors
+// fetched then: descriptors of stage t are fetched during stage t-(2*NST-2) and read (into registers) right behind the
+// barrier that ends stage t-NST, for the gather DMAs issued during stage t-NST+1.
+// ================================================================================================
+struct PixDesc {
+  int32_t base;        // source pixel index of tap (0,0) of this output pixel (may be "virtual": outside the image)
+  uint32_t info;       // (source row pitch in pixels) << 16 | x-tap validity bits << 8 | y-tap validity bits
+};
+
+__device__ __forceinline__ u32x2 lds_read_b64_asm(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void pin2(u32x2& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin1(unsigned& a) { asm volatile("" : "+v"(a)); }
+
+template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
+__device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, unsigned char* smem) {
+  constexpr int NW = WCO * WCI;
+  constexpr int YB = BCO * 2, XB = BCI * 2;
+  constexpr int TILE_Y = KS * YB, TILE_X = KS * XB, STAGE = TILE_Y + TILE_X;
+  constexpr int NY = TILE_Y / 1024, NX = TILE_X / 1024;
+  constexpr int LY = NY / NW, LX = NX / NW;
+  constexpr int NDSC = KS * 8 / 256;                            // 256-byte descriptor DMAs per stage
+  constexpr int P = NDSC + LY + LX;                              // DMA instructions per wave per stage
+  constexpr int CT = BCO / WCO / 32, IT = BCI / WCI / 32, NM = CT * IT;
+  constexpr int KK = KS / 16;
+  constexpr int DR = 16;                                         // descriptor ring depth (stages)
+  constexpr int DESC_BASE = NST * STAGE;
+  constexpr int DLEAD = 2 * NST - 2;                             // descriptors run this many stages ahead of the stage computed
+  static_assert(NY % NW == 0 && NX % NW == 0 && LY >= 1 && LX >= 1, "tile / wave mismatch");
+  static_assert(YB >= 256 && XB >= 256, "64-byte-chunk swizzle needs >= 4 chunks per row");
+  static_assert(KK == 2 || KK == 4, "stage depth");
+  static_assert(NST >= 3 && DLEAD < DR && NDSC >= 1, "ring depths");
+  static_assert((NST - 1) * P + DLEAD * NDSC <= 63, "vmcnt range");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_co = wave / WCI, wave_ci = wave % WCI;
+  const int tiles_per_member = p.gx * p.gy;
+  const int tiles_per_split_wg = tiles_per_member * p.group;
+  const int xcd = bid & 7, jj = bid >> 3;
+  const int witem = xcd * p.chunk + jj;
+  if (jj >= p.chunk || witem >= tiles_per_split_wg * p.splits) return;
+  const int sp = witem / tiles_per_split_wg;
+  const int rem_sp = witem - sp * tiles_per_split_wg;
+  const int member = rem_sp / tiles_per_member;
+  const int rem_wg = rem_sp - member * tiles_per_member;
+  const uint16_t* dy_p = p.dyv[0];
+  const uint16_t* x_p = p.xv[0];
+  float* db_p = p.dbv[0];
+#pragma unroll
+  for (int g = 1; g < DSL_MAX_GROUP; ++g) {
+    dy_p = member == g ? p.dyv[g] : dy_p;
+    x_p = member == g ? p.xv[g] : x_p;
+    db_p = member == g ? p.dbv[g] : db_p;
+  }
+  const int co0 = (rem_wg % p.gx) * BCO;
+  const int colt = rem_wg / p.gx;
+  const bool do_db = colt == 0 && ((p.dbmask >> member) & 1);
+  constexpr int DB_PAIRS = BCO / 2, DB_RG = 64 * NW / DB_PAIRS, DB_ROWS = KS / DB_RG;
+  static_assert(DB_ROWS >= 1 && DB_ROWS <= 8 && DB_RG * DB_PAIRS == 64 * NW, "bias-gradient thread mapping");
+  const int db_cp = tid % DB_PAIRS, db_rg = tid / DB_PAIRS;
+  float db_lo = 0.f, db_hi = 0.f;
+  const int ctiles = p.cs / BCI;
+  const int tap = colt / ctiles;
+  const int ci0 = (colt - tap * ctiles) * BCI;
+  const int tr = tap / p.kw, ts = tap - tr * p.kw;
+  const int kt0 = sp * p.tiles_per_split;
+  const int kt1 = min(kt0 + p.tiles_per_split, p.ktiles);
+  if (kt0 >= kt1) return;      // (cannot happen with the host's split factors; a workgroup without stages has nothing to add)
+
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)dy_p, 0, (int)p.ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x_p, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)p.pixtab, 0, (int)p.pixtab_bytes, 0x00020000);
+
+  // per DMA instruction this lane's (row, source channel) inside the tile (as in wgrad_glds_body)
+  unsigned yv[LY];             // running byte offset of this lane's dY element (row of the stage being fetched)
+  unsigned xcol[LX], xdaddr[LX];
+#pragma unroll
+  for (int i = 0; i < LY; ++i) {
+    const int off = (wave + NW * i) * 1024 + lane * 16;
+    const int row = off / YB, inrow = off % YB;
+    const int ch = (((inrow >> 6) ^ (row & 3)) << 5) + ((inrow & 63) >> 1);
+    yv[i] = co0 + ch < p.cy ? (unsigned)(((kt0 * KS + row) * p.cy + co0 + ch) * 2) : 0x80000000u;
+  }
+#pragma unroll
+  for (int i = 0; i < LX; ++i) {
+    const int off = (wave + NW * i) * 1024 + lane * 16;
+    const int row = off / XB, inrow = off % XB;
+    const int ch = (((inrow >> 6) ^ (row & 3)) << 5) + ((inrow & 63) >> 1);
+    xcol[i] = (unsigned)(ci0 + ch) * 2u;
+    xdaddr[i] = (unsigned)(DESC_BASE + row * 8);
+  }
+  const unsigned y_step = (unsigned)(KS * p.cy * 2);
+  const unsigned ldx2 = (unsigned)(p.ldx * 2);
+  const unsigned sel = (1u << tr) | (0x100u << ts);
+
+  f32x16 acc[CT][IT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < IT; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+  const int g16 = lane >> 4, l16 = lane & 15;
+  const int iblk = (g16 & 1) * 16, kblk = (g16 >> 1) * 8;
+  const int krow_l = kblk + (l16 >> 2);
+  const int ccol_l = iblk + 4 * (l16 & 3);
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  unsigned a_off[CT], b_off[IT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int col = wave_co * (32 * CT) + ct * 32 + ccol_l;
+    a_off[ct] = krow_l * YB + ((((col * 2) >> 6) ^ (krow_l & 3)) << 6) + ((col * 2) & 63);
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int col = wave_ci * (32 * IT) + it * 32 + ccol_l;
+    b_off[it] = TILE_Y + krow_l * XB + ((((col * 2) >> 6) ^ (krow_l & 3)) << 6) + ((col * 2) & 63);
+  }
+  Frag fa[2][CT], fb[2][IT];
+  auto issue = [&](unsigned stage_addr, int kk, int f) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const unsigned ad = stage_addr + a_off[ct] + kk * 16 * YB;
+      fa[f][ct].lo = lds_tr_read_b64(ad);
+      fa[f][ct].hi = lds_tr_read_b64(ad + 4 * YB);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const unsigned ad = stage_addr + b_off[it] + kk * 16 * XB;
+      fb[f][it].lo = lds_tr_read_b64(ad);
+      fb[f][it].hi = lds_tr_read_b64(ad + 4 * XB);
+    }
+  };
+  auto wait_lds = [&](int f) {       // every outstanding LDS read of this wave has landed; the registers it wrote change HERE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { pin2(fa[f][ct].lo); pin2(fa[f][ct].hi); }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { pin2(fb[f][it].lo); pin2(fb[f][it].hi); }
+  };
+
+  // ---- DMA pieces of one stage: [0, NDSC) descriptors of stage t_desc, [NDSC, NDSC+LY) dY rows, then the gather rows of
+  // stage t_data into ring slot ld_slot
+  int t_data = kt0, t_desc = kt0, ld_slot = 0;
+  unsigned xv[LX];                   // gather offsets of stage t_data (from its descriptors)
+  u32x2 dreg[LX];
+  auto piece = [&](int k) {          // k is a constant after unrolling
+    if (k < NDSC) {
+      const unsigned v = (unsigned)(t_desc * (KS * 8) + k * 256 + lane * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lptr_t)(smem + DESC_BASE + (t_desc & (DR - 1)) * (KS * 8) + k * 256), 4, v, 0, 0, 0);
+    } else if (k < NDSC + LY) {
+      const int i = k - NDSC;
+      const unsigned v = t_data < kt1 ? yv[i] : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lptr_t)(smem + ld_slot * STAGE + (wave + NW * i) * 1024), 16, v, 0, 0, 0);
+    } else {
+      const int i = k - NDSC - LY;
+      const unsigned v = t_data < kt1 ? xv[i] : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(smem + ld_slot * STAGE + TILE_Y + (wave + NW * i) * 1024), 16, v, 0, 0, 0);
+    }
+  };
+  auto desc_read = [&]() {           // descriptors of stage t_data (landed and barrier-published) -> registers
+#pragma unroll
+    for (int i = 0; i < LX; ++i) dreg[i] = lds_read_b64_asm(lds_base + xdaddr[i] + (unsigned)((t_data & (DR - 1)) * (KS * 8)));
+  };
+  auto desc_use = [&]() {            // ... -> this lane's gather offsets (after the wait that covers desc_read)
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+      pin2(dreg[i]);
+      const unsigned info = dreg[i][1];
+      const unsigned px = (unsigned)((int)dreg[i][0] + tr * (int)(info >> 16) + ts);
+      xv[i] = (info & sel) == sel ? px * ldx2 + xcol[i] : 0x80000000u;
+    }
+  };
+  auto advance = [&]() {             // the stage's pieces are all issued
+    ++t_data;
+    ++t_desc;
+    ld_slot = (ld_slot + 1 == NST) ? 0 : ld_slot + 1;
+#pragma unroll
+    for (int i = 0; i < LY; ++i) yv[i] += y_step;
+  };
+  // one k-step's MFMAs with the DMA pieces [lo, hi) of the stage issued between them: one piece behind every second MFMA
+  // (everything here is pinned in source order)
+  auto block = [&](int f, int lo, int hi) {
+    bf16x8 a[CT], b[IT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      union { struct { u32x2 l, h; } s; bf16x8 v; } u;
+      u.s.l = fa[f][ct].lo;
+      u.s.h = fa[f][ct].hi;
+      a[ct] = u.v;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      union { struct { u32x2 l, h; } s; bf16x8 v; } u;
+      u.s.l = fb[f][it].lo;
+      u.s.h = fb[f][it].hi;
+      b[it] = u.v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int k = lo;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      acc[m / IT][m % IT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m / IT], b[m % IT], acc[m / IT][m % IT], 0, 0, 0);
+      if ((m & 1) == 0 && m + 1 < NM && k < hi) {
+        __builtin_amdgcn_sched_barrier(0);
+        piece(k);
+        ++k;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+      if (k + j < hi) piece(k + j);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr int PA = (KK - 1) * P / KK;          // pieces issued before the stage's barrier (k-steps 0 .. KK-2)
+
+  // ---- prologue: the descriptors of the first NST-1 stages, then NST-1 whole stages (each with the descriptor pieces of a
+  // later stage, so that every stage - prologue or not - is exactly P DMA instructions: the waits below count in stages)
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j) {
+#pragma unroll
+    for (int k = 0; k < NDSC; ++k) piece(k);
+    ++t_desc;
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j) {
+    desc_read();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    desc_use();
+#pragma unroll
+    for (int k = 0; k < P; ++k) piece(k);
+    advance();
+  }
+  // steady state from here: stage s fetches the descriptors of stage s + DLEAD (t_desc) and the data of stage s + NST - 1 (t_data)
+  wait_vmcnt<(NST - 2) * P>();                   // stage kt0 landed, and the descriptors fetched with it (stage kt0 + NST - 1's)
+  __builtin_amdgcn_s_barrier();
+  desc_read();
+  issue(lds_base, 0, 0);
+
+  unsigned dbr[8];
+  int slot_c = 0;
+  for (int s = kt0; s < kt1; ++s) {
+    const unsigned st = lds_base + slot_c * STAGE;
+    const int nslot = (slot_c + 1 == NST) ? 0 : slot_c + 1;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const int f = kk & 1;
+      wait_lds(f);
+      if (kk == 0) desc_use();
+      if (kk == 1 && do_db) {          // the dY column sums of this stage (issued in k-step 0)
+#pragma unroll
+        for (int j = 0; j < DB_ROWS; ++j) {
+          pin1(dbr[j]);
+          db_lo += __uint_as_float(dbr[j] << 16);
+          db_hi += __uint_as_float(dbr[j] & 0xffff0000u);
+        }
+      }
+      if (kk < KK - 1) {
+        issue(st, kk + 1, f ^ 1);
+        if (kk == 0 && do_db) {
+#pragma unroll
+          for (int j = 0; j < DB_ROWS; ++j) {
+            const int row = db_rg * DB_ROWS + j;
+            dbr[j] = lds_read_b32_asm(st + row * YB + ((((db_cp * 4) >> 6) ^ (row & 3)) << 6) + ((db_cp * 4) & 63));
+          }
+        }
+      } else {
+        wait_vmcnt<(NST - 3) * P + PA>();      // stage s+1 landed (and every older DMA of this wave)
+        __builtin_amdgcn_s_barrier();          // ... for every wave; every wave is done reading stage s
+        issue(lds_base + nslot * STAGE, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // pieces of this k-step (compile-time bounds)
+      block(f, kk * P / KK, (kk + 1) * P / KK);
+      if (kk == KK - 1) {
+        advance();
+        desc_read();                           // descriptors of the stage fetched next (published by the barrier above)
+      }
+    }
+    slot_c = nslot;
+  }
+  wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  if (do_db) {               // fold the row groups in a fixed order; one value per column leaves the workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    red[(db_rg * DB_PAIRS + db_cp) * 2] = db_lo;
+    red[(db_rg * DB_PAIRS + db_cp) * 2 + 1] = db_hi;
+    __syncthreads();
+    if (tid < BCO) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < DB_RG; ++r) sacc += red[(r * DB_PAIRS + (tid >> 1)) * 2 + (tid & 1)];
+      const int co = co0 + tid;
+      if (p.direct) {
+        if (co < p.cd) db_p[co] = sacc;
+      } else {
+        p.dbws[((long long)sp * p.group + member) * p.cyp + co] = sacc;
+      }
+    }
+  }
+  const int frow = lane & 31, fhalf = lane >> 5;
+  if (p.direct) {
+    float* dw_p = p.dwv[0];
+    const float* sc_p = p.scalev[0];
+#pragma unroll
+    for (int g = 1; g < DSL_MAX_GROUP; ++g) {
+      dw_p = member == g ? p.dwv[g] : dw_p;
+      sc_p = member == g ? p.scalev[g] : sc_p;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const long long col = (long long)tap * p.cs + ci0 + wave_ci * (32 * IT) + it * 32 + frow;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int co = co0 + wave_co * (32 * CT) + ct * 32 + (j & 3) + 8 * (j >> 2) + 4 * fhalf;
+          if (co < p.cd) dw_p[(long long)co * p.krow + col] = sc_p ? acc[ct][it][j] * sc_p[co] : acc[ct][it][j];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const long long col = (long long)tap * p.cs + ci0 + wave_ci * (32 * IT) + it * 32 + frow;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int co = co0 + wave_co * (32 * CT) + ct * 32 + (j & 3) + 8 * (j >> 2) + 4 * fhalf;
+        p.ws[(((long long)sp * p.group + member) * p.cyp + co) * p.krow + col] = acc[ct][it][j];
+      }
+    }
+}
+
+template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
+__global__ __launch_bounds__(64 * WCO * WCI) void wgrad_pipe_kernel(const WgK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  wgrad_pipe_body<BCO, BCI, WCO, WCI, KS, NST>(p, (int)blockIdx.x, smem);
+}
+
 // Several weight-gradient launches of ONE tile configuration as one grid (dsl_conv2d_wgrad_multi): sub-launch s owns the
 // blocks [wg_end[s-1], wg_end[s]) (multiples of 8, so a block's XCD is the same as in a launch of its own); its WgK comes
 // from a table in device memory, read once with scalar loads before the K loop.  The host orders the sub-launches by
@@ -1532,6 +1907,20 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_glds_multi_kernel(const 
   }
   const WgK p = tab[sub];
   wgrad_glds_body<BCO, BCI, WCO, WCI, KS, NST>(p, (int)blockIdx.x - start, smem);
+}
+
+template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
+__global__ __launch_bounds__(64 * WCO * WCI) void wgrad_pipe_multi_kernel(const WgMultiHdr h, const WgK* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int sub = 0, start = 0;
+#pragma unroll
+  for (int s = 1; s < kMaxMulti; ++s) {
+    const bool in = s < h.nsub && (int)blockIdx.x >= h.wg_end[s - 1];
+    sub = in ? s : sub;
+    start = in ? h.wg_end[s - 1] : start;
+  }
+  const WgK p = tab[sub];
+  wgrad_pipe_body<BCO, BCI, WCO, WCI, KS, NST>(p, (int)blockIdx.x - start, smem);
 }
 
 // the reduce passes of a multi launch: entry e (one member of one sub-launch with more than one split) owns the blocks
@@ -1926,6 +2315,93 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   return 0;
 }
 
+// ---- v3 weight gradient: per-geometry pixel descriptor tables (PixDesc), built on the host once per geometry and kept
+// in device memory for the life of the process (a few hundred KB per geometry; a training run has ~20 geometries)
+namespace {
+constexpr int kWgV3KS = 32, kWgV3DR = 16;
+struct PixTabEntry {
+  int dev, nseg, n, stride, pad, kh, kw;
+  int gh[DSL_MAX_SEG], gw[DSL_MAX_SEG], sh[DSL_MAX_SEG], sw[DSL_MAX_SEG];
+  void* ptr;
+  unsigned bytes;
+};
+std::mutex g_pixtab_mu;
+std::vector<PixTabEntry> g_pixtabs;
+
+bool wgrad_v3_enabled() {
+  static const bool on = [] { const char* e = getenv("DSL_WGRAD_V3"); return !e || atoi(e) != 0; }();
+  return on;
+}
+// ring depth of the v3 kernel per tile configuration (1: 256x256 -> 4 x 32 KB; 2, 3: 24 KB stages)
+int wgrad_v3_nst(int cfg) { return cfg == 1 ? 4 : 5; }
+bool wgrad_v3_ok(const dsl_wgrad_desc* d, int cfg) {
+  if (!wgrad_v3_enabled() || cfg < 1 || cfg > 3 || d->kh > 8 || d->kw > 8) return false;
+  long long px = 0, xo = 0;
+  for (int s = 0; s < d->nseg; ++s) {
+    px += (long long)d->n * d->gh[s] * d->gw[s];
+    xo += (long long)d->n * d->sh[s] * d->sw[s];
+    if (d->sw[s] >= 65536) return false;
+  }
+  const long long ldx = d->ldx > 0 ? d->ldx : d->cs;
+  return px * d->cy * 2 < 0x7fff0000LL && xo * ldx * 2 < 0x7fff0000LL && px < (1 << 20);
+}
+// returns the device table of d's geometry (building it on first use), or nullptr on failure
+const void* wgrad_pixtab(const dsl_wgrad_desc* d, unsigned* bytes) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_pixtab_mu);
+  for (const PixTabEntry& e : g_pixtabs) {
+    if (e.dev != dev || e.nseg != d->nseg || e.n != d->n || e.stride != d->stride || e.pad != d->pad || e.kh != d->kh || e.kw != d->kw) continue;
+    bool same = true;
+    for (int s = 0; s < d->nseg; ++s)
+      same = same && e.gh[s] == d->gh[s] && e.gw[s] == d->gw[s] && e.sh[s] == d->sh[s] && e.sw[s] == d->sw[s];
+    if (same) { *bytes = e.bytes; return e.ptr; }
+  }
+  long long px = 0;
+  for (int s = 0; s < d->nseg; ++s) px += (long long)d->n * d->gh[s] * d->gw[s];
+  std::vector<PixDesc> h((size_t)px);
+  long long xoff = 0;
+  size_t i = 0;
+  for (int s = 0; s < d->nseg; ++s) {
+    const int sh = d->sh[s], sw = d->sw[s];
+    for (int img = 0; img < d->n; ++img)
+      for (int y = 0; y < d->gh[s]; ++y)
+        for (int x = 0; x < d->gw[s]; ++x) {
+          const int y0 = y * d->stride - d->pad, x0 = x * d->stride - d->pad;
+          unsigned ym = 0, xm = 0;
+          for (int r = 0; r < d->kh; ++r) if ((unsigned)(y0 + r) < (unsigned)sh) ym |= 1u << r;
+          for (int c = 0; c < d->kw; ++c) if ((unsigned)(x0 + c) < (unsigned)sw) xm |= 1u << c;
+          h[i].base = (int32_t)(xoff + ((long long)img * sh + y0) * sw + x0);
+          h[i].info = ((unsigned)sw << 16) | (xm << 8) | ym;
+          ++i;
+        }
+    xoff += (long long)d->n * sh * sw;
+  }
+  PixTabEntry e;
+  memset(&e, 0, sizeof(e));
+  e.dev = dev; e.nseg = d->nseg; e.n = d->n; e.stride = d->stride; e.pad = d->pad; e.kh = d->kh; e.kw = d->kw;
+  for (int s = 0; s < d->nseg; ++s) { e.gh[s] = d->gh[s]; e.gw[s] = d->gw[s]; e.sh[s] = d->sh[s]; e.sw[s] = d->sw[s]; }
+  e.bytes = (unsigned)(px * sizeof(PixDesc));
+  if (hipMalloc(&e.ptr, e.bytes + 256) != hipSuccess) return nullptr;
+  if (hipMemcpy(e.ptr, h.data(), e.bytes, hipMemcpyHostToDevice) != hipSuccess) { hipFree(e.ptr); return nullptr; }
+  g_pixtabs.push_back(e);
+  *bytes = e.bytes;
+  return e.ptr;
+}
+int wgrad_v3_fill(const dsl_wgrad_desc* d, WgK& k, long long px) {
+  unsigned tb = 0;
+  k.pixtab = wgrad_pixtab(d, &tb);
+  DSL_CHECK(k.pixtab != nullptr, "dsl_conv2d_wgrad: could not build the pixel descriptor table");
+  k.pixtab_bytes = tb;
+  k.ybytes = (unsigned)(px * d->cy * 2);
+  return 0;
+}
+size_t wgrad_v3_lds(int cfg) {
+  const int bcos[5] = {0, 256, 256, 128, 128}, bcis[5] = {0, 256, 128, 256, 128};
+  return (size_t)wgrad_v3_nst(cfg) * kWgV3KS * 2 * (bcos[cfg] + bcis[cfg]) + (size_t)kWgV3DR * kWgV3KS * 8;
+}
+}  // namespace
+
 // wgrad tile configurations: 0 = v1 (BCO 128|64 x 128, register staged), 1 = 256x256, 2 = 256co x 128ci,
 // 3 = 128co x 256ci, 4 = 128x128 (v2)
 static int wgrad_pick(const dsl_wgrad_desc* d) {
@@ -2093,27 +2569,38 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
 #endif
     k.chunk = (k.gx * k.gy * count * splits + 7) / 8;
     dim3 grid2(k.chunk * 8);
+    const bool v3 = wgrad_v3_ok(d, cfg);
     const int kss[5] = {64, 64, 64, 64, 64}, nsts[5] = {2, 2, 3, 3, 2};
-    const int ks = kss[cfg];
+    const int ks = v3 ? kWgV3KS : kss[cfg];
     // the stage length of this tile configuration defines the K-tile unit
     k.ktiles = (px + ks - 1) / ks;
     k.tiles_per_split = (k.ktiles + splits - 1) / splits;
-    const size_t lds2 = (size_t)nsts[cfg] * ks * 2 * (bco + bci);
-#define LAUNCHW(A, B, C_, D, KS_, S_)                                                                                 \
+    if (v3)
+      if (int rc = wgrad_v3_fill(d, k, px)) return rc;
+    const size_t lds2 = v3 ? wgrad_v3_lds(cfg) : (size_t)nsts[cfg] * ks * 2 * (bco + bci);
+#define LAUNCHW(KERNEL, A, B, C_, D, KS_, S_)                                                                         \
   do {                                                                                                               \
     static bool a_ = false;                                                                                          \
     if (!a_) {                                                                                                       \
-      hipFuncSetAttribute((const void*)wgrad_glds_kernel<A, B, C_, D, KS_, S_>,                                      \
+      hipFuncSetAttribute((const void*)KERNEL<A, B, C_, D, KS_, S_>,                                                 \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                    \
       a_ = true;                                                                                                     \
     }                                                                                                                \
-    hipLaunchKernelGGL((wgrad_glds_kernel<A, B, C_, D, KS_, S_>), grid2, dim3(64 * C_ * D), lds2, st, k);             \
+    hipLaunchKernelGGL((KERNEL<A, B, C_, D, KS_, S_>), grid2, dim3(64 * C_ * D), lds2, st, k);                        \
   } while (0)
-    switch (cfg) {
-      case 1: LAUNCHW(256, 256, 2, 4, 64, 2); break;
-      case 2: LAUNCHW(256, 128, 4, 2, 64, 3); break;
-      case 3: LAUNCHW(128, 256, 2, 4, 64, 3); break;
-      default: LAUNCHW(128, 128, 2, 2, 64, 2); break;
+    if (v3) {
+      switch (cfg) {
+        case 1: LAUNCHW(wgrad_pipe_kernel, 256, 256, 2, 4, 32, 4); break;
+        case 2: LAUNCHW(wgrad_pipe_kernel, 256, 128, 4, 2, 32, 5); break;
+        default: LAUNCHW(wgrad_pipe_kernel, 128, 256, 2, 4, 32, 5); break;
+      }
+    } else {
+      switch (cfg) {
+        case 1: LAUNCHW(wgrad_glds_kernel, 256, 256, 2, 4, 64, 2); break;
+        case 2: LAUNCHW(wgrad_glds_kernel, 256, 128, 4, 2, 64, 3); break;
+        case 3: LAUNCHW(wgrad_glds_kernel, 128, 256, 2, 4, 64, 3); break;
+        default: LAUNCHW(wgrad_glds_kernel, 128, 128, 2, 2, 64, 2); break;
+      }
     }
 #undef LAUNCHW
   } else if (bco == 128) {
@@ -2172,7 +2659,7 @@ struct ColsumItem { const void* x; float* out; long long rows; int c, ld, clear;
 struct WgMultiTable {
   int magic, cfg, nsub, total_blocks;
   WgMultiHdr hdr;
-  int n_red, red_blocks, n_colsum, pad_;
+  int n_red, red_blocks, n_colsum, v3;
   double flops, bytes;
   ColsumItem colsum[kMaxColsum];
   WgK k[kMaxMulti];
@@ -2180,7 +2667,7 @@ struct WgMultiTable {
 };
 constexpr int kMultiMagic = 0x574d5431;
 
-int wgrad_fill_k(const dsl_wgrad_desc* descs, int count, int splits, int cfg, WgK& k, long long* px_out, long long* xo_out) {
+int wgrad_fill_k(const dsl_wgrad_desc* descs, int count, int splits, int cfg, bool v3, WgK& k, long long* px_out, long long* xo_out) {
   const dsl_wgrad_desc* d = descs;
   memset(&k, 0, sizeof(k));
   k.nseg = d->nseg; k.n = d->n;
@@ -2224,8 +2711,11 @@ int wgrad_fill_k(const dsl_wgrad_desc* descs, int count, int splits, int cfg, Wg
   k.gy = d->kh * d->kw * d->cs / bcis[cfg];
   k.splits = splits;
   k.chunk = (k.gx * k.gy * count * splits + 7) / 8;
-  k.ktiles = (px + 63) / 64;
+  const int ks = v3 ? kWgV3KS : 64;
+  k.ktiles = (px + ks - 1) / ks;
   k.tiles_per_split = (k.ktiles + splits - 1) / splits;
+  if (v3)
+    if (int rc = wgrad_v3_fill(d, k, px)) return rc;
   *px_out = px;
   *xo_out = xo;
   return 0;
@@ -2323,6 +2813,12 @@ extern "C" int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* cou
   t->nsub = nsub;
   int splits[kMaxMulti], first[kMaxMulti], order[kMaxMulti];
   wgrad_multi_splits(descs, counts, nsub, splits);
+  {                                    // the pipelined kernel serves the launch only if it can serve every sub-launch
+    bool v3 = true;
+    int off = 0;
+    for (int s = 0; s < nsub; ++s) { v3 = v3 && wgrad_v3_ok(&descs[off], t->cfg); off += counts[s]; }
+    t->v3 = v3 ? 1 : 0;
+  }
   long long per_wg[kMaxMulti];
   {
     int off = 0;
@@ -2344,7 +2840,7 @@ extern "C" int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* cou
     const dsl_wgrad_desc* d = &descs[first[s]];
     WgK& k = t->k[i];
     long long px, xo;
-    if (int rc = wgrad_fill_k(d, counts[s], splits[s], t->cfg, k, &px, &xo)) return rc;
+    if (int rc = wgrad_fill_k(d, counts[s], splits[s], t->cfg, t->v3 != 0, k, &px, &xo)) return rc;
     k.direct = splits[s] == 1 ? 1 : 0;
     k.ws = (float*)ws;
     blocks += k.chunk * 8;
@@ -2397,23 +2893,31 @@ extern "C" int dsl_conv2d_wgrad_multi(const void* table_host, const void* table_
   hipStream_t st = (hipStream_t)stream;
   const int prof = dsl_prof_active() ? dsl_prof_begin(3, t->flops, st, t->bytes) : -1;
   const int bcos[5] = {0, 256, 256, 128, 128}, bcis[5] = {0, 256, 128, 256, 128}, nsts[5] = {2, 2, 3, 3, 2};
-  const size_t lds2 = (size_t)nsts[t->cfg] * 64 * 2 * (bcos[t->cfg] + bcis[t->cfg]);
+  const size_t lds2 = t->v3 ? wgrad_v3_lds(t->cfg) : (size_t)nsts[t->cfg] * 64 * 2 * (bcos[t->cfg] + bcis[t->cfg]);
   const dim3 grid(t->total_blocks);
-#define LAUNCHM(A, B, C_, D, KS_, S_)                                                                                \
+#define LAUNCHM(KERNEL, A, B, C_, D, KS_, S_)                                                                        \
   do {                                                                                                               \
     static bool a_ = false;                                                                                          \
     if (!a_) {                                                                                                       \
-      hipFuncSetAttribute((const void*)wgrad_glds_multi_kernel<A, B, C_, D, KS_, S_>,                                \
+      hipFuncSetAttribute((const void*)KERNEL<A, B, C_, D, KS_, S_>,                                                 \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                    \
       a_ = true;                                                                                                     \
     }                                                                                                                \
-    hipLaunchKernelGGL((wgrad_glds_multi_kernel<A, B, C_, D, KS_, S_>), grid, dim3(64 * C_ * D), lds2, st, t->hdr, ktab); \
+    hipLaunchKernelGGL((KERNEL<A, B, C_, D, KS_, S_>), grid, dim3(64 * C_ * D), lds2, st, t->hdr, ktab);              \
   } while (0)
-  switch (t->cfg) {
-    case 1: LAUNCHM(256, 256, 2, 4, 64, 2); break;
-    case 2: LAUNCHM(256, 128, 4, 2, 64, 3); break;
-    case 3: LAUNCHM(128, 256, 2, 4, 64, 3); break;
-    default: LAUNCHM(128, 128, 2, 2, 64, 2); break;
+  if (t->v3) {
+    switch (t->cfg) {
+      case 1: LAUNCHM(wgrad_pipe_multi_kernel, 256, 256, 2, 4, 32, 4); break;
+      case 2: LAUNCHM(wgrad_pipe_multi_kernel, 256, 128, 4, 2, 32, 5); break;
+      default: LAUNCHM(wgrad_pipe_multi_kernel, 128, 256, 2, 4, 32, 5); break;
+    }
+  } else {
+    switch (t->cfg) {
+      case 1: LAUNCHM(wgrad_glds_multi_kernel, 256, 256, 2, 4, 64, 2); break;
+      case 2: LAUNCHM(wgrad_glds_multi_kernel, 256, 128, 4, 2, 64, 3); break;
+      case 3: LAUNCHM(wgrad_glds_multi_kernel, 128, 256, 2, 4, 64, 3); break;
+      default: LAUNCHM(wgrad_glds_multi_kernel, 128, 128, 2, 2, 64, 2); break;
+    }
   }
 #undef LAUNCHM
   dsl_prof_end(prof, st);

@@ -21,6 +21,18 @@ import numpy as np
 import torch
 
 
+def mark_ready(img, stream=None):
+    """Attaches the producer's event to a batch image tensor: recorded now on `stream` (default: the current stream).  A loader
+    that renders batches on its own stream calls this after its last kernel; FCOS.forward_train then starts the frozen prefix of
+    the forward pass (image layout, stem, layer1) behind THAT event instead of behind everything queued on the training
+    stream - i.e. under the tail of the previous step's backward pass (FCOS.pipeline_prefix)."""
+    if img.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record(stream if stream is not None else torch.cuda.current_stream(img.device))
+        img._dsl_ready = ev
+    return img
+
+
 def synth_boxes(rng, n, H=800, W=1333, lo=16.0, hi=600.0):
     cx, cy = rng.uniform(0, W, n), rng.uniform(0, H, n)
     w = np.exp(rng.uniform(np.log(lo), np.log(min(hi, W)), n))

@@ -270,10 +270,11 @@ class FCOS(nn.Module):
         # once per train_step, as mmcv's OptimizerHook does.
         self.eager_backward = False
         self._in_train_step, self._deferred_plan = False, None
-        # True: the caller guarantees that a batch's image tensor is complete before the PREVIOUS step's backward pass was queued
-        # (resident inputs, a loader on its own synchronised stream): the frozen prefix of the forward pass - image layout, stem,
-        # pool, layer1 - then runs on its own stream under the tail of that backward pass and the optimizer step (bench.py sets it)
-        self.pipeline_prefix = False
+        # The frozen prefix of the forward pass - image layout, stem, pool, layer1 - runs on its own stream; when the batch's image
+        # tensor carries its producer's event (dsl_amd.data.mark_ready: resident inputs, a loader that renders on its own stream)
+        # it starts under the tail of the PREVIOUS step's backward pass and optimizer step, otherwise it is ordered behind
+        # everything queued on the caller's stream (always correct, no overlap)
+        self.pipeline_prefix = True
         self._prefix_stream = None
         self.loss_scale = 1.0         # constant factor on every gradient (gradient accumulation: 1/k); the reported losses stay unscaled
         self._pending = []
@@ -366,6 +367,20 @@ class FCOS(nn.Module):
                 self._prefix_stream = torch.cuda.Stream()
             if img.is_cuda:
                 img.record_stream(self._prefix_stream)
+            ready = getattr(img, '_dsl_ready', None)          # event of the image's producer (dsl_amd.data.mark_ready)
+            if getattr(self, '_prefix_plan', None) is not plan:
+                # first use of this plan (or the first step at all): SLOT_TAIL was never recorded, so nothing orders the prefix
+                # stream behind the caller's stream, which wrote the frozen packs (store.refresh) and possibly the image
+                self._prefix_stream.wait_stream(torch.cuda.current_stream())
+                self._prefix_plan = plan
+            elif ready is not None:
+                self._prefix_stream.wait_event(ready)
+            elif img.is_cuda:
+                # unknown producer: it can only have been queued on the caller's stream, behind the previous step - correct for
+                # any caller, the prefix then simply runs after that step instead of under its tail
+                ev = torch.cuda.Event()
+                ev.record()
+                self._prefix_stream.wait_event(ev)
             with torch.cuda.stream(self._prefix_stream):
                 plan.prefix.run()
             fwd = plan.fwd_rest

@@ -215,23 +215,38 @@ class EvalHook:
         if store is not None and runner.logger:
             runner.logger.info('Using ema model for eval')
         results = multi_gpu_test(det, self.dataloader, store)
-        ds = getattr(self.dataloader, 'dataset', self.dataloader)
-        if hasattr(ds, 'evaluate'):
-            metrics = ds.evaluate(results, metric=self.metric, **self.eval_kwargs)
-        else:
-            prefix = self.jsonfile_prefix or (os.path.join(runner.work_dir, f'eval_epoch_{runner.epoch + 1}') if runner.work_dir else None)
-            files, tmp = format_results(results, ds.img_ids, ds.cat_ids, prefix)
-            metrics = coco_bbox_eval(json.load(open(files['bbox'])), ds.img_ids, ds.cat_ids, ds.annotations)
-            metrics = OrderedDict((f'bbox_{k}', v) for k, v in metrics.items())
-            if tmp is not None:
-                tmp.cleanup()
+        # DistEvalHook (mmdet/core/evaluation/eval_hooks.py): every rank takes part in the gather above, but only rank 0 formats,
+        # evaluates, logs and saves - the other ranks would race on the same json / checkpoint paths - and the metrics are
+        # broadcast so every rank's history / best agree
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        rank = dist.get_rank() if multi else 0
+        metrics = None
+        if rank == 0:
+            ds = getattr(self.dataloader, 'dataset', self.dataloader)
+            if hasattr(ds, 'evaluate'):
+                metrics = ds.evaluate(results, metric=self.metric, **self.eval_kwargs)
+            else:
+                prefix = self.jsonfile_prefix or (os.path.join(runner.work_dir, f'eval_epoch_{runner.epoch + 1}') if runner.work_dir else None)
+                files, tmp = format_results(results, ds.img_ids, ds.cat_ids, prefix)
+                metrics = coco_bbox_eval(json.load(open(files['bbox'])), ds.img_ids, ds.cat_ids, ds.annotations)
+                metrics = OrderedDict((f'bbox_{k}', v) for k, v in metrics.items())
+                if tmp is not None:
+                    tmp.cleanup()
+        if multi:
+            box = [metrics]
+            dist.broadcast_object_list(box, src=0)
+            metrics = box[0]
         self.history.append((runner.epoch + 1, dict(metrics)))
-        if runner.logger:
+        if runner.logger and rank == 0:
             runner.logger.info('Epoch(val) [%d]\t%s', runner.epoch + 1, ', '.join(f'{k}: {v:.4f}' for k, v in metrics.items()))
         key = next((k for k in metrics if self.save_best and k.endswith(self.save_best)), None)
         if key is not None and (self.best is None or metrics[key] > self.best) and runner.work_dir:
             self.best = metrics[key]
-            runner.save_checkpoint(runner.work_dir, filename_tmpl='best_' + key + '_epoch_{}.pth', create_symlink=False)
+            if rank == 0:
+                runner.save_checkpoint(runner.work_dir, filename_tmpl='best_' + key + '_epoch_{}.pth', create_symlink=False)
+        if multi:
+            dist.barrier()
         return metrics
 
 

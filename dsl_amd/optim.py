@@ -42,10 +42,18 @@ class FlatSGD:
         st = self.store
         if hasattr(self.model, 'wait_grads'):
             self.model.wait_grads()
-        if self.momentum_buf is None or self.momentum_buf.device != st.device:
+        if self.momentum_buf is None:
             self.momentum_buf = torch.zeros_like(st.train)
-            self.gnorm_sq = torch.zeros(1, device=st.device)
             self.steps = 0
+        elif self.momentum_buf.device != st.device or self.momentum_buf.shape != st.train.shape:
+            # state restored from a checkpoint (CPU tensor, possibly without the tile padding of this build): move it
+            # into a buffer laid out like the parameter buffer and keep the step count (resume must not re-zero momentum)
+            buf = torch.zeros_like(st.train)
+            n = min(buf.numel(), self.momentum_buf.numel())
+            buf.view(-1)[:n].copy_(self.momentum_buf.reshape(-1)[:n].to(device=st.device, dtype=buf.dtype))
+            self.momentum_buf = buf
+        if self.gnorm_sq is None or self.gnorm_sq.device != st.device:
+            self.gnorm_sq = torch.zeros(1, device=st.device)
         sp = L.stream_ptr()
         gptr = None
         if self.max_norm is not None:
@@ -66,7 +74,14 @@ class FlatSGD:
         return dict(momentum=self.momentum_buf, steps=self.steps, param_groups=self.param_groups)
 
     def load_state_dict(self, sd):
-        self.momentum_buf, self.steps, self.param_groups = sd['momentum'], sd['steps'], sd['param_groups']
+        """Restores momentum, the step count (first-step rule of torch.optim.SGD: buf = grad) and the groups' learning
+        rates.  The momentum tensor may live on the CPU (runner.resume loads with map_location='cpu'); step() moves it."""
+        m = sd['momentum']
+        self.momentum_buf = m.detach().clone() if isinstance(m, torch.Tensor) else None
+        self.steps = int(sd['steps']) if self.momentum_buf is not None else 0
+        self.param_groups = [dict(g) for g in sd['param_groups']]
+        self.gnorm_sq = None
+        self._sumsq_ws = None
 
 
 def build_optimizer(model, cfg, grad_clip=None):

@@ -218,6 +218,9 @@ class SemiEpochBasedRunner:
             t.refresh()
         else:
             L.check(L.lib.dsl_cast_bf16(L.ptr(t.train), L.ptr(t.train16), t.n_train, L.stream_ptr()), 'dsl_cast_bf16')
+            # RLA_ResNet keeps the affine parameters of its eval-mode BatchNorms trainable: the teacher's forward reads the
+            # FOLDED (scale, bias), so they are re-made from the lerped gamma / beta (no-op for the plain ResNet)
+            t.refold_bn(L.stream_ptr())
         self.ema_flag = True
 
     def save_checkpoint(self, out_dir, filename_tmpl='epoch_{}.pth', save_optimizer=True, meta=None, create_symlink=True):
@@ -548,7 +551,9 @@ class UnlabelPredHook(Hook):
         det = runner._det(runner.model)
         teacher = runner._det(runner.ema_model) if (self.use_ema and runner.ema_flag and runner.ema_model is not None) else det
         thr = self.infer_score_thre if thr is None else thr
-        if self.async_sweep and self.iter_fuse_flag:
+        if self.async_sweep and self.iter_fuse_flag and teacher is not det:
+            # (teacher is det - no EMA teacher yet, or use_ema=False - sweeps synchronously: the student's next SGD step and
+            # weight re-pack would rewrite the bf16 weights / BatchNorm folds under the side stream's reads)
             # the sweep of an image the loader hands out `prefetch_depth` batches from now runs on its own stream beside the
             # student's next step (the reference refreshes `preload` iterations ahead of the loader for the same reason); it
             # starts behind everything queued so far (the teacher's EMA update included), the next EMA update waits for it
