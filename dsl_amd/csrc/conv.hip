@@ -1658,19 +1658,24 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
     b_off[it] = TILE_Y + krow_l * XB + ((((col * 2) >> 6) ^ (krow_l & 3)) << 6) + ((col * 2) & 63);
   }
   Frag fa[2][CT], fb[2][IT];
+  constexpr int NR = 2 * (CT + IT);         // fragment reads per k-step
+  auto rd = [&](unsigned stage_addr, int kk, int f, int j) {      // read j of the k-step's NR (j is a constant after unrolling)
+#ifdef DSL_ABLATE_BUILD
+    if (p.dbg & 8) return;
+#endif
+    if (j < 2 * CT) {
+      const int ct = j >> 1;
+      const unsigned ad = stage_addr + a_off[ct] + kk * 16 * YB + (j & 1) * 4 * YB;
+      if (j & 1) fa[f][ct].hi = lds_tr_read_b64(ad); else fa[f][ct].lo = lds_tr_read_b64(ad);
+    } else {
+      const int it = (j - 2 * CT) >> 1;
+      const unsigned ad = stage_addr + b_off[it] + kk * 16 * XB + (j & 1) * 4 * XB;
+      if (j & 1) fb[f][it].hi = lds_tr_read_b64(ad); else fb[f][it].lo = lds_tr_read_b64(ad);
+    }
+  };
   auto issue = [&](unsigned stage_addr, int kk, int f) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const unsigned ad = stage_addr + a_off[ct] + kk * 16 * YB;
-      fa[f][ct].lo = lds_tr_read_b64(ad);
-      fa[f][ct].hi = lds_tr_read_b64(ad + 4 * YB);
-    }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const unsigned ad = stage_addr + b_off[it] + kk * 16 * XB;
-      fb[f][it].lo = lds_tr_read_b64(ad);
-      fb[f][it].hi = lds_tr_read_b64(ad + 4 * XB);
-    }
+    for (int j = 0; j < NR; ++j) rd(stage_addr, kk, f, j);
   };
   auto wait_lds = [&](int f) {       // every outstanding LDS read of this wave has landed; the registers it wrote change HERE
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1686,6 +1691,9 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
   unsigned xv[LX];                   // gather offsets of stage t_data (from its descriptors)
   u32x2 dreg[LX];
   auto piece = [&](int k) {          // k is a constant after unrolling
+#ifdef DSL_ABLATE_BUILD
+    if ((p.dbg & 1) && t_data >= kt0 + NST) return;      // no DMA after the ring's first fill
+#endif
     if (k < NDSC) {
       const unsigned v = (unsigned)(t_desc * (KS * 8) + k * 256 + lane * 4);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lptr_t)(smem + DESC_BASE + (t_desc & (DR - 1)) * (KS * 8) + k * 256), 4, v, 0, 0, 0);
@@ -1721,7 +1729,7 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
   };
   // one k-step's MFMAs with the DMA pieces [lo, hi) of the stage issued between them: one piece behind every second MFMA
   // (everything here is pinned in source order)
-  auto block = [&](int f, int lo, int hi) {
+  auto block = [&](int f, int lo, int hi, unsigned rd_stage, int rd_kk) {
     bf16x8 a[CT], b[IT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -1741,15 +1749,22 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
     int k = lo;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
+#ifdef DSL_ABLATE_BUILD
+      if (!(p.dbg & 2))
+#endif
       acc[m / IT][m % IT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m / IT], b[m % IT], acc[m / IT][m % IT], 0, 0, 0);
-      if ((m & 1) == 0 && m + 1 < NM && k < hi) {
-        __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the next k-step's fragment reads ride between the MFMAs (a burst of NR reads in front of the block keeps the wave
+      // on LDS issue for as long as the block's MFMAs take: measured, the two simply added up)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+        if (j >= m * NR / NM && j < (m + 1) * NR / NM) rd(rd_stage, rd_kk, f ^ 1, j);
+      if ((m & 1) == 1 && k < hi) {
         piece(k);
         ++k;
-        __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < P; ++j)
       if (k + j < hi) piece(k + j);
@@ -1800,23 +1815,25 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
           db_hi += __uint_as_float(dbr[j] & 0xffff0000u);
         }
       }
-      if (kk < KK - 1) {
-        issue(st, kk + 1, f ^ 1);
-        if (kk == 0 && do_db) {
+      if (kk == 0 && do_db) {
 #pragma unroll
-          for (int j = 0; j < DB_ROWS; ++j) {
-            const int row = db_rg * DB_ROWS + j;
-            dbr[j] = lds_read_b32_asm(st + row * YB + ((((db_cp * 4) >> 6) ^ (row & 3)) << 6) + ((db_cp * 4) & 63));
-          }
+        for (int j = 0; j < DB_ROWS; ++j) {
+          const int row = db_rg * DB_ROWS + j;
+          dbr[j] = lds_read_b32_asm(st + row * YB + ((((db_cp * 4) >> 6) ^ (row & 3)) << 6) + ((db_cp * 4) & 63));
         }
-      } else {
+      }
+      if (kk == KK - 1) {
         wait_vmcnt<(NST - 3) * P + PA>();      // stage s+1 landed (and every older DMA of this wave)
+#ifdef DSL_ABLATE_BUILD
+        if (!(p.dbg & 16))
+#endif
         __builtin_amdgcn_s_barrier();          // ... for every wave; every wave is done reading stage s
-        issue(lds_base + nslot * STAGE, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // pieces of this k-step (compile-time bounds)
-      block(f, kk * P / KK, (kk + 1) * P / KK);
+      // this k-step's MFMAs, between them the fragment reads of the next k-step (the last k-step: of the next stage's first,
+      // behind the barrier above) and this k-step's share of the stage's DMA pieces
+      if (kk < KK - 1) block(f, kk * P / KK, (kk + 1) * P / KK, st, kk + 1);
+      else block(f, kk * P / KK, P, lds_base + nslot * STAGE, 0);
       if (kk == KK - 1) {
         advance();
         desc_read();                           // descriptors of the stage fetched next (published by the barrier above)
@@ -1826,6 +1843,9 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
   }
   wait_vmcnt<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef DSL_ABLATE_BUILD
+  if (p.dbg & 4) return;
+#endif
 
   if (do_db) {               // fold the row groups in a fixed order; one value per column leaves the workgroup
     __syncthreads();
@@ -1883,7 +1903,13 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
 template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
 __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_pipe_kernel(const WgK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  wgrad_pipe_body<BCO, BCI, WCO, WCI, KS, NST>(p, (int)blockIdx.x, smem);
+  // persistent form (grid < work items, a multiple of 8 so that a block keeps its XCD): the launch never holds more CUs than
+  // its workgroup budget, whatever the number of tiles and splits - the caller's chain of small launches keeps the rest
+  const int total = p.chunk * 8;
+  for (int vb = (int)blockIdx.x; vb < total; vb += (int)gridDim.x) {
+    wgrad_pipe_body<BCO, BCI, WCO, WCI, KS, NST>(p, vb, smem);
+    __syncthreads();
+  }
 }
 
 // Several weight-gradient launches of ONE tile configuration as one grid (dsl_conv2d_wgrad_multi): sub-launch s owns the
@@ -1921,6 +1947,24 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_pipe_multi_kernel(const 
   }
   const WgK p = tab[sub];
   wgrad_pipe_body<BCO, BCI, WCO, WCI, KS, NST>(p, (int)blockIdx.x - start, smem);
+}
+
+// persistent form of the multi launch: `grid` (a multiple of 8) workgroups walk the block list
+template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
+__global__ __launch_bounds__(64 * WCO * WCI) void wgrad_pipe_multi_persist_kernel(const WgMultiHdr h, const WgK* __restrict__ tab, int total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  for (int vb = (int)blockIdx.x; vb < total; vb += (int)gridDim.x) {
+    int sub = 0, start = 0;
+#pragma unroll
+    for (int s = 1; s < kMaxMulti; ++s) {
+      const bool in = s < h.nsub && vb >= h.wg_end[s - 1];
+      sub = in ? s : sub;
+      start = in ? h.wg_end[s - 1] : start;
+    }
+    const WgK p = tab[sub];
+    wgrad_pipe_body<BCO, BCI, WCO, WCI, KS, NST>(p, vb - start, smem);
+    __syncthreads();
+  }
 }
 
 // the reduce passes of a multi launch: entry e (one member of one sub-launch with more than one split) owns the blocks
@@ -2328,6 +2372,12 @@ struct PixTabEntry {
 std::mutex g_pixtab_mu;
 std::vector<PixTabEntry> g_pixtabs;
 
+int wgrad_slots();
+bool wgrad_persist() {
+  // measured (tools/exp_env.sh, bench.py N = 2): persistent grids of 128 workgroups +2.3 % (96 .. 160 within 0.3 %, 64: -1 %)
+  static const bool on = [] { const char* e = getenv("DSL_WGRAD_PERSIST"); return !e || atoi(e) != 0; }();
+  return on;
+}
 bool wgrad_v3_enabled() {
   static const bool on = [] { const char* e = getenv("DSL_WGRAD_V3"); return !e || atoi(e) != 0; }();
   return on;
@@ -2442,7 +2492,7 @@ static int wgrad_splits_for(const dsl_wgrad_desc* d, int count) {
     // small convolutions, and a full round of 128 KB-LDS workgroups that live for 100-250 us would leave those
     // kernels only the handful of CUs the round did not cover
     // (measured, bench.py N = 2: 256 -> 305, 224 -> 306, 192 -> 309, 160 -> 313, 128 -> 310 img/s)
-    static const int slots_env = [] { const char* e = getenv("DSL_WGRAD_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 160; }();
+    static const int slots_env = [] { const char* e = getenv("DSL_WGRAD_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
     const int slots = d->slots > 0 ? d->slots : slots_env;
     splits = slots * per_cu / tiles;
   }
@@ -2589,6 +2639,10 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
     hipLaunchKernelGGL((KERNEL<A, B, C_, D, KS_, S_>), grid2, dim3(64 * C_ * D), lds2, st, k);                        \
   } while (0)
     if (v3) {
+      if (wgrad_persist()) {
+        const int cap = ((d->slots > 0 ? d->slots : wgrad_slots()) + 7) / 8 * 8;
+        if ((int)grid2.x > cap) grid2.x = cap;
+      }
       switch (cfg) {
         case 1: LAUNCHW(wgrad_pipe_kernel, 256, 256, 2, 4, 32, 4); break;
         case 2: LAUNCHW(wgrad_pipe_kernel, 256, 128, 4, 2, 32, 5); break;
@@ -2722,7 +2776,7 @@ int wgrad_fill_k(const dsl_wgrad_desc* descs, int count, int splits, int cfg, bo
 }
 
 int wgrad_slots() {
-  static const int slots = [] { const char* e = getenv("DSL_WGRAD_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 160; }();
+  static const int slots = [] { const char* e = getenv("DSL_WGRAD_SLOTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
   return slots;
 }
 
@@ -2905,7 +2959,27 @@ extern "C" int dsl_conv2d_wgrad_multi(const void* table_host, const void* table_
     }                                                                                                                \
     hipLaunchKernelGGL((KERNEL<A, B, C_, D, KS_, S_>), grid, dim3(64 * C_ * D), lds2, st, t->hdr, ktab);              \
   } while (0)
-  if (t->v3) {
+  const int cap = (wgrad_slots() + 7) / 8 * 8;
+  if (t->v3 && wgrad_persist() && t->total_blocks > cap) {
+    const dim3 pgrid(cap);
+#define LAUNCHP(A, B, C_, D, KS_, S_)                                                                                \
+  do {                                                                                                               \
+    static bool a_ = false;                                                                                          \
+    if (!a_) {                                                                                                       \
+      hipFuncSetAttribute((const void*)wgrad_pipe_multi_persist_kernel<A, B, C_, D, KS_, S_>,                        \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                    \
+      a_ = true;                                                                                                     \
+    }                                                                                                                \
+    hipLaunchKernelGGL((wgrad_pipe_multi_persist_kernel<A, B, C_, D, KS_, S_>), pgrid, dim3(64 * C_ * D), lds2, st, t->hdr, ktab, \
+                       t->total_blocks);                                                                             \
+  } while (0)
+    switch (t->cfg) {
+      case 1: LAUNCHP(256, 256, 2, 4, 32, 4); break;
+      case 2: LAUNCHP(256, 128, 4, 2, 32, 5); break;
+      default: LAUNCHP(128, 256, 2, 4, 32, 5); break;
+    }
+#undef LAUNCHP
+  } else if (t->v3) {
     switch (t->cfg) {
       case 1: LAUNCHM(wgrad_pipe_multi_kernel, 256, 256, 2, 4, 32, 4); break;
       case 2: LAUNCHM(wgrad_pipe_multi_kernel, 256, 128, 4, 2, 32, 5); break;

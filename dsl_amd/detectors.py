@@ -422,6 +422,7 @@ class FCOS(nn.Module):
         segment's data-gradient chain - so the bulk RCCL traffic overlaps the remaining backward (what torch DDP's bucket
         hooks do at mmdet/apis/train.py:92-96); only the last, smallest bucket (layer2, 5 MB) is exposed."""
         self._pending = []
+        self._last_bwd_infos = [info for _, info in plan.bwd_segments]      # bucket ranges / event slots, for the optimizer
         ddp = self.world_size > 1
         on_gpu = self.store.grad.is_cuda
         if ddp and on_gpu and self._comm_stream is None:

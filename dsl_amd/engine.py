@@ -486,8 +486,13 @@ class Plan:
         self._wg_pending = []
         g_feats = self.buf('g_feats', M, 256)
         # ================= segment 0: head + FPN =================
+        # where in this pass the next step's frozen prefix (FCOS.pipeline_prefix) may start: 0 = with the pass, 3 / 2 / 1 = behind
+        # layer4's / layer3's / layer2's data gradients (1 = the whole chain, the round-2 setting)
+        PREFIX_LI = int(os.environ.get('DSL_PREFIX_AT', '2'))       # measured (tools/exp_env.sh): 1: 355.5, 3: 360, 2 / 0: +0.2 % over 3
         ol = OpList()
         ol.wait(L.SLOT_PACKS, stream=0)      # the data-gradient weight packs of the last optimizer step (ParamStore.repack_dgrad)
+        if PREFIX_LI == 0:
+            ol.record(L.SLOT_TAIL, stream=0)
         ol.prof(5, 0, self._head_flops, self.M * 256 * 2.0 * (8 * 2 + 8 * 5 + 2))       # same FLOPs as the forward phase: data gradients
         tower_group = []
         # the two towers' backward chains are independent until both have added into g_feats: the regression tower's runs on
@@ -536,7 +541,7 @@ class Plan:
                                  dbias=st.t32_ptr(lay['spec'].name + '.bias', st.grad))
                 ol.gn_bwd(gd, side=sd)
                 tower_group.append(self._wgrad(ol, lay['spec'], g_pre[tower], lay['xin'], N, ls, ls, side=SIDE, emit=False, no_db=True,
-                                               slots=int(os.environ.get('DSL_TOWER_SLOTS', '96'))))     # measured: tools/exp_r2z.sh (48-128: 5.84 ms, 160-192: 5.89)
+                                               slots=int(os.environ.get('DSL_TOWER_SLOTS', '72'))))     # measured: tools/exp_r2z.sh (48-128: 5.84 ms, 160-192: 5.89); round 3: 72 / 96 / 128: 5.435 / 5.461 / 5.456
             if (HALVES and i in (2, 0)) or i == 0:
                 if BT and SIDE:
                     ol.fork(1, other=BT)       # the weight-gradient stream also waits for the regression tower's stream
@@ -702,8 +707,8 @@ class Plan:
                         for spec, dy in ((c1, gA1),) if ds_early else ((ds, g_pre), (c1, gA1)):
                             ol.conv(self._dgrad(spec.name, dy, tgt, N, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
-            if li == 1:
-                ol.record(L.SLOT_TAIL, stream=0)       # the data-gradient chain is done: the next step's frozen prefix may start
+            if li == PREFIX_LI:
+                ol.record(L.SLOT_TAIL, stream=0)       # from here on the next step's frozen prefix may run beside this pass
             if GROUP and (li > 1 or GROUP_LAST):
                 # last segment: the caller's stream has nothing left to do, it takes part of the groups itself
                 on_main = os.environ.get('DSL_TAIL_MAIN', '2') if li == 1 else '0'     # measured: tools/exp_r2w.sh
