@@ -4,7 +4,7 @@ import re
 import sqlite3
 import sys
 db = sqlite3.connect(sys.argv[1])
-marker = sys.argv[2] if len(sys.argv) > 2 else 'sgd_kernel'
+marker = sys.argv[2] if len(sys.argv) > 2 else 'loss_kernel'
 rows = db.execute('select name, queue_id, start, end from kernels order by start').fetchall()
 marks = [r[3] for r in rows if marker in r[0]]
 t0, t1 = marks[-2], marks[-1]

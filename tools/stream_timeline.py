@@ -6,7 +6,7 @@ import sqlite3
 import sys
 db = sqlite3.connect(sys.argv[1])
 nlast = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-marker = sys.argv[3] if len(sys.argv) > 3 else 'sgd_kernel'
+marker = sys.argv[3] if len(sys.argv) > 3 else 'loss_kernel'
 rows = db.execute('select name, queue_id, start, end from kernels order by start').fetchall()
 marks = [r[3] for r in rows if marker in r[0]]
 t0, t1 = marks[-nlast - 1], marks[-1]
