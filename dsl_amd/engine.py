@@ -315,7 +315,25 @@ class Plan:
         self._pp = {}           # descriptors that touch layer1's output (pipelined prefix: two buffers, patched per step)
         PAIR_FWD = os.environ.get('DSL_PAIR_FWD', '')      # stages (layer numbers) whose conv3 -> next conv1 pairs run fused, e.g. '23'
         pair_done = False
+        # Image-split stages (DSL_IMG_SPLIT, default layer3; measured: none 372.6, 3: 384.0, 34: 383.4, 4: 372.1, 23: -0.5 % vs 3): their launches are 66-132 workgroups of 15-40 us - mostly
+        # fill, epilogue and kernel boundary on half a chip.  The images of a batch are independent through the backbone, so the
+        # batch goes through these stages as TWO chains (images [0, ceil(N/2)) on the caller's stream, the rest on stream 3) of
+        # half-size launches: one chain's fixed per-launch costs hide under the other chain's kernels.
+        SPLIT = os.environ.get('DSL_IMG_SPLIT', '3') if (self.BR and N >= 2 and not PAIR_FWD and self.training) else ''
+        split_open = False
+
+        def br_ws(d_):
+            d_.workspace, d_.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
+            return d_
         for li, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
+            split = str(li + 1) in SPLIT
+            if split and not split_open:
+                f.fork(self.BR)
+                split_open = True
+            elif split_open and not split:
+                f.join(self.BR)
+                split_open = False
+            groups = [(0, (N + 1) // 2, 0), ((N + 1) // 2, N, self.BR)] if split else [(0, N, 0)]
             for b in range(nb):
                 p = f'backbone.layer{li + 1}.{b}'
                 c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
@@ -327,17 +345,38 @@ class Plan:
                 idt = x
                 if b == 0:      # the downsample conv only meets the main branch at conv3's residual add
                     idt = self.buf(p + '.idt', N, oh, ow, planes * 4)
+                if split:
+                    for g0, g1, sd in groups:
+                        wsf = br_ws if sd else (lambda d_: d_)
+                        n_ = g1 - g0
+                        off = g0 * h * w * x.shape[-1] * 2          # this group's byte offset into the stage input
+                        if b == 0:
+                            dd = wsf(self._conv(cv[p + '.downsample.0'], x[g0:g1], idt[g0:g1], n_, [(h, w)], [(oh, ow)]))
+                            f.conv(dd, side=sd)
+                            if li == 1:
+                                self._pp.setdefault('ds', []).append((dd, off))
+                        d1 = wsf(self._conv(c1, x[g0:g1], a1[g0:g1], n_, [(h, w)], [(oh, ow)], relu=True))
+                        f.conv(d1, side=sd)
+                        if li == 1 and b == 0:
+                            self._pp.setdefault('c1', []).append((d1, off))
+                        f.conv(wsf(self._conv(c2, a1[g0:g1], a2[g0:g1], n_, [(oh, ow)], [(oh, ow)], relu=True)), side=sd)
+                        f.conv(wsf(self._conv(c3, a2[g0:g1], out[g0:g1], n_, [(oh, ow)], [(oh, ow)], relu=True, addend=idt[g0:g1])), side=sd)
+                    self.blocks.append(dict(prefix=p, xin=x, a1=a1, a2=a2, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
+                                            stage=li, b=b, planes=planes))
+                    x, h, w = out, oh, ow
+                    continue
+                if b == 0:
                     dd = self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)])
                     if self.BR:
                         dd.workspace, dd.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
                         f.fork(self.BR)
                     f.conv(dd, side=self.BR)
                 if li == 1 and b == 0:
-                    self._pp['ds'] = dd
+                    self._pp['ds'] = [(dd, 0)]
                 if not pair_done:       # (else: computed by the previous block's pair launch)
                     d1 = self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True)
                     if li == 1 and b == 0:
-                        self._pp['c1'] = d1
+                        self._pp['c1'] = [(d1, 0)]
                     f.conv(d1)
                 f.conv(self._conv(c2, a1, a2, N, [(oh, ow)], [(oh, ow)], relu=True))
                 if b == 0 and self.BR:
@@ -364,6 +403,8 @@ class Plan:
             self.stage_ld.append(planes * 4)
             if li == 0:
                 self._prefix_end = len(f.items)        # pack + stem + pool + layer1: frozen weights, a function of the image alone
+        if split_open:
+            f.join(self.BR)
 
     def _gn_workspace(self, key):
         """Launches on one stream run one after the other and may share the block-record scratch."""
@@ -654,6 +695,7 @@ class Plan:
             engine_rla.build_backward(self, buckets, SIDE)
             return
         blocks_by_stage = {li: [b for b in self.blocks if b['stage'] == li] for li in (1, 2, 3)}
+        BSPLIT = os.environ.get('DSL_IMG_SPLIT_BWD', '23')      # measured (tools/exp_env.sh): '' 372-377, 3: 378.5, 23: 382.5, 34: 381.5, 234: 379.7 img/s
         for li in (3, 2, 1):
             ol = OpList()
             if li == 1:
@@ -663,6 +705,15 @@ class Plan:
             planes = blks[0]['planes']
             g_pre = self.g_stage[li]          # gradient w.r.t. the (pre-ReLU-masked) output of the stage's last block
             g3, g2, g1 = [], [], []           # same-geometry weight gradients of this stage's blocks
+            # image-split data-gradient chains (as in the forward pass, DSL_IMG_SPLIT_BWD): images [0, ceil(N/2)) on the caller's
+            # stream, the rest on stream 3; the stage's weight gradients (whole batch) go out behind the JOIN at its end
+            grp_all = GROUP and (li > 1 or GROUP_LAST)
+            bsplit = bool(BB) and N >= 2 and grp_all and str(li + 1) in BSPLIT
+            groups = [(0, (N + 1) // 2, 0), ((N + 1) // 2, N, BB)] if bsplit else [(0, N, 0)]
+            if bsplit:
+                ol.join(BB)          # whatever stream 3 still runs (laterals, an earlier scatter) is visible to the caller's stream ...
+                ol.fork(BB)          # ... and stream 3 starts behind everything the caller's stream has queued
+                self._br_pending = False
             for blk in reversed(blks):
                 p = blk['prefix']
                 c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
@@ -670,6 +721,36 @@ class Plan:
                 gA1 = self.buf(p + '.g_a1', N, hw[0], hw[1], planes)
                 grp = GROUP and (li > 1 or GROUP_LAST)
                 tsl = TAIL_SLOTS if li == 1 else 0      # last segment: nothing else is left to run beside these launches
+                if bsplit:
+                    g3.append(self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw], side=SIDE, emit=False, slots=tsl))
+                    g2.append(self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw], side=SIDE, emit=False, slots=tsl))
+                    g_prev = self.buf(p + '.g_in', N, hw[0], hw[1], planes * 4) if blk['b'] > 0 else None
+                    for g0, g1_, sd in groups:
+                        wsf = br_ws if sd else (lambda d_: d_)
+                        n_ = g1_ - g0
+                        ol.conv(wsf(self._dgrad(c3.name, g_pre[g0:g1_], gA2[g0:g1_], n_, [hw], [hw], cs=c3.cout, cd=c3.cin, k=1, stride=1, pad=0,
+                                                mask=blk['a2'][g0:g1_], mask_last=True)), side=sd)
+                        ol.conv(wsf(self._dgrad(c2.name, gA2[g0:g1_], gA1[g0:g1_], n_, [hw], [hw], cs=c2.cout, cd=c2.cin, k=3, stride=1, pad=1,
+                                                mask=blk['a1'][g0:g1_], mask_last=True)), side=sd)
+                        if blk['b'] > 0:
+                            ol.conv(wsf(self._dgrad(c1.name, gA1[g0:g1_], g_prev[g0:g1_], n_, [hw], [hw], cs=c1.cout, cd=c1.cin, k=1, stride=1,
+                                                    pad=0, addend=g_pre[g0:g1_], mask=blk['xin'][g0:g1_], mask_last=True)), side=sd)
+                        elif li > 1:      # stride-2 scatters into the previous stage's gradient: downsample path, then conv1
+                            ds = cv[p + '.downsample.0']
+                            tgt, ihw = self.g_stage[li - 1], blk['in_hw']
+                            for spec, dy in ((ds, g_pre), (c1, gA1)):
+                                ol.conv(wsf(self._dgrad(spec.name, dy[g0:g1_], tgt[g0:g1_], n_, [hw], [ihw], cs=spec.cout, cd=spec.cin, k=1,
+                                                        stride=1, pad=0, os=2, addend=tgt[g0:g1_], mask=blk['xin'][g0:g1_], mask_first=True)), side=sd)
+                    if blk['b'] > 0:
+                        g1.append(self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, emit=False, slots=tsl))
+                        g_pre = g_prev
+                    else:
+                        ol.join(BB)       # both chains are done: the weight gradients below (and the groups) read whole-batch tensors
+                        d1 = self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, emit=True, slots=tsl)
+                        dwd = self._wgrad(ol, cv[p + '.downsample.0'], g_pre, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, slots=tsl)
+                        if li == 1:
+                            self._pp['wg_c1'], self._pp['wg_ds'] = d1, dwd
+                    continue
                 ds_early = BB and blk['b'] == 0 and li > 1
                 if ds_early:        # the downsample path's scatter into the previous stage's gradient, beside conv3 -> conv2 -> conv1
                     ds = cv[p + '.downsample.0']
@@ -762,8 +843,8 @@ class Plan:
         """Points the five descriptors that touch layer1's output at buffer p."""
         ptr = self._l1out[p].data_ptr()
         self._pp['c3'].dst = ptr
-        self._pp['c1'].src = ptr
-        self._pp['ds'].src = ptr
+        for d_, off in self._pp['c1'] + self._pp['ds']:
+            d_.src = ptr + off
         self._pp['wg_c1'].x = ptr
         self._pp['wg_ds'].x = ptr
         self._parity = p
