@@ -315,6 +315,22 @@ def main():
                                          'the per-launch figures above stretch when two launches overlap',
                         whole_step_frac=round(value / world * GFLOP_PER_IMAGE_STEP / 1e3 / PEAK_BF16_TFLOPS, 4))
     cpu = extra = None
+    if world > 1:
+        # communication trace (outside the timed region): per gradient bucket, when its all-reduce was issued behind the bucket's
+        # named event and when it was complete, in ms from the start of the step - what the scaling efficiency hinges on
+        det.comm_trace = []
+        for _ in range(2):
+            step()
+        ev_end = torch.cuda.Event(enable_timing=True)
+        ev_end.record()
+        torch.cuda.synchronize()
+        tr = det.comm_trace[-1]
+        det.comm_trace = None
+        bk = [dict(mb=round(b['mb'], 1), start_ms=round(tr['t0'].elapsed_time(b['start']), 3),
+                   done_ms=round(tr['t0'].elapsed_time(b['done']), 3) if b['done'] is not None else None) for b in tr['buckets']]
+        extra = dict(comm=dict(buckets=bk, step_ms=round(tr['t0'].elapsed_time(ev_end), 3),
+                               note='rank 0; bucket order head+FPN, layer4, layer3, layer2; the optimizer updates a bucket as soon as '
+                                    'its all-reduce is done (per-bucket SGD), so only traffic still in flight at step_ms is exposed'))
     if rank == 0 and world == 1 and not args.no_dsl:
         del opt
         extra = dict(dsl_iteration=dsl_iteration_timing())

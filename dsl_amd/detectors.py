@@ -279,6 +279,7 @@ class FCOS(nn.Module):
         self.loss_scale = 1.0         # constant factor on every gradient (gradient accumulation: 1/k); the reported losses stay unscaled
         self._pending = []
         self._comm_stream = None
+        self.comm_trace = None        # set to [] (bench.py --gpus N): per step, per gradient bucket, timed events of its all-reduce
 
     # ---- nn.Module surface redirected to the flat store ------------------------------------------
     def init_weights(self):
@@ -349,6 +350,10 @@ class FCOS(nn.Module):
         eng = self._get_engine()
         N, _, H, W = img.shape
         assert len(img_metas) == N == len(gt_bboxes) == len(gt_labels)
+        if self.comm_trace is not None and img.is_cuda:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+            self.comm_trace.append(dict(t0=t0, buckets=[]))
         plan = eng.plan(self.store, N, H, W, training=True)
         head = self.bbox_head
         if head.loss_weight != 1.0 and gt_bboxes_ignore is None:
@@ -441,6 +446,10 @@ class FCOS(nn.Module):
             if info['main']:
                 cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
+                if self.comm_trace:
+                    es = torch.cuda.Event(enable_timing=True)
+                    es.record()            # the bucket's named event has fired and the previous bucket's traffic is queued
+                    self.comm_trace[-1]['buckets'].append(dict(mb=(hi - lo) * 4 / 1e6, start=es, done=None))
                 self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
         self._rebind_grads()
 

@@ -74,6 +74,11 @@ class FlatSGD:
                 if pend:
                     with torch.cuda.stream(os_):
                         pend[k].wait()
+                        tr = getattr(self.model, 'comm_trace', None)
+                        if tr and k < len(tr[-1]['buckets']):
+                            ed = torch.cuda.Event(enable_timing=True)
+                            ed.record()
+                            tr[-1]['buckets'][k]['done'] = ed
                 else:
                     never = L.lib.dsl_stream_wait_slot(int(info['slot']), osp)
                     if info['main'] or never != 0:

@@ -47,11 +47,11 @@ def build():
     return model.cuda()
 
 
-def _worker(rank, world, port, q, eager, out_path):
+def _worker(rank, world, port, q, eager, out_path, backend='gloo'):
     try:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        torch.cuda.set_device(0)
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        torch.cuda.set_device(rank if backend == 'nccl' else 0)       # nccl (= RCCL): one GPU per rank
+        dist.init_process_group(backend, rank=rank, world_size=world)
         from dsl_amd.parallel import HipDistributedDataParallel
         model = build()
         model.eager_backward = eager                 # must be the same on every rank: it changes the collective order
@@ -74,13 +74,12 @@ def _worker(rank, world, port, q, eager, out_path):
         q.put((rank, traceback.format_exc(), False, None, None))
 
 
-@pytest.mark.parametrize('eager', [False, True])
-def test_ddp_step_equals_big_batch(eager, tmp_path):
+def _ddp_vs_big_batch(eager, tmp_path, backend):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
     out_path = str(tmp_path / 'g_ddp.pt')
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, eager, out_path)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, eager, out_path, backend)) for r in range(2)]
     for p in procs:
         p.start()
     try:
@@ -113,6 +112,37 @@ def test_ddp_step_equals_big_batch(eager, tmp_path):
         assert logs[0][k] == pytest.approx(float(v), rel=2e-3), (k, logs[0][k], float(v))
 
 
+@pytest.mark.parametrize('eager', [False, True])
+def test_ddp_step_equals_big_batch(eager, tmp_path):
+    _ddp_vs_big_batch(eager, tmp_path, 'gloo')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank: this box has fewer than 2')
+def test_ddp_step_equals_big_batch_rccl(tmp_path):
+    """The same check with backend "nccl" (= RCCL over xGMI) and one GPU per rank: the bucketed all-reduces run on the
+    communication stream behind the named events, the per-bucket optimizer path is NOT involved (gradients are compared).
+    Skipped on 1-GPU boxes; on a multi-GPU node it is RCCL's first contact with this code before the scaling bench."""
+    _ddp_vs_big_batch(True, tmp_path, 'nccl')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank: this box has fewer than 2')
+def test_bench_two_rank_rccl():
+    """`bench.py --gpus 2` exactly as the driver launches it (nccl, one GPU per rank), with the per-bucket communication
+    trace in the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+           '--no-prof']
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert j['n_gpus'] == 2 and j['value'] > 0 and len(j['extra']['comm']['buckets']) == 4
+
+
 def test_bench_two_rank_dry_run():
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU), here with both ranks on the
     one GPU of the box and gloo collectives (DSL_BENCH_ONE_GPU / DSL_DIST_BACKEND test hooks): the multi-rank path of the
@@ -135,3 +165,5 @@ def test_bench_two_rank_dry_run():
     assert j['config']['global_batch'] == 4 and j['config']['parallelism'] == 'dp2'
     assert j['value'] == pytest.approx(4 * 3 / (j['ms_per_step'] * 3e-3), rel=1e-3) and j['value'] > 0
     assert j['cpu_baseline'] is None and np.isfinite(j['final_losses']['loss'])
+    comm = j['extra']['comm']          # per gradient bucket: [MB, all-reduce start, done] in ms from the start of the step
+    assert len(comm['buckets']) == 4 and all(b['done_ms'] >= b['start_ms'] >= 0 for b in comm['buckets'])
