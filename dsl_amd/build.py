@@ -46,7 +46,9 @@ def build_lib(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+        # -Wl,--no-undefined: a kernel whose host stub hipcc dropped (a lambda with AMDGPU builtins inside a __global__ function
+        # fails its host-side instantiation silently) must fail the BUILD, not the first dlopen on the GPU box
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--no-undefined'] + objs + ['-o', LIB]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -941,6 +941,301 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   }
 }
 
+// NMF x { 1 MFMA, its share of the NRD fragment reads, 1 DMA piece for the first NVM }
+template <int I, int NMF, int NRD, int NVM>
+__device__ __forceinline__ void kt_sched() {
+  if constexpr (I < NMF) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int R = ((I + 1) * NRD) / NMF - (I * NRD) / NMF;
+    if constexpr (R > 0) __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+    if constexpr (I < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    kt_sched<I + 1, NMF, NRD, NVM>();
+  }
+}
+
+// ================================================================================================
+// v4 ("conv_kt"): the v3 kernel with the fragment pipeline at K-TILE granularity, for the tiles whose waves own one
+// 32-pixel MFMA column (128x128 on 8 waves, 128x64, 64x128, 64x64: 2 MFMAs per k-step per wave).  Measured on the layer3
+// shapes (tools/conv_cost.py): v3 spends ~1500 cycles per K tile where MFMA needs 512 and DMA issue ~600, and removing
+// either changes nothing - the k-step loop is bound by LDS read LATENCY: the reads of k-step kk+1 are issued only 2 MFMAs
+// (64 cycles) before their use.  Here a wave reads all 4 k-steps of tile kt+1 (12 ds_read_b128, 48 VGPRs) while it runs the 8
+// MFMAs of tile kt: the latency is paid once per tile and hidden under a whole tile of MFMAs.  The ring slot of tile kt+1 is
+// read during tile kt, so a tile must have landed one iteration earlier than in v3: NST = 3 for the same look-ahead.
+// ================================================================================================
+template <int BCO, int BPX, int WCO, int WPX, int NST>
+__device__ __forceinline__ void conv_kt_body(const ConvK& p, unsigned char* smem) {
+  // (a __device__ function, not the kernel itself: lambdas inside a __global__ function are implicitly __host__ __device__, and
+  // one that contains AMDGPU builtins silently costs the kernel its host stub)
+  constexpr int T = 64 * WCO * WPX;
+  constexpr int RPP = T / 8;                 // tile rows filled per pass (8 lanes per 128-byte row)
+  constexpr int WPASS = BCO / RPP, XPASS = BPX / RPP;
+  constexpr int TILE_W = BCO * 128;
+  constexpr int STAGE = (BCO + BPX) * 128;
+  constexpr int PT = BPX / WPX / 32;         // 32-pixel MFMA tiles per wave
+  static_assert(BCO / WCO == 64, "each wave owns 64 couts");
+  static_assert(BCO % RPP == 0 && BPX % RPP == 0 && (BPX / WPX) % 32 == 0, "tile/thread mismatch");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_co = wave / WPX, wave_px = wave % WPX;
+  // XCD-aware tile order (workgroups are dealt round-robin to the XCDs: equal b % 8 = same XCD): every XCD owns a contiguous run of tiles in (cout tile
+  // fastest, then pixel tile, then K split) order, so neighbouring pixel tiles - which share their halo rows - and
+  // the cout tiles of one pixel range hit the same L2 instead of being fetched into up to three of them.
+#ifdef DSL_ABLATE_BUILD
+  if (p.dbg & 128) return;                   // launch + dispatch floor
+#endif
+  const int wi = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.xcd_chunk || wi >= p.gx * p.gy * p.splits) return;
+  const int bz = wi / (p.gx * p.gy);
+  const int rem_t = wi - bz * (p.gx * p.gy);
+  const int by = rem_t / p.gx;
+  const int co0 = (rem_t - by * p.gx) * BCO;
+  const int px0 = by * BPX;
+  const int totpx = p.pxstart[p.nseg];
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ ((tid >> 4) & 7);     // source chunk that belongs in LDS slot (tid & 7) of this row
+
+  // buffer resources: base shifted back by `margin` so that every VALID tap has a non-negative per-lane offset
+  // (the hardware range-checks the per-lane offset, not the scalar one)
+  const unsigned margin = (unsigned)(p.kw * p.lds * 2);
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.src) - margin), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, 0x7fffffff, 0x00020000);
+
+  const int kt0 = bz * p.kt_per_split;
+#ifdef DSL_ABLATE_BUILD
+  const int kt1 = (p.dbg & 8) ? kt0 + 1 : min(kt0 + p.kt_per_split, p.ktiles);
+#else
+  const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+#endif
+  // ---- per-lane gather state of the XPASS pixel rows this lane fills (constant over the K loop)
+  unsigned r_base[XPASS], r_step[XPASS], r_mask[XPASS];
+#pragma unroll
+  for (int i = 0; i < XPASS; ++i) {
+    const int gp = px0 + lrow + RPP * i;
+    int seg = 0, img = 0, y = 0, x = 0;
+    const bool ok = gp < totpx;
+    if (ok) decode_pixel(p, gp, seg, img, y, x);
+    const int sh = p.sh[seg], sw = p.sw[seg];
+    const int row0 = p.mode == 0 ? y * p.stride - p.pad : y + p.pad;               // source row of tap r = 0
+    const int col0 = p.mode == 0 ? x * p.stride - p.pad : x + p.pad - (p.kw - 1);  // leftmost source column
+    unsigned m = 0;
+    for (int r = 0; r < p.kh; ++r) {
+      const int sy = p.mode == 0 ? row0 + r : row0 - r;
+      if (ok && (unsigned)sy < (unsigned)sh) m |= 1u << r;
+    }
+    for (int s_ = 0; s_ < p.kw; ++s_) {
+      const int sx = p.mode == 0 ? col0 + s_ : x + p.pad - s_;
+      if (ok && (unsigned)sx < (unsigned)sw) m |= 0x100u << s_;
+    }
+    r_mask[i] = m;
+    const unsigned pitch = (unsigned)(sw * p.lds * 2);
+    r_step[i] = p.mode == 0 ? pitch : 0u - pitch;
+    r_base[i] = (unsigned)(((int)(p.soff[seg]) + img * sh * sw + row0 * sw + col0) * p.lds + chunk * 8) * 2u + margin;
+  }
+  const unsigned w_voff = (unsigned)(lrow * (int)p.wrow + chunk * 8) * 2u;
+  const unsigned w_pass = (unsigned)(RPP * (int)p.wrow) * 2u;
+  constexpr int LPT = WPASS + XPASS;
+
+  // ---- DMA-side state.  Everything a tile's LPT DMA instructions need is ready-made: per-lane offsets xv[] (the pixel row
+  // at the current tap, or out of range), wv (weights), scalar offsets s_pix / s_w, the ring slot's LDS base.  The per-tile
+  // update is three scalar adds; a new tap (every kc tiles) and the end of the K range are rare uniform branches.  (v3 redid the
+  // tap / mask / wrap arithmetic branch-free for every tile: ~60 SALU + ~25 VALU per 8 MFMAs - the K loop of the small tiles
+  // was bound by instruction issue, tools/pmc_conv.sh.)
+  const int kc_ = p.kc, kw_ = p.kw, mode_ = p.mode, lds2_ = p.lds * 2;      // (locals: the K loop must not touch the argument struct)
+  int d_c = kt0 % kc_;                                          // channel slice of the tile being fetched
+  int d_tr = (kt0 / kc_) / kw_, d_ts = (kt0 / kc_) % kw_;       // ... and its tap
+  int d_left = kt1 - kt0;                                       // live tiles still to fetch
+  unsigned xv[XPASS], wv = w_voff;
+  unsigned s_pix = 0, s_w = (unsigned)(co0 * (int)p.wrow + kt0 * BK) * 2u;
+  unsigned ld_base = 0;                                         // LDS offset of the slot being filled
+  // (plain statements and one-level lambdas only: a lambda that calls another by-reference lambda keeps the captured scalars in
+  // memory, and every value loaded back from scratch counts as divergent - the DMA offsets then go through waterfall loops)
+#define KT_TAP_SETUP()                                                                                                   \
+  do {                                                                                                                   \
+    const unsigned sel_ = (1u << d_tr) | (0x100u << d_ts);                                                               \
+    for (int j_ = 0; j_ < XPASS; ++j_)                                                                                   \
+      xv[j_] = (r_mask[j_] & sel_) == sel_ ? r_base[j_] + (unsigned)d_tr * r_step[j_] : 0x80000000u;                      \
+    s_pix = (unsigned)((mode_ == 0 ? d_ts : kw_ - 1 - d_ts) * lds2_ + d_c * 128);                                        \
+  } while (0)
+  KT_TAP_SETUP();
+  if (d_left <= 0) {
+#pragma unroll
+    for (int j = 0; j < XPASS; ++j) xv[j] = 0x80000000u;
+    wv = 0x80000000u;
+  }
+  const unsigned lw = (unsigned)(wave * 8 * 128);
+  auto piece = [&](int j) {            // j is a constant after unrolling
+#ifdef DSL_ABLATE_BUILD
+    if (p.dbg & (j < XPASS ? 1 : 2)) return;
+#endif
+    if (j < XPASS)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lptr_t)(smem + ld_base + lw + TILE_W + j * RPP * 128), 16, xv[j], s_pix, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lptr_t)(smem + ld_base + lw + (j - XPASS) * RPP * 128), 16, wv,
+                                               s_w + (unsigned)(j - XPASS) * w_pass, 0, 0);
+  };
+  auto advance = [&]() {               // the tile's pieces are all issued
+    s_pix += 128;
+    s_w += BK * 2;
+    ld_base = ld_base + STAGE == NST * STAGE ? 0u : ld_base + STAGE;
+    --d_left;
+    ++d_c;
+    if (d_left == 0) {                 // past the K range: zeros from here on (fixed DMA count per iteration, see v3)
+#pragma unroll
+      for (int j = 0; j < XPASS; ++j) xv[j] = 0x80000000u;
+      wv = 0x80000000u;
+    } else if (d_c == kc_) {           // next tap
+      d_c = 0;
+      if (++d_ts == kw_) {
+        d_ts = 0;
+        ++d_tr;
+      }
+      KT_TAP_SETUP();
+    }
+  };
+
+#ifdef DSL_ABLATE_BUILD
+  if (p.dbg & 256) return;                   // + kernel-argument loads and the per-pixel decode
+#endif
+  f32x16 acc[2][PT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int fswz = (frow >> 1) & 7;
+  const int a_off = (wave_co * 64 + frow) * 128;
+  const int b_off = TILE_W + (wave_px * (32 * PT) + frow) * 128;
+  // fragments of a WHOLE K tile per buffer (4 k-steps x (2 A + PT B)), two buffers: the reads of tile kt+1 are issued
+  // between the MFMAs of tile kt, one full tile (>= 256 MFMA cycles per wave) before their first use
+  bf16x8 fa[2][4][2], fb[2][4][PT];
+  auto read_all = [&](const unsigned char* base, int f) {
+#ifdef DSL_ABLATE_BUILD
+    if (p.dbg & 64) return;
+#endif
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) fa[f][kk][ct] = *reinterpret_cast<const bf16x8*>(base + a_off + ct * 32 * 128 + coff);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) fb[f][kk][pt] = *reinterpret_cast<const bf16x8*>(base + b_off + pt * 32 * 128 + coff);
+    }
+  };
+  auto mma_all = [&](int f) {
+#ifdef DSL_ABLATE_BUILD
+    if (p.dbg & 4) return;
+#endif
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+          acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][kk][ct], fb[f][kk][pt], acc[ct][pt], 0, 0, 0);
+  };
+  constexpr int NMF = 8 * PT, NRD = 4 * (2 + PT);
+  static_assert(NST * LPT <= 63, "vmcnt range");
+  // prologue: all NST slots filled (tiles kt0 .. kt0+NST-1), tile kt0's fragments on their way to buffer 0
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) piece(j);
+    advance();
+  }
+  wait_vmcnt<(NST - 1) * LPT>();
+  __builtin_amdgcn_s_barrier();
+  read_all(smem, 0);
+  unsigned rd_base = 0;                  // LDS offset of the slot whose fragments are read NEXT (tile kt+1)
+  // (no generic lambdas here: a lambda with AMDGPU builtins that is called from inside a generic lambda fails substitution in
+  // hipcc's HOST pass, and the kernel silently loses its host stub - an undefined symbol at load time)
+  auto iter = [&](int f) {             // f is a constant after inlining
+    rd_base = rd_base + STAGE == NST * STAGE ? 0u : rd_base + STAGE;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of tile kt are in registers
+    wait_vmcnt<(NST - 2) * LPT>();                         // tile kt+1 landed (this wave's pieces)
+#ifdef DSL_ABLATE_BUILD
+    if (!(p.dbg & 32))
+#endif
+    __builtin_amdgcn_s_barrier();                          // ... for every wave; slot(kt) is free
+    read_all(smem + rd_base, f ^ 1);
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) piece(j);                // tile kt+NST -> the slot tile kt just vacated
+    mma_all(f);
+    kt_sched<0, NMF, NRD, LPT>();
+    __builtin_amdgcn_sched_barrier(0);
+    advance();
+  };
+  // an even number of iterations (the buffer index is a compile-time constant): a tile past kt1 is all zeros (out-of-range DMAs)
+  for (int kt = kt0; kt < kt1; kt += 2) {
+    iter(0);
+    iter(1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wait_vmcnt<0>();                         // the out-of-range tail DMAs still write (zeros) into the ring
+#ifdef DSL_ABLATE_BUILD
+  if (p.dbg & 16) return;
+#endif
+
+  if (p.splits > 1) {                      // split-K: raw fp32 partial tile -> workspace [split][pixel][cd_pad]
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int gp = px0 + wave_px * (32 * PT) + pt * 32 + (lane & 31);
+      if (gp >= totpx) continue;
+      float* row = p.ws + ((long long)bz * totpx + gp) * p.cd_pad;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = co0 + wave_co * 64 + ct * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(row + co) = o;
+        }
+    }
+    return;
+  }
+
+  // ---- epilogue staged through LDS (see conv_glds_kernel)
+  constexpr int ROWB = BCO * 4 + 16;
+  constexpr int CPX = 32 * WPX;
+  constexpr int GPR = BCO / 8;
+  static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wave_co * 64 + ct * 32 + 8 * g + 4 * fhalf;
+        f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
+      }
+    __syncthreads();
+    for (int id = tid; id < CPX * GPR; id += T) {
+      const int pl = id / GPR, cg = id - pl * GPR;
+      const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
+      const int co = co0 + cg * 8;
+      if (gp >= totpx || co >= p.cd) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32 + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      long long dpix, apix;
+      conv_out_index(p, gp, dpix, apix);
+      conv_epilogue8(p, dpix, apix, co, v);
+    }
+  }
+}
+
+template <int BCO, int BPX, int WCO, int WPX, int NST>
+__global__ __launch_bounds__(64 * WCO * WPX) void conv_kt_kernel(const ConvK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  conv_kt_body<BCO, BPX, WCO, WPX, NST>(p, smem);
+}
+
 // ================================================================================================
 // weight gradient
 // ================================================================================================
@@ -2293,7 +2588,39 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     }                                                                                                         \
     hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_>), dim3(8 * k.xcd_chunk), dim3(64 * C_ * D), lds, st, k); \
   } while (0)
-    if (force_v2_kernel) {
+    // v4 (K-tile-granular fragment pipeline, lean per-tile bookkeeping) for the one-MFMA-column tiles: DSL_CONV_KT = 0 off
+    // (default), 1 where the launch has at most one workgroup per CU, 2 always.  Measured and rejected (tools/conv_cost.py,
+    // tools/pmc_conv.sh): it halves the instructions per K tile and takes the LDS latency off the k-step chain (SQ_WAIT_ANY
+    // 47 % -> 32 % of wave cycles), but the layer3 / layer4 shapes run within 4 % of v3 either way and the step is slower (372
+    // vs 386 img/s: one workgroup per CU) - these launches are bound by the 64 B/clk/CU L2 -> LDS path ((BCO + BPX) x 128 B per
+    // K tile: 32 KB per 512 MFMA cycles for 128 x 128), not by issue or latency; only operand reuse across taps would cut that.
+    static const int kt_mode = [] { const char* e = getenv("DSL_CONV_KT"); return e ? atoi(e) : 0; }();
+    const long long n_wg = (long long)grid.x * grid.y * grid.z;
+    const bool use_kt = !force_v2_kernel && !smallc && (pick == 3 || pick == 5 || pick == 6 || pick == 7) &&
+                        (kt_mode == 2 || (kt_mode == 1 && n_wg <= 256LL * c.occ));
+    if (use_kt) {
+      constexpr int KT_NST = 3;
+      size_t ldk = (size_t)KT_NST * (c.bco + c.bpx) * 128;
+      const size_t stg = (size_t)32 * c.wpx * (c.bco * 4 + 16);
+      if (stg > ldk) ldk = stg;
+#define LAUNCHK(A, B, C_, D)                                                                                  \
+  do {                                                                                                        \
+    static bool attr_k = false;                                                                               \
+    if (!attr_k) {                                                                                            \
+      hipFuncSetAttribute((const void*)conv_kt_kernel<A, B, C_, D, KT_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)ldk);                                                                          \
+      attr_k = true;                                                                                          \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_kt_kernel<A, B, C_, D, KT_NST>), dim3(8 * k.xcd_chunk), dim3(64 * C_ * D), ldk, st, k); \
+  } while (0)
+      switch (pick) {
+        case 3: LAUNCHK(128, 128, 2, 4); break;
+        case 5: LAUNCHK(128, 64, 2, 2); break;
+        case 6: LAUNCHK(64, 64, 1, 2); break;
+        default: LAUNCHK(64, 128, 1, 4); break;
+      }
+#undef LAUNCHK
+    } else if (force_v2_kernel) {
       switch (pick) {
         case 0: LAUNCH2(256, 192, 4, 2, 2); break;
         case 1: LAUNCH2(256, 128, 4, 2, 3); break;
