@@ -98,7 +98,7 @@ def cpu_baseline(batch, seed=0, warmup=1, steps=2):
                        + ', '.join(f'{t:.1f}' for t in times) + ' s'), losses
 
 
-def dsl_iteration_timing(steps=10, warm=4):
+def dsl_iteration_timing(steps=12, warm=6, variants=None):
     """BASELINE.json configs[2] beside the headline line: the semi-supervised iteration - labeled + unlabeled image and the
     half-scale copy (N = 3 through the student), ignore boxes, loss_weight 3, sisoft, clip, SGD, EMA teacher update every
     iteration - without and with the teacher's pseudo-label refresh of the upcoming unlabeled image (self-scheduled
@@ -109,7 +109,7 @@ def dsl_iteration_timing(steps=10, warm=4):
     from dsl_amd.registry import build_detector
     from dsl_amd.runner import EMAOWNHook, OptimizerHook, SemiEpochBasedRunner, UnlabelPredHook
     out = {}
-    for refresh, rla, asyn in ((False, False, False), (True, False, False), (True, False, True), (True, True, False)):
+    for refresh, rla, asyn in variants or ((False, False, False), (True, False, False), (True, False, True), (True, True, False)):
         student, teacher = build_detector(model_cfg(dsl=True, rla=rla)).cuda(), build_detector(model_cfg(dsl=True, rla=rla)).cuda()
         if rla:
             import warnings
@@ -136,7 +136,7 @@ def dsl_iteration_timing(steps=10, warm=4):
                                    interval_mode='iteration', interval=1, bank=bank)
             hook.iter_fuse_flag = True          # steady state: the initial full sweep is not part of an iteration's cost
             runner.register_hook(hook, priority=50)
-        marks = {}
+        evs = []
 
         class Clock:
             priority = 90
@@ -145,17 +145,23 @@ def dsl_iteration_timing(steps=10, warm=4):
                 return lambda r: None
 
             def after_train_iter(self, r):
-                if r.iter + 1 == warm:
-                    torch.cuda.synchronize()
-                    marks['t0'] = time.perf_counter()
+                if r.iter + 1 >= warm:          # one event per iteration on the training stream (stream order = iteration order)
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    evs.append(e)
         runner.register_hook(Clock(), priority=90)
         runner.run([loader], max_epochs=1)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - marks['t0']) / steps
+        # median of the per-iteration intervals: a one-off stall inside the window (first use of a new shape, an allocator
+        # hiccup after the previous variant's teardown - the 13 <-> 18 ms spread of round 2's record) does not move it
+        gaps = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
+        dt = gaps[len(gaps) // 2] * 1e-3
+        out.setdefault('spread', {})
         if os.environ.get('DSL_BENCH_VERBOSE'):
             print(f'dsl_iteration refresh={refresh} rla={rla} async={asyn}: {dt * 1e3:.3f} ms', file=sys.stderr, flush=True)
         key = 'ms_per_iter' if not refresh else ('ms_per_iter_with_teacher_refresh' + ('_async' if asyn else '') + ('_rla_backbone' if rla else ''))
         out[key] = round(dt * 1e3, 3)
+        out['spread'][key] = [round(gaps[0], 3), round(gaps[-1], 3)]           # min / max interval, ms
         del student, teacher, runner, opt, loader
         torch.cuda.empty_cache()
     out['imgs_per_iter'] = 2
@@ -274,6 +280,16 @@ def main():
         if hit:
             traffic = tj['kernels'][hit[0]]['hbm_bytes_per_launch']
             traffic_src = 'profiles/traffic.json: ' + tj.get('source', '')
+    # MFMA-pipe busy fraction of the kernel classes from the SQ counters of the same separate --pmc pass (profiles/pmc_sq.json)
+    mfma_busy = None
+    sf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_sq.json')
+    if os.path.exists(sf):
+        sj = json.load(open(sf)).get('kernels', {})
+        pick = lambda pre: next((v for k, v in sj.items() if k.startswith(pre)), None)
+        mfma_busy = {name: (dict(mfma_busy_frac=v['mfma_busy_frac'], wait_any_frac=v['wait_any_frac'], avg_us=v['avg_us']) if v else None)
+                     for name, v in (('conv_128x128', pick(DOMINANT[:-1])), ('head_tile_256x192', pick('conv_pipe_kernel<256, 192')),
+                                     ('wgrad_256x256', pick('wgrad_pipe_kernel<256, 256')))}
+        mfma_busy['source'] = 'profiles/pmc_sq.json (separate rocprofv3 --pmc pass of this command; SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32))'
     if not args.no_prof:
         launches = (C.c_int64 * NC)()
         ms = (C.c_double * NC)()
@@ -313,6 +329,7 @@ def main():
                         head_phases_note='wall time on the caller\'s stream of the head (16 tower convs + 2 predictors + 8 GroupNorm '
                                          'passes per direction, the two towers side by side on two streams), uninstrumented kernels; '
                                          'the per-launch figures above stretch when two launches overlap',
+                        mfma_busy_frac=mfma_busy,
                         whole_step_frac=round(value / world * GFLOP_PER_IMAGE_STEP / 1e3 / PEAK_BF16_TFLOPS, 4))
     cpu = extra = None
     if world > 1:
@@ -334,6 +351,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_dsl:
         del opt
         extra = dict(dsl_iteration=dsl_iteration_timing())
+        if roof is not None:        # BASELINE.json configs[2] beside the headline, also where a record that keeps `roofline` keeps it
+            roof['configs2_dsl_iteration_ms'] = {k: v for k, v in extra['dsl_iteration'].items() if k.startswith('ms_per_iter')}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, _ = cpu_baseline(batch)
     if rank == 0:

@@ -62,9 +62,31 @@ def build_forward(plan, s1, h1, w1):
     xh = plan.buf('rla.xh.0.0', N * h * w, cx + RLA_PAD, zero=True)
     f._add(L.OP_MAXPOOL, i=(N, h1, w1, 64, cx + RLA_PAD), p=(s1, xh))
     plan.rla_blocks = []
+    import os
+    # image-split stages (as in Plan._fwd_resnet): the images of a batch are independent through the backbone - eval-mode
+    # BatchNorms, per-image recurrent state - so the batch runs through these stages as two chains of half-batch launches on two
+    # streams (DSL_RLA_SPLIT: stage indices, default 1, 2, 3; the DSL iteration has N = 3: images [0, 2) and [2, 3))
+    SPLIT = os.environ.get('DSL_RLA_SPLIT', '123') if (plan.BR and N >= 2 and plan.training) else ''
+    split_open = False
+
+    def br_ws(d_):
+        d_.workspace, d_.workspace_bytes = L.ptr(plan.conv_ws_br), plan.conv_ws_br.numel()
+        return d_
+
+    def rows(t, g0, hw, ld):
+        """Pointer to image g0's first row of a [N * hw][ld] bf16 tensor (or of a raw pointer into one)."""
+        return (t if isinstance(t, int) else t.data_ptr()) + g0 * hw * ld * 2
     for s_, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
         c4 = planes * 4
         co, rc = cv[f'backbone.conv_outs.{s_}'], cv[f'backbone.recurrent_convs.{s_}']
+        split = str(s_) in SPLIT
+        if split and not split_open:
+            f.fork(plan.BR)
+            split_open = True
+        elif split_open and not split:
+            f.join(plan.BR)
+            split_open = False
+        groups = [(0, (N + 1) // 2, 0), ((N + 1) // 2, N, plan.BR)] if split else [(0, N, 0)]
         for b in range(nb):
             p = f'backbone.stages.{s_}.{b}'
             c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
@@ -75,39 +97,51 @@ def build_forward(plan, s1, h1, w1):
             a2 = plan.buf(p + '.a2', N * oh * ow, planes)
             last = s_ == 3 and b == nb - 1
             nxt = plan.buf(f'rla.xh.{s_}.{b + 1}', N * oh * ow, c4 + RLA_PAD, zero=True)      # the next block's XH
-            f.conv(plan._conv(c1, xh, a1, N, [(h, w)], [(h, w)], relu=True, cs=ldx, lds=ldx))
-            f.conv(plan._conv(c2, a1, a2, N, [(h, w)], [(oh, ow)], relu=True))
-            if b == 0:
-                idt = plan.buf(p + '.idt', N * oh * ow, c4)
-                f.conv(plan._conv(cv[p + '.downsample.0'], xh, idt, N, [(h, w)], [(oh, ow)], cs=cx, lds=ldx))
-                idt_ld = c4
-            else:
-                idt, idt_ld = xh, ldx                      # the block input itself (x part of its rows)
-            f.conv(plan._conv(c3, a2, nxt, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt, lda=idt_ld, dst_ld=c4 + RLA_PAD))
+            idt = plan.buf(p + '.idt', N * oh * ow, c4) if b == 0 else None
             blk = dict(prefix=p, stage=s_, b=b, planes=planes, cx=cx, c4=c4, xh=xh, ldx=ldx, a1=a1, a2=a2, out=nxt,
                        ld_out=c4 + RLA_PAD, in_hw=(h, w), out_hw=(oh, ow), stride=stride, last=last, pooled=False)
             if not last:
-                h_ptr, h_ld = xh.data_ptr() + cx * 2, ldx       # h part of this block's input rows
-                if b == 0 and stride != 1:
-                    hp = plan.buf(p + '.hpool', N * oh * ow, RLA_C)
-                    _rla_op(f, L.RLA_AVGPOOL, p=(h_ptr, hp), i=(ldx, RLA_C, N, h, w, RLA_C))
-                    h_ptr, h_ld = hp.data_ptr(), RLA_C
-                    blk['pooled'] = True
+                pooled = b == 0 and stride != 1
+                hp = plan.buf(p + '.hpool', N * oh * ow, RLA_C) if pooled else None
                 u = plan.buf(p + '.u', N * oh * ow, RLA_C)
-                f.conv(plan._conv(co, nxt, u, N, [(oh, ow)], [(oh, ow)], cs=c4, lds=c4 + RLA_PAD, addend=h_ptr, lda=h_ld,
-                                  dst_ld=RLA_C, affine=False))
                 tw = rc.cin_store                              # 64 (frozen stage 0) / 128: T rows are as wide as the stored K
                 t = plan.buf(p + '.t', N * oh * ow, tw, zero=True)
                 bnn = f'backbone.stage_bns.{s_}.{b}'
                 sc, bi = st.bn_ptrs(bnn)
-                _rla_op(f, L.RLA_BN_TANH, p=(u, sc, bi, t), i=(RLA_C, tw, RLA_C), rows=N * oh * ow)
-                f.conv(plan._conv(rc, t, nxt.data_ptr() + c4 * 2, N, [(oh, ow)], [(oh, ow)], cs=tw, dst_ld=c4 + RLA_PAD,
-                                  affine=False))
-                blk.update(u=u, t=t, tw=tw, bn=bnn)
+                blk.update(u=u, t=t, tw=tw, bn=bnn, pooled=pooled)
+            ihw, ohw = h * w, oh * ow
+            for g0, g1, sd in groups:
+                n_ = g1 - g0
+                wsf = br_ws if sd else (lambda d_: d_)
+                xh_g, a1_g, a2_g, nxt_g = rows(xh, g0, ihw, ldx), rows(a1, g0, ihw, planes), rows(a2, g0, ohw, planes), rows(nxt, g0, ohw, c4 + RLA_PAD)
+                f.conv(wsf(plan._conv(c1, xh_g, a1_g, n_, [(h, w)], [(h, w)], relu=True, cs=ldx, lds=ldx)), side=sd)
+                f.conv(wsf(plan._conv(c2, a1_g, a2_g, n_, [(h, w)], [(oh, ow)], relu=True)), side=sd)
+                if b == 0:
+                    idt_g, idt_ld = rows(idt, g0, ohw, c4), c4
+                    f.conv(wsf(plan._conv(cv[p + '.downsample.0'], xh_g, idt_g, n_, [(h, w)], [(oh, ow)], cs=cx, lds=ldx)), side=sd)
+                else:
+                    idt_g, idt_ld = xh_g, ldx                  # the block input itself (x part of its rows)
+                f.conv(wsf(plan._conv(c3, a2_g, nxt_g, n_, [(oh, ow)], [(oh, ow)], relu=True, addend=idt_g, lda=idt_ld,
+                                      dst_ld=c4 + RLA_PAD)), side=sd)
+                if not last:
+                    h_ptr, h_ld = xh_g + cx * 2, ldx           # h part of this block's input rows
+                    if blk['pooled']:
+                        hp_g = rows(hp, g0, ohw, RLA_C)
+                        _rla_op(f, L.RLA_AVGPOOL, p=(h_ptr, hp_g), i=(ldx, RLA_C, n_, h, w, RLA_C), side=sd)
+                        h_ptr, h_ld = hp_g, RLA_C
+                    u_g, t_g = rows(u, g0, ohw, RLA_C), rows(t, g0, ohw, tw)
+                    f.conv(wsf(plan._conv(co, nxt_g, u_g, n_, [(oh, ow)], [(oh, ow)], cs=c4, lds=c4 + RLA_PAD, addend=h_ptr, lda=h_ld,
+                                          dst_ld=RLA_C, affine=False)), side=sd)
+                    _rla_op(f, L.RLA_BN_TANH, p=(u_g, sc, bi, t_g), i=(RLA_C, tw, RLA_C), rows=n_ * ohw, side=sd)
+                    f.conv(wsf(plan._conv(rc, t_g, nxt_g + c4 * 2, n_, [(oh, ow)], [(oh, ow)], cs=tw, dst_ld=c4 + RLA_PAD,
+                                          affine=False)), side=sd)
             plan.rla_blocks.append(blk)
             xh, cx, h, w = nxt, c4, oh, ow
         plan.stage_out.append((xh, (h, w)))
         plan.stage_ld.append(c4 + RLA_PAD)
+    if split_open:
+        f.join(plan.BR)
+    plan._keep_rla = getattr(plan, '_keep_rla', [])
 
 
 def build_backward(plan, buckets, SIDE):

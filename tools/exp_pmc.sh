@@ -16,7 +16,7 @@ F=$(find gpurun_out/pmc_${TAG}_FETCH_SIZE -name '*_results.db' | head -1)
 W=$(find gpurun_out/pmc_${TAG}_WRITE_SIZE -name '*_results.db' | head -1)
 S=$(find gpurun_out/pmc_${TAG}_SQ -name '*_results.db' | head -1)
 python tools/pmc_traffic.py $F $W gpurun_out/${TAG}_traffic.json gpurun_out/${TAG}_bench_prof.log > gpurun_out/${TAG}_pmc_traffic.txt 2>&1
-python tools/pmc_summary.py $S > gpurun_out/${TAG}_pmc_sq.txt 2>&1
+python tools/pmc_summary.py $S gpurun_out/${TAG}_pmc_sq.json > gpurun_out/${TAG}_pmc_sq.txt 2>&1
 rm -rf gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE gpurun_out/pmc_${TAG}_SQ
 head -12 gpurun_out/${TAG}_pmc_traffic.txt
 head -40 gpurun_out/${TAG}_pmc_sq.txt

@@ -51,7 +51,7 @@ for k, v in out.items():
 wg = [(v['launches'], v['hbm_bytes_per_launch']) for k, v in out.items() if k.startswith('wgrad')]
 if wg and algo.get('wgrad (all launches, average)'):
     tot = sum(n * b for n, b in wg)
-    nl = sum(n for k, v in out.items() if k.startswith('wgrad_glds') for n in [v['launches']])
+    nl = sum(v['launches'] for k, v in out.items() if k.startswith(('wgrad_glds', 'wgrad_pipe')))
     out['wgrad (all launches, average)'] = dict(launches=nl, hbm_bytes_per_launch=round(tot / max(nl, 1)),
                                                 algorithmic_bytes_per_launch=algo['wgrad (all launches, average)'],
                                                 measured_over_algorithmic=round(tot / max(nl, 1) / algo['wgrad (all launches, average)'], 2),
