@@ -552,7 +552,7 @@ class Plan:
                     bregion='head.cls_b', side=SIDE)
         self._wgrad(ol, None, lp.g_rc, self.tower['reg_convs'][3]['act'], N, ls, ls, cy=64, cd=5, wregion='head.regctr_w',
                     bregion='head.regctr_b', side=SIDE)
-        # (measured, tools/exp_r2t.sh / exp_r2u.sh: weight gradients that start while the head's large data-gradient launches
+        # (measured, tools/experiments_r2.txt (exp_r2t) / exp_r2u.sh: weight gradients that start while the head's large data-gradient launches
         # still run cost more than the idle side stream saves - predictors first: 5.97 vs 5.94 ms, tower halves: 6.10 vs 6.05)
         if os.environ.get('DSL_PRED_EARLY', '0') != '0':
             self._flush_wgrads(ol, side=SIDE)
@@ -582,7 +582,7 @@ class Plan:
                                  dbias=st.t32_ptr(lay['spec'].name + '.bias', st.grad))
                 ol.gn_bwd(gd, side=sd)
                 tower_group.append(self._wgrad(ol, lay['spec'], g_pre[tower], lay['xin'], N, ls, ls, side=SIDE, emit=False, no_db=True,
-                                               slots=int(os.environ.get('DSL_TOWER_SLOTS', '72'))))     # measured: tools/exp_r2z.sh (48-128: 5.84 ms, 160-192: 5.89); round 3: 72 / 96 / 128: 5.435 / 5.461 / 5.456
+                                               slots=int(os.environ.get('DSL_TOWER_SLOTS', '72'))))     # measured: tools/experiments_r2.txt (exp_r2z) (48-128: 5.84 ms, 160-192: 5.89); round 3: 72 / 96 / 128: 5.435 / 5.461 / 5.456
             if (HALVES and i in (2, 0)) or i == 0:
                 if BT and SIDE:
                     ol.fork(1, other=BT)       # the weight-gradient stream also waits for the regression tower's stream
@@ -792,7 +792,7 @@ class Plan:
                 ol.record(L.SLOT_TAIL, stream=0)       # from here on the next step's frozen prefix may run beside this pass
             if GROUP and (li > 1 or GROUP_LAST):
                 # last segment: the caller's stream has nothing left to do, it takes part of the groups itself
-                on_main = os.environ.get('DSL_TAIL_MAIN', '2') if li == 1 else '0'     # measured: tools/exp_r2w.sh
+                on_main = os.environ.get('DSL_TAIL_MAIN', '2') if li == 1 else '0'     # measured: tools/experiments_r2.txt (exp_r2w)
                 order = sorted(((3, g3), (2, g2), (1, g1)), key=lambda t: str(t[0]) in on_main)     # side-stream groups first: one FORK
                 for gi, grp_descs in order:
                     mine = str(gi) in on_main

@@ -12,7 +12,7 @@ from .registry import OPTIMIZERS
 
 
 _BUCKET_SGD = os.environ.get('DSL_BUCKET_SGD', '1') != '0'    # per-bucket optimizer steps beside the backward pass (no clipping only)
-_PACK_SIDE = os.environ.get('DSL_PACK_SIDE', '1') != '0'     # data-gradient weight packs off the caller's stream (measured: tools/exp_r2l.sh)
+_PACK_SIDE = os.environ.get('DSL_PACK_SIDE', '1') != '0'     # data-gradient weight packs off the caller's stream (measured: tools/experiments_r2.txt (exp_r2l))
 
 
 @OPTIMIZERS.register_module(name='SGD')

@@ -12,6 +12,8 @@ done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
   -d $R/gpurun_out/pmc_${TAG}_SQ -o p -- $CMD > $R/gpurun_out/pmc_${TAG}_SQ.log 2>&1
 cd $R
+# the algorithmic bytes per launch of the kernel classes come from an (instrumented) bench.py run's roofline object
+python bench.py --no-cpu-baseline --no-dsl > gpurun_out/${TAG}_bench_prof.log 2>&1
 F=$(find gpurun_out/pmc_${TAG}_FETCH_SIZE -name '*_results.db' | head -1)
 W=$(find gpurun_out/pmc_${TAG}_WRITE_SIZE -name '*_results.db' | head -1)
 S=$(find gpurun_out/pmc_${TAG}_SQ -name '*_results.db' | head -1)
