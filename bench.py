@@ -26,7 +26,7 @@ PEAK_HBM_GBS = 8000.0              # HBM3E spec (same guide; ~6.3 TB/s achievabl
 DOMINANT = 'conv_pipe_kernel<128, 128, 2, 4, 2>'    # the kernel class 0 of dsl_prof_* brackets (largest share of the step)
 
 
-def model_cfg(dsl=False, rla=False):
+def model_cfg(dsl=False, rla=False, fp8=False):
     head = dict(type='FCOSHead', num_classes=80, in_channels=256, stacked_convs=4, feat_channels=256,
                 strides=[8, 16, 32, 64, 128], norm_on_bbox=True, centerness_on_reg=True, dcn_on_last_conv=False,
                 center_sampling=True, conv_bias=True,
@@ -39,7 +39,7 @@ def model_cfg(dsl=False, rla=False):
                     norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='caffe')
     if rla:     # the backbone the reference's DSL config names (configs/fcos_semi/RLA_*.py:3-13)
         backbone = dict(type='RLA_ResNet', layers=[3, 4, 6, 3], frozen_stages=1, norm_eval=True, style='pytorch')
-    return dict(type='FCOS',
+    return dict(type='FCOS', **(dict(fp8=dict(layers='towers')) if fp8 else {}),
                 backbone=backbone,
                 neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
                           add_extra_convs='on_output', num_outs=5, relu_before_extra_convs=True),
@@ -70,6 +70,39 @@ def synth_batch(rank, n_img=2, H=800, W=1344, device='cuda'):
         gtl.append(torch.from_numpy(rng.randint(0, 80, len(b)).astype('int64')))
     metas = [dict(img_shape=(800, 1333, 3), pad_shape=(H, W, 3), scale_factor=1.0) for _ in range(n_img)]
     return dict(img=img.to(device), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
+
+
+def fp8_step_timing(batch, steps=20, warm=5):
+    """BASELINE.json configs[4], first slice (beside the bf16 headline, never instead of it): the same supervised step with the head
+    towers' forward convolutions on the fp8 MFMA path (FCOS(fp8=dict(layers='towers')), dynamic per-tensor activation scales)."""
+    from dsl_amd.data import mark_ready
+    from dsl_amd.optim import FlatSGD
+    from dsl_amd.registry import build_detector
+    model = build_detector(model_cfg(fp8=True)).cuda()
+    model.lazy_log = True
+    model.eager_backward = True
+    opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+    mark_ready(batch['img'])
+
+    def step():
+        out = model.train_step(batch, opt)
+        out['loss'].backward()
+        opt.step()
+        return out
+    for _ in range(warm):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    losses = {k: round(float(v), 4) for k, v in out['log_vars'].items()}
+    del model, opt
+    torch.cuda.empty_cache()
+    return dict(imgs_per_s=round(len(batch['img_metas']) / dt, 1), ms_per_step=round(dt * 1e3, 3), final_losses=losses,
+                note='same step, batch and optimizer as the headline; forward of the 8 tower convolutions in OCP e4m3 on '
+                     'v_mfma_scale_f32_32x32x64_f8f6f4, everything else (and the whole backward pass) bf16; off by default in the product')
 
 
 def cpu_baseline(batch, seed=0, warmup=1, steps=2):
@@ -350,7 +383,7 @@ def main():
                                     'its all-reduce is done (per-bucket SGD), so only traffic still in flight at step_ms is exposed'))
     if rank == 0 and world == 1 and not args.no_dsl:
         del opt
-        extra = dict(dsl_iteration=dsl_iteration_timing())
+        extra = dict(dsl_iteration=dsl_iteration_timing(), fp8_towers=fp8_step_timing(batch))
         if roof is not None:        # BASELINE.json configs[2] beside the headline, also where a record that keeps `roofline` keeps it
             roof['configs2_dsl_iteration_ms'] = {k: v for k, v in extra['dsl_iteration'].items() if k.startswith('ms_per_iter')}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

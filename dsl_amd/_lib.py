@@ -22,6 +22,7 @@ F5 = C.c_float * MAX_SEG
 # conv flags / op kinds (mirror the enums of dsl_hip.h)
 CONV_RELU_OUT, CONV_RELU_IN, CONV_OUT_F32, CONV_MASK_FIRST, CONV_MASK_LAST, CONV_ADD_UPSAMPLE, \
     CONV_SMALL_C = 1, 2, 4, 8, 16, 32, 64
+CONV_FP8 = 128
 (OP_CONV, OP_WGRAD, OP_GN_FWD, OP_GN_BWD, OP_MAXPOOL, OP_SUM2X2, OP_COLSUM, OP_MEMSET, OP_PACK_IMAGE,
  OP_ASSIGN, OP_LOSS, OP_FORK, OP_JOIN, OP_WGRAD_GROUP, OP_RECORD, OP_WAIT) = range(1, 17)
 OP_RLA = 17
@@ -29,6 +30,7 @@ OP_PACK_DGRAD = 18
 OP_WGRAD_MULTI = 19
 OP_PAIR = 20
 OP_PROF = 21
+OP_QUANT_FP8, OP_QUANT_FP8_W, OP_FP8_COMB = 22, 23, 24
 PROF_CLASSES = 8
 MAX_MULTI = 16
 SLOT_TAIL, SLOT_PREFIX = 13, 14     # pipelined frozen prefix: 'previous backward's data-gradient chain done', 'prefix of this step done'
@@ -162,6 +164,8 @@ _SIGS = {
     'dsl_avgpool2x2_bwd': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_bn_tanh_fwd': [_vp, _i, _vp, _vp, _vp, _i, _l, _i, _vp], 'dsl_bn_tanh_bwd_workspace_bytes': [_l, _i],
     'dsl_bn_tanh_bwd': [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
+    'dsl_quant_fp8': [_vp, _vp, _l, _i, _i, _f, _vp], 'dsl_absmax': [_vp, _l, _i, _i, _vp, _i, _vp],
+    'dsl_quant_fp8_dyn': [_vp, _vp, _l, _i, _i, _vp, _i, _vp], 'dsl_fp8_comb': [_vp, _vp, _i, _vp, _i, _vp], 'dsl_quant_fp8_weights': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'dsl_bn_fold': [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp], 'dsl_bn_wgrad_post': [_vp, _i, _i, _f, _vp], 'dsl_rla_op': [_vp, _vp],
     'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp], 'dsl_groupnorm_workspace_bytes': [_vp],
     'dsl_sum2x2': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], 'dsl_colsum': [_vp, _vp, _l, _i, _i, _vp],

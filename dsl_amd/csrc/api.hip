@@ -144,6 +144,26 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
       case DSL_OP_PACK_IMAGE: rc = dsl_pack_image((const float*)o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], stream); break;
       case DSL_OP_ASSIGN: rc = dsl_fcos_assign((const dsl_fcos_desc*)o.desc, stream); break;
       case DSL_OP_LOSS: rc = dsl_fcos_loss((const dsl_fcos_desc*)o.desc, stream); break;
+      case DSL_OP_QUANT_FP8: {
+        float sc;
+        const int32_t bits = (int32_t)o.l[1];
+        memcpy(&sc, &bits, 4);
+        if (o.p[2]) {
+          rc = dsl_absmax(o.p[0], (long)o.l[0], o.i[0], o.i[1], (float*)o.p[2], o.i[2], stream);
+          if (rc == 0) rc = dsl_quant_fp8_dyn(o.p[0], o.p[1], (long)o.l[0], o.i[0], o.i[1], (const float*)o.p[2], o.i[2], stream);
+        } else {
+          rc = dsl_quant_fp8(o.p[0], o.p[1], (long)o.l[0], o.i[0], o.i[1], sc, stream);
+        }
+        break;
+      }
+      case DSL_OP_FP8_COMB: rc = dsl_fp8_comb((const float*)o.p[0], (float*)o.p[1], o.i[0], (const float*)o.p[2], o.i[2], stream); break;
+      case DSL_OP_QUANT_FP8_W: {
+        float sc;
+        const int32_t bits = (int32_t)o.l[1];
+        memcpy(&sc, &bits, 4);
+        rc = dsl_quant_fp8_weights((const float*)o.p[0], o.p[1], (float*)o.p[2], (const float*)o.p[3], o.i[0], o.i[1], o.i[2], sc, stream);
+        break;
+      }
       default:
         dsl_set_error("dsl_run_ops: unknown op kind %d at index %d", o.kind, k);
         return -1;

@@ -941,6 +941,284 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   }
 }
 
+// ================================================================================================
+// fp8 forward convolution (BASELINE.json configs[4], first slice): the v3 kernel with 1-byte operands - OCP e4m3 activations
+// [pixel][C] and weights [CoutPad][kh][kw][Cin], quantised by dsl_quant_fp8 / dsl_quant_fp8_weights - on the MX-scaled MFMA
+// v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 2^0; the per-output-channel weight scale and the per-tensor activation scale are
+// folded into the fp32 epilogue's `scale`).  Same LDS geometry as bf16 (128-byte rows, same swizzle, same DMA instruction count
+// per K tile), but a K tile is 128 elements: half the DMA / LDS bytes per FLOP and twice the MFMA rate.  Forward mode, Cin % 128 == 0.
+// The reference has no such path (its training is fp32); off by default behind the detector's `fp8=dict(...)` key.
+// ================================================================================================
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+template <int BCO, int BPX, int WCO, int WPX, int NST>
+__global__ __launch_bounds__(64 * WCO * WPX) void conv_f8_kernel(const ConvK p) {
+  constexpr bool SMC = false;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int T = 64 * WCO * WPX;
+  constexpr int RPP = T / 8;                 // tile rows filled per pass (8 lanes per 128-byte row)
+  constexpr int WPASS = BCO / RPP, XPASS = BPX / RPP;
+  constexpr int TILE_W = BCO * 128;
+  constexpr int STAGE = (BCO + BPX) * 128;
+  constexpr int PT = BPX / WPX / 32;         // 32-pixel MFMA tiles per wave
+  static_assert(BCO / WCO == 64, "each wave owns 64 couts");
+  static_assert(BCO % RPP == 0 && BPX % RPP == 0 && (BPX / WPX) % 32 == 0, "tile/thread mismatch");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_co = wave / WPX, wave_px = wave % WPX;
+  // XCD-aware tile order (workgroups are dealt round-robin to the XCDs: equal b % 8 = same XCD): every XCD owns a contiguous run of tiles in (cout tile
+  // fastest, then pixel tile, then K split) order, so neighbouring pixel tiles - which share their halo rows - and
+  // the cout tiles of one pixel range hit the same L2 instead of being fetched into up to three of them.
+  const int wi = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.xcd_chunk || wi >= p.gx * p.gy * p.splits) return;
+  const int bz = wi / (p.gx * p.gy);
+  const int rem_t = wi - bz * (p.gx * p.gy);
+  const int by = rem_t / p.gx;
+  const int co0 = (rem_t - by * p.gx) * BCO;
+  const int px0 = by * BPX;
+  const int totpx = p.pxstart[p.nseg];
+  const int lrow = tid >> 3;
+  const int chunk = (tid & 7) ^ ((tid >> 4) & 7);     // source chunk that belongs in LDS slot (tid & 7) of this row
+
+  // buffer resources: base shifted back by `margin` so that every VALID tap has a non-negative per-lane offset
+  // (the hardware range-checks the per-lane offset, not the scalar one)
+  const unsigned margin = (unsigned)(p.kw * p.lds);            // (1-byte elements)
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.src) - margin), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, 0x7fffffff, 0x00020000);
+
+  const int kt0 = bz * p.kt_per_split;
+  const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+  int cidx = kt0 % p.kc;
+  int tap_r = (kt0 / p.kc) / p.kw, tap_s = (kt0 / p.kc) % p.kw;
+
+  unsigned r_cur[XPASS], r_step[XPASS], r_mask[XPASS];
+  int r_y[XPASS], r_x[XPASS], r_hw[XPASS];            // SMC: top-left source pixel of the window, source size
+#pragma unroll
+  for (int i = 0; i < XPASS; ++i) {
+    const int gp = px0 + lrow + RPP * i;
+    int seg = 0, img = 0, y = 0, x = 0;
+    const bool ok = gp < totpx;
+    if (ok) decode_pixel(p, gp, seg, img, y, x);
+    const int sh = p.sh[seg], sw = p.sw[seg];
+    if (SMC) {
+      r_y[i] = ok ? y * p.stride - p.pad : -100000;    // not ok: every tap fails the bounds test
+      r_x[i] = x * p.stride - p.pad;
+      r_hw[i] = (sh << 16) | sw;
+      r_cur[i] = (unsigned)(((int)(p.soff[seg]) + img * sh * sw + r_y[i] * sw + r_x[i]) * 16) + margin;
+      r_step[i] = r_mask[i] = 0;
+      continue;
+    }
+    const int row0 = p.mode == 0 ? y * p.stride - p.pad : y + p.pad;               // source row of tap r = 0
+    const int col0 = p.mode == 0 ? x * p.stride - p.pad : x + p.pad - (p.kw - 1);  // leftmost source column
+    unsigned m = 0;
+    for (int r = 0; r < p.kh; ++r) {
+      const int sy = p.mode == 0 ? row0 + r : row0 - r;
+      if (ok && (unsigned)sy < (unsigned)sh) m |= 1u << r;
+    }
+    for (int s_ = 0; s_ < p.kw; ++s_) {
+      const int sx = p.mode == 0 ? col0 + s_ : x + p.pad - s_;
+      if (ok && (unsigned)sx < (unsigned)sw) m |= 0x100u << s_;
+    }
+    r_mask[i] = m;
+    const unsigned pitch = (unsigned)(sw * p.lds);
+    r_step[i] = p.mode == 0 ? pitch : 0u - pitch;
+    const unsigned base = (unsigned)(((int)(p.soff[seg]) + img * sh * sw + row0 * sw + col0) * p.lds + chunk * 16) + margin;
+    r_cur[i] = base + (unsigned)tap_r * r_step[i];
+  }
+  const unsigned w_voff = (unsigned)(lrow * (int)p.wrow + chunk * 16);
+  const unsigned w_pass = (unsigned)(RPP * (int)p.wrow);
+  unsigned w_soff = (unsigned)(co0 * (int)p.wrow + kt0 * 128);
+
+  // ---- DMA of one K tile = LPT "pieces" per thread (XPASS pixel passes, then WPASS weight passes), issued a few at
+  // a time between the MFMAs: a burst of all pieces right after the barrier fills the CU's address queue and
+  // every wave then blocks on issue with an empty MFMA pipe.
+  // Branch-free: past the last tile every lane goes out of range (zeros land in a slot nobody reads), so each
+  // iteration issues exactly LPT DMA instructions and the vmcnt bookkeeping is a compile-time constant.
+  constexpr int LPT = WPASS + XPASS;
+  constexpr int P0 = (LPT + 1) / 3;                   // pieces issued right after the barrier (stage 3)
+  constexpr int P1 = P0 + (LPT - P0 + 1) / 2;         // pieces [P0, P1) in stage 0, [P1, LPT) in stage 1
+  int kt_next = kt0;               // K tile being fetched
+  int ld_slot = 0;                 // ... and the ring slot it goes to
+  auto pieces = [&](auto lo_c, auto hi_c) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+    unsigned char* stage = smem + ld_slot * STAGE;
+    const bool live = kt_next < kt1;
+    const unsigned sel = live ? ((1u << tap_r) | (0x100u << tap_s)) : 0xffffffffu;
+    const unsigned s_off = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds + cidx * 128);
+    const unsigned wv = live ? w_voff : 0x80000000u;
+    int s_tr = 0, s_ts = 0;
+    bool s_ok = false;
+    if (SMC) {                    // this lane's tap of the K tile
+      const int tap = kt_next * 8 + chunk;
+      s_tr = tap / p.kw;
+      s_ts = tap - s_tr * p.kw;
+      s_ok = live && tap < p.kh * p.kw;
+    }
+#pragma unroll
+    for (int j = LO; j < HI; ++j) {
+      if (j < XPASS) {
+        unsigned v, so;
+        if (SMC) {
+          const int sh = r_hw[j] >> 16, sw = r_hw[j] & 0xffff;
+          const bool in = s_ok && (unsigned)(r_y[j] + s_tr) < (unsigned)sh && (unsigned)(r_x[j] + s_ts) < (unsigned)sw;
+          v = in ? r_cur[j] + (unsigned)((s_tr * sw + s_ts) * 16) : 0x80000000u;
+          so = 0;
+        } else {
+          v = (r_mask[j] & sel) == sel ? r_cur[j] : 0x80000000u;
+          so = s_off;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lptr_t)(stage + TILE_W + (j * RPP + wave * 8) * 128), 16, v, so, 0, 0);
+      } else {
+        const int i = j - XPASS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lptr_t)(stage + (i * RPP + wave * 8) * 128), 16, wv,
+                                                 w_soff + i * w_pass, 0, 0);
+      }
+    }
+    if (HI == LPT) {               // tile fully issued: advance to the next (r, s, channel-block) and ring slot
+      ++kt_next;
+      ld_slot = (ld_slot + 1 == NST) ? 0 : ld_slot + 1;
+      w_soff += BK * 2;
+      const bool c_wrap = cidx + 1 == p.kc;
+      const bool s_wrap = c_wrap && tap_s + 1 == p.kw;
+      cidx = c_wrap ? 0 : cidx + 1;
+      tap_s = s_wrap ? 0 : (c_wrap ? tap_s + 1 : tap_s);
+      tap_r += s_wrap ? 1 : 0;
+      const unsigned adv = s_wrap ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int i = 0; i < XPASS; ++i) r_cur[i] += r_step[i] & adv;
+    }
+  };
+  using c0_t = std::integral_constant<int, 0>;
+  using cp0_t = std::integral_constant<int, P0>;
+  using cp1_t = std::integral_constant<int, P1>;
+  using clpt_t = std::integral_constant<int, LPT>;
+
+  f32x16 acc[2][PT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int fswz = (frow >> 1) & 7;
+  const int a_off = (wave_co * 64 + frow) * 128;
+  const int b_off = TILE_W + (wave_px * (32 * PT) + frow) * 128;
+  // a K tile is 128 fp8 elements = 2 k-steps of v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 e4m3 x fp8 e4m3, block scales 2^0): a lane's
+  // operand is 32 consecutive K elements of its row = two 16-byte chunks of the swizzled 128-byte LDS row
+  v8i32 fa[2][2], fb[2][PT];
+  auto rd32 = [&](const unsigned char* row, int kk) -> v8i32 {
+    const int c0 = ((4 * kk + 2 * fhalf) ^ fswz) << 4, c1 = ((4 * kk + 2 * fhalf + 1) ^ fswz) << 4;
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(row + c0), hi = *reinterpret_cast<const u32x4*>(row + c1);
+    v8i32 r = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    return r;
+  };
+  auto lds_read = [&](const unsigned char* base, int kk, int f) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) fa[f][ct] = rd32(base + a_off + ct * 32 * 128, kk);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) fb[f][pt] = rd32(base + b_off + pt * 32 * 128, kk);
+  };
+  auto mma_half = [&](int f, int ct) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+      acc[ct][pt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  };
+  auto mma = [&](int f) {
+    mma_half(f, 0);
+    mma_half(f, 1);
+  };
+
+  static_assert((NST - 1) * LPT <= 63, "vmcnt range");
+  // prologue: NST-1 whole tiles + the first pieces of the NST-th
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) pieces(c0_t{}, clpt_t{});
+  pieces(c0_t{}, cp0_t{});
+  wait_vmcnt<(NST - 2) * LPT + P0>();
+  __builtin_amdgcn_s_barrier();
+  lds_read(smem, 0, 0);
+  int slot = 0;
+  for (int kt = kt0; kt < kt1 - 1; ++kt) {
+    const unsigned char* base = smem + slot * STAGE;
+    const int nslot = (slot + 1 == NST) ? 0 : slot + 1;
+    lds_read(base, 1, 1);
+    pieces(cp0_t{}, clpt_t{});
+    mma(0);
+    mma_half(1, 0);
+    sched_stage<2 * PT, 2 * (2 + PT), LPT - P0>();
+    sched_stage<PT, 0, 0>();
+    __builtin_amdgcn_sched_barrier(0);     // keep these MFMAs in front of the waits below
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tile kt are in registers
+    wait_vmcnt<(NST - 2) * LPT>();         // tile kt+1 landed (tiles kt+2 .. kt+NST-1 may stay in flight)
+    __builtin_amdgcn_s_barrier();          // ... and both hold for every wave
+    lds_read(smem + nslot * STAGE, 0, 0);
+    pieces(c0_t{}, cp0_t{});               // start refilling the slot tile kt just vacated with tile kt+NST
+    mma_half(1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + PT), 0);
+    sched_stage<PT, 0, P0>();
+    slot = nslot;
+  }
+  {                                        // last tile
+    const unsigned char* base = smem + slot * STAGE;
+    lds_read(base, 1, 1);
+    mma(0);
+    mma(1);
+    sched_stage<2 * PT, 2 * (2 + PT), 0>();
+  }
+  wait_vmcnt<0>();                         // the out-of-range tail DMAs still write (zeros) into the ring
+
+  if (p.splits > 1) {                      // split-K: raw fp32 partial tile -> workspace [split][pixel][cd_pad]
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int gp = px0 + wave_px * (32 * PT) + pt * 32 + (lane & 31);
+      if (gp >= totpx) continue;
+      float* row = p.ws + ((long long)bz * totpx + gp) * p.cd_pad;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = co0 + wave_co * 64 + ct * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(row + co) = o;
+        }
+    }
+    return;
+  }
+
+  // ---- epilogue staged through LDS (see conv_glds_kernel)
+  constexpr int ROWB = BCO * 4 + 16;
+  constexpr int CPX = 32 * WPX;
+  constexpr int GPR = BCO / 8;
+  static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wave_co * 64 + ct * 32 + 8 * g + 4 * fhalf;
+        f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
+      }
+    __syncthreads();
+    for (int id = tid; id < CPX * GPR; id += T) {
+      const int pl = id / GPR, cg = id - pl * GPR;
+      const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
+      const int co = co0 + cg * 8;
+      if (gp >= totpx || co >= p.cd) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32 + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      long long dpix, apix;
+      conv_out_index(p, gp, dpix, apix);
+      conv_epilogue8(p, dpix, apix, co, v);
+    }
+  }
+}
+
 // NMF x { 1 MFMA, its share of the NRD fragment reads, 1 DMA piece for the first NVM }
 template <int I, int NMF, int NRD, int NVM>
 __device__ __forceinline__ void kt_sched() {
@@ -2414,7 +2692,7 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
   const long long lds_ = d->lds > 0 ? d->lds : d->cs;
   const bool dma_ok = conv_v2_only(d) || (d->kh <= 8 && d->kw <= 8 && src_px * lds_ * 2 + (long long)d->kw * lds_ * 2 < 0x7fff0000LL);
   const bool smallc_pipe = smallc && d->cd_pad % 64 == 0 && !getenv("DSL_STEM_V1");    // stem: pipelined kernel, 64-cout tile
-  const bool v1_only = (smallc && !smallc_pipe) || (d->flags & DSL_CONV_RELU_IN) || !dma_ok;
+  const bool v1_only = ((smallc && !smallc_pipe) || (d->flags & DSL_CONV_RELU_IN) || !dma_ok) && !(d->flags & DSL_CONV_FP8);
   if (!v1_only && force != 15) {
     double best = 1e300;
     const bool out_f32 = (d->flags & DSL_CONV_OUT_F32) != 0;
@@ -2423,8 +2701,9 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
       if (force >= 1 && force <= kNumCfg && force - 1 != c) continue;
       if (c >= 5 && conv_v2_only(d)) continue;       // the small tiles exist for the pipelined kernel only
       if (smallc && c != 4) continue;                // the 8-channel-source variant is instantiated for the 64x256 tile
+      if ((d->flags & DSL_CONV_FP8) && c != 0 && c != 1 && c != 3) continue;     // fp8: instantiated for 256x192, 256x128, 128x128
       for (int sp = 1; sp <= 16; ++sp) {
-        if (sp > 1 && smallc) break;
+        if (sp > 1 && (smallc || (d->flags & DSL_CONV_FP8))) break;
         if (sp > 1 && (!d->workspace || sp > ktiles / 2 || (size_t)sp * px * d->cd_pad * 4 > d->workspace_bytes)) break;
         if (force_split > 1 && sp != force_split) continue;
         const double t = conv_cost_us(c, px, d->cd_pad, ktiles, sp, out_f32);
@@ -2458,7 +2737,8 @@ double conv_algo_bytes(const dsl_conv_desc* d, long long px) {
     src_px += (double)d->n * d->sh[s] * d->sw[s];
     dst_px += (double)d->n * d->dh[s] * d->dw[s];
   }
-  double b = src_px * conv_real_cin(d) * 2.0 + (double)d->cd * d->kh * d->kw * conv_real_cin(d) * 2.0 +
+  const double es = (d->flags & DSL_CONV_FP8) ? 1.0 : 2.0;
+  double b = src_px * conv_real_cin(d) * es + (double)d->cd * d->kh * d->kw * conv_real_cin(d) * es +
              dst_px * d->cd * ((d->flags & DSL_CONV_OUT_F32) ? 4.0 : 2.0);
   if (d->addend) b += dst_px * d->cd * 2.0;
   if (d->mask) b += dst_px * d->cd * 2.0;
@@ -2488,8 +2768,12 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   DSL_CHECK(d->nseg >= 1 && d->nseg <= DSL_MAX_SEG, "dsl_conv2d: nseg=%d out of range", d->nseg);
   DSL_CHECK(d->src && d->wgt && d->dst, "dsl_conv2d: null tensor pointer");
   const bool smallc = (d->flags & DSL_CONV_SMALL_C) != 0;
+  const bool fp8 = (d->flags & DSL_CONV_FP8) != 0;
   if (smallc)
     DSL_CHECK(d->cs == 8 && d->mode == 0, "dsl_conv2d: SMALL_C needs cs == 8, forward mode");
+  else if (fp8)
+    DSL_CHECK(d->cs % 128 == 0 && d->cs > 0 && d->mode == 0 && !(d->flags & DSL_CONV_RELU_IN) && d->scale,
+              "dsl_conv2d: FP8 needs forward mode, cs %% 128 == 0 (cs=%d) and the dequantisation `scale` vector", d->cs);
   else
     DSL_CHECK(d->cs % 64 == 0 && d->cs > 0, "dsl_conv2d: source channels %d not a multiple of 64", d->cs);
   DSL_CHECK(d->cd_pad % 64 == 0 && d->cd <= d->cd_pad && d->cd > 0, "dsl_conv2d: bad cd=%d cd_pad=%d", d->cd, d->cd_pad);
@@ -2527,17 +2811,20 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     if (d->gh[s] != d->dh[s] || d->gw[s] != d->dw[s]) k.ident = 0;
   k.cs = d->cs; k.cd = d->cd; k.ldd = d->ldd; k.lda = d->lda; k.ldm = d->ldm;
   k.lds = d->lds > 0 ? d->lds : d->cs;
-  DSL_CHECK(k.lds >= d->cs && k.lds % 8 == 0, "dsl_conv2d: lds=%d must be >= cs=%d and a multiple of 8", k.lds, d->cs);
+  DSL_CHECK(k.lds >= d->cs && k.lds % (fp8 ? 16 : 8) == 0, "dsl_conv2d: lds=%d must be >= cs=%d and a multiple of 16 bytes", k.lds, d->cs);
   k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.mode = d->mode; k.os = d->os;
   k.flags = d->flags;
   if (smallc) {
     k.ktiles = (d->kh * d->kw + 7) / 8;
     k.kc = 1;
+  } else if (fp8) {
+    k.kc = d->cs / 128;                 // a K tile is 128 one-byte elements: the same 128-byte LDS rows
+    k.ktiles = d->kh * d->kw * k.kc;
   } else {
     k.kc = d->cs / 64;
     k.ktiles = d->kh * d->kw * k.kc;
   }
-  k.wrow = (long long)k.ktiles * BK;
+  k.wrow = (long long)k.ktiles * (fp8 ? 128 : BK);
   k.src = (const uint16_t*)d->src; k.wgt = (const uint16_t*)d->wgt; k.dst = d->dst;
   k.scale = d->scale; k.bias = d->bias;
   k.addend = (const uint16_t*)d->addend; k.mask = (const uint16_t*)d->mask;
@@ -2598,7 +2885,25 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     const long long n_wg = (long long)grid.x * grid.y * grid.z;
     const bool use_kt = !force_v2_kernel && !smallc && (pick == 3 || pick == 5 || pick == 6 || pick == 7) &&
                         (kt_mode == 2 || (kt_mode == 1 && n_wg <= 256LL * c.occ));
-    if (use_kt) {
+    if (fp8) {
+      DSL_CHECK(!force_v2_kernel && (pick == 0 || pick == 1 || pick == 3), "dsl_conv2d: no fp8 kernel for this shape (tile config %d)", pick);
+#define LAUNCH8(A, B, C_, D, S_)                                                                               \
+  do {                                                                                                        \
+    static bool attr_8 = false;                                                                               \
+    if (!attr_8) {                                                                                            \
+      hipFuncSetAttribute((const void*)conv_f8_kernel<A, B, C_, D, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)lds);                                                                          \
+      attr_8 = true;                                                                                          \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_f8_kernel<A, B, C_, D, S_>), dim3(8 * k.xcd_chunk), dim3(64 * C_ * D), lds, st, k); \
+  } while (0)
+      switch (pick) {
+        case 0: LAUNCH8(256, 192, 4, 2, 2); break;
+        case 1: LAUNCH8(256, 128, 4, 2, 3); break;
+        default: LAUNCH8(128, 128, 2, 4, 2); break;
+      }
+#undef LAUNCH8
+    } else if (use_kt) {
       constexpr int KT_NST = 3;
       size_t ldk = (size_t)KT_NST * (c.bco + c.bpx) * 128;
       const size_t stg = (size_t)32 * c.wpx * (c.bco * 4 + 16);

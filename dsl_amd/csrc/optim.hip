@@ -215,3 +215,158 @@ extern "C" int dsl_pack_dgrad_batched(const dsl_pack_item* items_dev, int n, int
   DSL_LAUNCH_CHECK("pack_dgrad_batched_kernel");
   return 0;
 }
+
+// ---- fp8 (OCP e4m3) quantisation for the fp8 forward convolutions (conv.hip conv_f8_kernel) --------------------------------
+namespace {
+__device__ __forceinline__ uint32_t cvt4_fp8(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -448.f), 448.f);      // e4m3fn has no infinity: saturate instead of producing NaN
+  b = fminf(fmaxf(b, -448.f), 448.f);
+  c = fminf(fmaxf(c, -448.f), 448.f);
+  d = fminf(fmaxf(d, -448.f), 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
+}
+__global__ __launch_bounds__(256) void quant_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y, long long rows, int c16,
+                                                        int ld_x, int c, float scale) {
+  const long long total = rows * c16;       // 16 elements per thread-iteration: 32 bytes in, 16 bytes out
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c16;
+    const int ch = (int)(i - r * c16) * 16;
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + r * ld_x + ch), v1 = *reinterpret_cast<const u32x4*>(x + r * ld_x + ch + 8);
+    u32x4 o;
+    o[0] = cvt4_fp8(bflo(v0[0]) * scale, bfhi(v0[0]) * scale, bflo(v0[1]) * scale, bfhi(v0[1]) * scale);
+    o[1] = cvt4_fp8(bflo(v0[2]) * scale, bfhi(v0[2]) * scale, bflo(v0[3]) * scale, bfhi(v0[3]) * scale);
+    o[2] = cvt4_fp8(bflo(v1[0]) * scale, bfhi(v1[0]) * scale, bflo(v1[1]) * scale, bfhi(v1[1]) * scale);
+    o[3] = cvt4_fp8(bflo(v1[2]) * scale, bfhi(v1[2]) * scale, bflo(v1[3]) * scale, bfhi(v1[3]) * scale);
+    *reinterpret_cast<u32x4*>(y + r * c + ch) = o;
+  }
+}
+// one workgroup per output channel: row maximum, then the scaled row
+__global__ __launch_bounds__(256) void quant_fp8_weights_kernel(const float* __restrict__ w, uint8_t* __restrict__ w8, float* __restrict__ comb,
+                                                                const float* __restrict__ bn_scale, int cout, int k, float inv_act_scale) {
+  __shared__ float sh[16];
+  const int co = blockIdx.x;
+  uint8_t* out = w8 + (long long)co * k;
+  if (co >= cout) {
+    for (int i = threadIdx.x * 4; i < k; i += blockDim.x * 4) *reinterpret_cast<uint32_t*>(out + i) = 0u;
+    if (threadIdx.x == 0) comb[co] = 0.f;
+    return;
+  }
+  const float* row = w + (long long)co * k;
+  float m = 0.f;
+  for (int i = threadIdx.x * 4; i < k; i += blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  const float s = m > 0.f ? 448.f / m : 1.f;
+  for (int i = threadIdx.x * 4; i < k; i += blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+    *reinterpret_cast<uint32_t*>(out + i) = cvt4_fp8(v[0] * s, v[1] * s, v[2] * s, v[3] * s);
+  }
+  if (threadIdx.x == 0) comb[co] = inv_act_scale / s * (bn_scale ? bn_scale[co] : 1.f);
+}
+// per-block maximum of |x| over a bf16 [rows][ld_x] tensor (first c columns): partials[block]; no atomics, nothing to clear
+__global__ __launch_bounds__(256) void absmax_kernel(const uint16_t* __restrict__ x, long long rows, int c8, int ld_x, float* __restrict__ partials) {
+  __shared__ float sh[4];
+  const long long total = rows * c8;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ld_x + (int)(i - r * c8) * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(bflo(v[e])), fabsf(bfhi(v[e]))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ float fold_absmax(const float* __restrict__ partials, int n, float* sh) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, partials[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = sh[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, sh[w]);
+  return m;
+}
+// dynamic per-tensor scale: scale = 448 / max|x| of THIS tensor (from absmax_kernel's partials): nothing saturates
+__global__ __launch_bounds__(256) void quant_fp8_dyn_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y, long long rows, int c16,
+                                                            int ld_x, int c, const float* __restrict__ partials, int n_partials) {
+  __shared__ float sh[4];
+  const float amax = fold_absmax(partials, n_partials, sh);
+  const float scale = amax > 0.f ? 448.f / amax : 1.f;
+  const long long total = rows * c16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c16;
+    const int ch = (int)(i - r * c16) * 16;
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + r * ld_x + ch), v1 = *reinterpret_cast<const u32x4*>(x + r * ld_x + ch + 8);
+    u32x4 o;
+    o[0] = cvt4_fp8(bflo(v0[0]) * scale, bfhi(v0[0]) * scale, bflo(v0[1]) * scale, bfhi(v0[1]) * scale);
+    o[1] = cvt4_fp8(bflo(v0[2]) * scale, bfhi(v0[2]) * scale, bflo(v0[3]) * scale, bfhi(v0[3]) * scale);
+    o[2] = cvt4_fp8(bflo(v1[0]) * scale, bfhi(v1[0]) * scale, bflo(v1[1]) * scale, bfhi(v1[1]) * scale);
+    o[3] = cvt4_fp8(bflo(v1[2]) * scale, bfhi(v1[2]) * scale, bflo(v1[3]) * scale, bfhi(v1[3]) * scale);
+    *reinterpret_cast<u32x4*>(y + r * c + ch) = o;
+  }
+}
+// the fp8 convolution's epilogue scale: comb[co] = winv[co] (1 / weight scale, x BatchNorm scale) x amax / 448 (1 / activation scale)
+__global__ __launch_bounds__(256) void fp8_comb_kernel(const float* __restrict__ winv, float* __restrict__ comb, int n, const float* __restrict__ partials,
+                                                       int n_partials) {
+  __shared__ float sh[4];
+  const float amax = fold_absmax(partials, n_partials, sh);
+  const float inv = amax > 0.f ? amax / 448.f : 1.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) comb[i] = winv[i] * inv;
+}
+}  // namespace
+
+extern "C" int dsl_quant_fp8(const void* x, void* y, long rows, int c, int ld_x, float scale, void* stream) {
+  DSL_CHECK(x && y && rows > 0 && c > 0 && c % 16 == 0 && ld_x >= c && ld_x % 8 == 0, "dsl_quant_fp8: bad arguments (c=%d ld_x=%d)", c, ld_x);
+  const long long total = (long long)rows * (c / 16);
+  hipLaunchKernelGGL(quant_fp8_kernel, dim3(nblocks(total, 4096)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint8_t*)y,
+                     (long long)rows, c / 16, ld_x, c, scale);
+  DSL_LAUNCH_CHECK("quant_fp8_kernel");
+  return 0;
+}
+
+extern "C" int dsl_quant_fp8_weights(const float* w, void* w8, float* comb, const float* bn_scale, int cout, int cout_pad, int k,
+                                     float inv_act_scale, void* stream) {
+  DSL_CHECK(w && w8 && comb && cout > 0 && cout_pad >= cout && k > 0 && k % 4 == 0, "dsl_quant_fp8_weights: bad arguments");
+  hipLaunchKernelGGL(quant_fp8_weights_kernel, dim3(cout_pad), dim3(256), 0, (hipStream_t)stream, w, (uint8_t*)w8, comb, bn_scale, cout, k,
+                     inv_act_scale);
+  DSL_LAUNCH_CHECK("quant_fp8_weights_kernel");
+  return 0;
+}
+
+extern "C" int dsl_absmax(const void* x, long rows, int c, int ld_x, float* partials, int n_partials, void* stream) {
+  DSL_CHECK(x && partials && rows > 0 && c > 0 && c % 8 == 0 && ld_x >= c && ld_x % 8 == 0 && n_partials > 0 && n_partials <= 4096,
+            "dsl_absmax: bad arguments");
+  hipLaunchKernelGGL(absmax_kernel, dim3(n_partials), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (long long)rows, c / 8, ld_x, partials);
+  DSL_LAUNCH_CHECK("absmax_kernel");
+  return 0;
+}
+
+extern "C" int dsl_quant_fp8_dyn(const void* x, void* y, long rows, int c, int ld_x, const float* partials, int n_partials, void* stream) {
+  DSL_CHECK(x && y && partials && rows > 0 && c > 0 && c % 16 == 0 && ld_x >= c && ld_x % 8 == 0 && n_partials > 0, "dsl_quant_fp8_dyn: bad arguments");
+  const long long total = (long long)rows * (c / 16);
+  hipLaunchKernelGGL(quant_fp8_dyn_kernel, dim3(nblocks(total, 4096)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint8_t*)y,
+                     (long long)rows, c / 16, ld_x, c, partials, n_partials);
+  DSL_LAUNCH_CHECK("quant_fp8_dyn_kernel");
+  return 0;
+}
+
+extern "C" int dsl_fp8_comb(const float* winv, float* comb, int n, const float* partials, int n_partials, void* stream) {
+  DSL_CHECK(winv && comb && partials && n > 0 && n_partials > 0, "dsl_fp8_comb: bad arguments");
+  hipLaunchKernelGGL(fp8_comb_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, winv, comb, n, partials, n_partials);
+  DSL_LAUNCH_CHECK("fp8_comb_kernel");
+  return 0;
+}
+

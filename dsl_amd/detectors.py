@@ -246,7 +246,11 @@ class FCOS(nn.Module):
     """SingleStageDetector (detectors/single_stage.py:10-165) specialised by detectors/fcos.py:5-18."""
 
     def __init__(self, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None,
-                 init_cfg=None):
+                 init_cfg=None, fp8=None):
+        """fp8 (not a key of the reference, whose training is fp32): dict(layers='towers') runs the FORWARD of the head towers' 3x3
+        convolutions on the MX-scaled fp8 MFMA (OCP e4m3 activations with a dynamic per-tensor scale 448 / max|x| of the very
+        tensor, per-output-channel weight scales re-made from the fp32 weights every step; the backward pass stays bf16 on the
+        bf16 tensors - straight-through).  None (default): everything bf16."""
         super().__init__()
         self.backbone = build_backbone(backbone)
         self.neck = build_neck(neck)
@@ -256,6 +260,9 @@ class FCOS(nn.Module):
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.store = ParamStore(self.bbox_head.num_classes, 'cpu', backbone=getattr(self.backbone, 'backbone_kind', 'resnet'))
         self.store.init_reference_style(0)
+        if fp8:
+            assert str(fp8.get('layers', 'towers')) == 'towers', "fp8: only layers='towers' is built"
+            self.store.fp8 = dict(fp8)
         self._params = None
         self._engine = None
         self._anchor = None

@@ -83,6 +83,23 @@ class OpList:
     def pair(self, d):
         self._add(L.OP_PAIR, d)
 
+    @staticmethod
+    def _fbits(x):
+        import struct
+        return struct.unpack('<i', struct.pack('<f', float(x)))[0]
+
+    def quant_fp8(self, x, y, rows, c, ld_x, scale=1.0, partials=None, side=False):
+        """The fp8 copy a fp8 convolution reads: y = e4m3(x * scale) with the tensor's own scale 448 / max|x| when `partials` (a
+        float workspace for the block maxima) is given, the static `scale` otherwise."""
+        n_p = 0 if partials is None else partials.numel()
+        self._add(L.OP_QUANT_FP8, i=(c, ld_x, n_p, 0, 0, 0, int(side)), p=(x, y, partials), l=(rows, self._fbits(scale)))
+
+    def fp8_comb(self, winv, comb, n, partials, side=False):
+        self._add(L.OP_FP8_COMB, i=(n, 0, partials.numel(), 0, 0, 0, int(side)), p=(winv, comb, partials))
+
+    def quant_fp8_w(self, w, w8, comb, cout, cout_pad, k, inv_act_scale, side=False):
+        self._add(L.OP_QUANT_FP8_W, i=(cout, cout_pad, k, 0, 0, 0, int(side)), p=(w, w8, comb, None), l=(0, self._fbits(inv_act_scale)))
+
     def prof(self, cls, end, flops=0.0, nbytes=0.0):
         """Phase mark on the caller's stream (a no-op unless dsl_prof_enable(3))."""
         import struct
@@ -271,18 +288,43 @@ class Plan:
         self._head_flops = 2.0 * self.M * (8 * 256 * 2304 + (80 + 5) * 2304)
         self._head_bytes = self.M * 256 * 2.0 * (8 * 2 + 8 * 3 + 2) + self.M * (80 + 8) * 4.0
         f.prof(4, 0, self._head_flops, self._head_bytes)
+        # fp8 forward of the tower convolutions (FCOS(fp8=dict(...)), BASELINE.json configs[4], off by default): e4m3 copies of the
+        # layer inputs (static per-tensor scale `act_scale`) and of the weights (per-output-channel scales, re-made every step from the
+        # fp32 master weights); the bf16 tensors stay what the backward pass reads (straight-through)
+        fp8 = getattr(st, 'fp8', None)
+        f8 = bool(fp8) and 'towers' in str(fp8.get('layers', 'towers'))
+        NPART = 512           # block maxima per quantised tensor (its dynamic scale = 448 / their maximum)
+        feats8 = None
+        if f8:
+            feats8 = self.buf('feats.f8', self.M, 256, dtype=torch.uint8)
+            pm0 = self.buf('feats.f8.amax', NPART, dtype=torch.float32)
+            f.quant_fp8(feats, feats8, self.M, 256, 256, partials=pm0)          # before the FORK: both towers read it
+            for tower in ('cls_convs', 'reg_convs'):
+                for i in range(4):
+                    spec = cv[f'bbox_head.{tower}.{i}.conv']
+                    w8 = self.buf(f'{tower}.{i}.w8', spec.cout_pad, 9 * 256, dtype=torch.uint8)
+                    winv = self.buf(f'{tower}.{i}.winv', spec.cout_pad, dtype=torch.float32)
+                    self.buf(f'{tower}.{i}.comb', spec.cout_pad, dtype=torch.float32)
+                    f.quant_fp8_w(st.t32_ptr(spec.name + '.weight'), w8, winv, spec.cout, spec.cout_pad, 9 * 256, 1.0)
         if FSIDE:
             f.fork(FSIDE)
         for tower in ('cls_convs', 'reg_convs'):
             side = FSIDE if tower == 'reg_convs' else 0
-            xin = feats
+            xin, xin8, pm = feats, feats8, (pm0 if f8 else None)
             lays = []
             for i in range(4):
                 spec = cv[f'bbox_head.{tower}.{i}.conv']
                 pre = self.buf(f'{tower}.{i}.pre', self.M, 256)
                 act = self.buf(f'{tower}.{i}.act', self.M, 256)
                 stats = self.buf(f'{tower}.{i}.stats', 5 * N * 32, 2, dtype=torch.float32)
-                cd_ = self._conv(spec, xin, pre, N, ls, ls)
+                if f8:
+                    comb = self.bufs[f'{tower}.{i}.comb']
+                    f.fp8_comb(self.bufs[f'{tower}.{i}.winv'], comb, spec.cout_pad, pm, side=side)
+                    cd_ = ops.conv_desc(xin8, self.bufs[f'{tower}.{i}.w8'], pre, n=N, grid=ls, src_hw=ls, dst_hw=ls, cs=256, cd=spec.cout,
+                                        cd_pad=spec.cout_pad, ldd=spec.cout, kh=3, kw=3, stride=1, pad=1, flags=L.CONV_FP8,
+                                        scale=comb, bias=st.t32_ptr(spec.name + '.bias'))
+                else:
+                    cd_ = self._conv(spec, xin, pre, N, ls, ls)
                 if side:
                     cd_.workspace, cd_.workspace_bytes = L.ptr(self.conv_ws_side), self.conv_ws_side.numel()
                 f.conv(cd_, side=side)
@@ -292,6 +334,10 @@ class Plan:
                 f.gn_fwd(gd, side=side)
                 lays.append(dict(spec=spec, xin=xin, pre=pre, act=act, stats=stats, gn=base))
                 xin = act
+                if f8 and i < 3:
+                    xin8 = self.buf(f'{tower}.{i}.act8', self.M, 256, dtype=torch.uint8)
+                    pm = self.buf(f'{tower}.{i}.act8.amax', NPART, dtype=torch.float32)
+                    f.quant_fp8(act, xin8, self.M, 256, 256, partials=pm, side=side)
             self.tower[tower] = lays
         cls_logits = self.buf('cls_logits', self.M, 80, dtype=torch.float32)
         regctr = self.buf('regctr', self.M, 8, dtype=torch.float32, zero=True)

@@ -49,7 +49,9 @@ enum {
   DSL_CONV_MASK_FIRST = 8,    /* v = acc*(mask>0) + addend */
   DSL_CONV_MASK_LAST = 16,    /* v = (acc + addend)*(mask>0) */
   DSL_CONV_ADD_UPSAMPLE = 32, /* addend is nearest-upsampled (fpn.py:163-172) */
-  DSL_CONV_SMALL_C = 64       /* source has 8 channels (stem, image packed NHWC8) */
+  DSL_CONV_SMALL_C = 64,      /* source has 8 channels (stem, image packed NHWC8) */
+  DSL_CONV_FP8 = 128          /* src and wgt are OCP fp8 e4m3 (dsl_quant_fp8 / dsl_quant_fp8_weights; forward mode, cs % 128 == 0,
+                               * cs / lds count bytes): MX-scaled fp8 MFMA, `scale` carries 1 / (weight scale x activation scale) */
 };
 
 typedef struct dsl_conv_desc {
@@ -141,6 +143,22 @@ int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* counts, int ns
                           void* table_host, size_t table_bytes);
 int dsl_conv2d_wgrad_multi(const void* table_host, const void* table_dev, void* stream);
 int dsl_wgrad_multi_info(const void* table_host, double* flops, double* bytes, int* blocks, int* red_blocks, int* nsub);
+
+/* fp8 forward path (BASELINE.json configs[4], first slice; the reference trains in fp32 and has no such path).
+ * dsl_quant_fp8: y[r][c] = e4m3(clamp(x[r][c] * scale, +-448)) for a bf16 [rows][ld_x] tensor -> fp8 [rows][c] (c % 16 == 0).
+ * dsl_quant_fp8_weights: per output channel co < cout: s = 448 / max|w[co][:]| (1 if the row is zero), w8[co][k] = e4m3(w * s),
+ * comb[co] = inv_act_scale / s  - the `scale` vector of the fp8 convolution's epilogue (x BatchNorm scale if bn_scale != NULL);
+ * rows cout .. cout_pad are zero-filled with comb 0. */
+int dsl_quant_fp8(const void* x_bf16, void* y_fp8, long rows, int c, int ld_x, float scale, void* stream);
+/* Dynamic per-tensor activation scale (what the engine uses): dsl_absmax writes n_partials block maxima of |x|; dsl_quant_fp8_dyn
+ * quantises with scale = 448 / max(partials) (the tensor's own maximum: nothing saturates); dsl_fp8_comb makes the convolution's
+ * epilogue scale comb[i] = winv[i] * max(partials) / 448 from the weights' inverse scales (dsl_quant_fp8_weights with
+ * inv_act_scale = 1).  No atomics, nothing to clear between steps. */
+int dsl_absmax(const void* x_bf16, long rows, int c, int ld_x, float* partials, int n_partials, void* stream);
+int dsl_quant_fp8_dyn(const void* x_bf16, void* y_fp8, long rows, int c, int ld_x, const float* partials, int n_partials, void* stream);
+int dsl_fp8_comb(const float* winv, float* comb, int n, const float* partials, int n_partials, void* stream);
+int dsl_quant_fp8_weights(const float* w, void* w8, float* comb, const float* bn_scale, int cout, int cout_pad, int k,
+                          float inv_act_scale, void* stream);
 
 /* Two back-to-back 1x1 convolutions as one launch (csrc/pair.hip): a bottleneck's expand conv and the next bottleneck's reduce
  * conv in the forward pass (resnet.py:262-301), the reduce conv's and the expand conv's data gradients in the backward pass.
@@ -387,6 +405,11 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_PACK_DGRAD = 18, /* dsl_pack_dgrad_batched(p[0] = item table, i[0] = items, i[1] = blocks) */
        DSL_OP_WGRAD_MULTI = 19, /* dsl_conv2d_wgrad_multi(p[0] = table_host, p[1] = table_dev) */
        DSL_OP_PAIR = 20,       /* desc = dsl_pair_desc -> dsl_conv1x1_pair */
+       DSL_OP_QUANT_FP8 = 22,  /* p[2] == NULL: dsl_quant_fp8(p[0] = x, p[1] = y, l[0] = rows, i[0] = c, i[1] = ld_x, scale = the float whose bits are
+                                * l[1]); else dsl_absmax(.., p[2] = partials, i[2] = n_partials) + dsl_quant_fp8_dyn(..) */
+       DSL_OP_FP8_COMB = 24,   /* dsl_fp8_comb(p[0] = winv, p[1] = comb, i[0] = n, p[2] = partials, i[2] = n_partials) */
+       DSL_OP_QUANT_FP8_W = 23, /* dsl_quant_fp8_weights(p[0] = w, p[1] = w8, p[2] = comb, p[3] = bn_scale, i[0] = cout, i[1] = cout_pad, i[2] = k,
+                                * inv_act_scale = the float whose bits are l[1]) */
        DSL_OP_PROF = 21 };     /* phase mark (dsl_prof_enable(3) only, else a no-op): i[0] = class >= 4, i[1] = 0 begin | 1 end, l[0] / l[1] =
                                 * algorithmic FLOPs / bytes of the phase as IEEE doubles' bit patterns (begin only) */
 typedef struct dsl_op {
