@@ -130,6 +130,14 @@ class ImagePrepItem(C.Structure):
                 ('mean', C.c_float * 3), ('inv_std', C.c_float * 3)]
 
 
+class AugItem(C.Structure):
+    _fields_ = [('h', C.c_int32), ('w', C.c_int32), ('kind', C.c_int32), ('order', C.c_int32), ('m', C.c_float * 6),
+                ('roi', C.c_int32 * 4), ('cval', C.c_int32), ('f', C.c_float * 3), ('rect', (C.c_int32 * 4) * 3), ('seed', C.c_uint32)]
+
+
+AUG_COPY, AUG_AFFINE, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_HUE, AUG_GRAY, AUG_BLUR_H, AUG_BLUR_V, AUG_ERASE = range(10)
+
+
 class Op(C.Structure):
     _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 7), ('desc', C.c_void_p),
                 ('p', C.c_void_p * 4), ('l', C.c_int64 * 2)]
@@ -164,6 +172,8 @@ _SIGS = {
     'dsl_avgpool2x2_bwd': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_bn_tanh_fwd': [_vp, _i, _vp, _vp, _vp, _i, _l, _i, _vp], 'dsl_bn_tanh_bwd_workspace_bytes': [_l, _i],
     'dsl_bn_tanh_bwd': [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
+    'dsl_image_prep_u8': [_vp, _i, _vp, _i, _i, _vp], 'dsl_image_aug': [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp],
+    'dsl_image_normalize': [_vp, _vp, _i, _vp, _i, _i, _vp],
     'dsl_quant_fp8': [_vp, _vp, _l, _i, _i, _f, _vp], 'dsl_absmax': [_vp, _l, _i, _i, _vp, _i, _vp],
     'dsl_quant_fp8_dyn': [_vp, _vp, _l, _i, _i, _vp, _i, _vp], 'dsl_fp8_comb': [_vp, _vp, _i, _vp, _i, _vp], 'dsl_quant_fp8_weights': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'dsl_bn_fold': [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp], 'dsl_bn_wgrad_post': [_vp, _i, _i, _f, _vp], 'dsl_rla_op': [_vp, _vp],

@@ -9,10 +9,13 @@ Mirrors, by name and argument meaning (configs/fcos_semi/RLA_*.py:68-82; mmdet/d
   Normalize(mean, std, to_rgb)                                          :652-690
   Pad(size_divisor)                                                     :581-650
   MultiDataLoader._merge_data2one_batch (pad to the batch's largest)    mmdet/datasets/builder.py:236-267
+  RandomAugmentBBox_Fast(aug_type='affine'|'default')                  mmdet/datasets/pipelines/semi_aug.py:344-531
+  UBAug()                                                               :2098-2140
 A transform's __call__(results) only DRAWS its random parameters and updates boxes / meta; `GpuBatchPipeline` then renders all
-images of the batch.  Not here (they resample through PIL / imgaug, neither is in this image, and nothing pins their
-output): RandomAugmentBBox_Fast (semi_aug.py:344-531) and UBAug (transforms.py:2098-2140) - the unlabeled stream's photometric
-/ affine augmentation stays on the CPU side of the boundary.
+images of the batch: one launch for the labeled stream, and for the unlabeled stream (the last two transforms) one launch per
+augmentation pass over uint8 canvases (dsl_image_prep_u8 -> dsl_image_aug ... -> dsl_image_normalize).  UBAug's colour,
+grayscale and blur passes are Pillow's 8-bit arithmetic, pinned to Pillow's outputs; imgaug's Affine follows its documentation
+(unpinned: imgaug is not in this image); RandomErasing's noise is this library's own stream.
 Fails loudly without the HIP library: there is no CPU rendering path in the product (the CPU restatement is oracle/datapath_oracle.py,
 test infrastructure).
 """
@@ -177,8 +180,168 @@ class Pad:
         return r
 
 
+def _affine_forward(kind, value, w, h):
+    """Forward matrix (input pixel -> output pixel) of one child of the reference's imgaug AFFINE_TRANSFORM[_WEAK]
+    (semi_aug.py:36-88) about the image centre (w / 2 - 0.5, h / 2 - 0.5); rotation / shear in degrees, positive rotation
+    clockwise in image coordinates.  imgaug is not available to this build: the convention follows its documentation, UNPINNED."""
+    cx, cy = w / 2.0 - 0.5, h / 2.0 - 0.5
+    T = lambda tx, ty: np.array([[1, 0, tx], [0, 1, ty], [0, 0, 1]], np.float64)
+    M = np.eye(3)
+    if kind == 'translate_x':
+        M = T(value * w, 0)
+    elif kind == 'translate_y':
+        M = T(0, value * h)
+    elif kind == 'rotate':
+        a = np.deg2rad(value)
+        M = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    elif kind == 'shear':
+        M = np.array([[1, -np.tan(np.deg2rad(value)), 0], [0, 1, 0], [0, 0, 1]])
+    return T(cx, cy) @ M @ T(-cx, -cy)
+
+
+def _draw_affine(rng, weak):
+    """iaa.OneOf of the four Affine children with their parameter ranges (semi_aug.py:36-88), interpolation order from [0, 1]."""
+    kind = ('translate_x', 'translate_y', 'rotate', 'shear')[rng.randint(4)]
+    if kind.startswith('translate'):
+        lim = 0.05 if weak else 0.1
+    else:
+        lim = 10.0 if weak else 30.0           # DEGREE = 30 (:35); the in-box transform uses 10
+    return kind, float(rng.uniform(-lim, lim)), int(rng.randint(2))
+
+
+@PIPELINES.register_module()
+class RandomAugmentBBox_Fast:
+    """mmdet/datasets/pipelines/semi_aug.py:344-531.  Built: aug_type 'affine' (the DSL config's, RLA_*.py:93) and 'default'.
+    __call__ draws the parameters and moves the boxes on the host; the image work is recorded as passes (`r['_aug']`) that
+    GpuBatchPipeline renders with dsl_image_aug.  An image WITHOUT boxes takes the reference's colour branch (:494-497,
+    RandAug policy of one op at probability 1): Identity / Color / Contrast / Brightness are rendered (level -> factor
+    0.18 level + 0.1, autoaug_fast.py `_enhancer_impl`), the histogram / filter ops AutoContrast, Equalize, Solarize, Sharpness,
+    Posterize are counted in `skipped_ops` and left out (documented deviation)."""
+    COLOR_OPS = ('Identity', 'AutoContrast', 'Equalize', 'Solarize', 'Color', 'Contrast', 'Brightness', 'Sharpness', 'Posterize')
+
+    def __init__(self, aug_type='strong', magnitude=10, weighted_inbox_selection=False):
+        if aug_type not in ('affine', 'default'):
+            raise NotImplementedError(f"RandomAugmentBBox_Fast(aug_type={aug_type!r}): 'affine' (configs/fcos_semi) and 'default' are built")
+        self.aug_type, self.magnitude, self.weighted = aug_type, magnitude, weighted_inbox_selection
+        self.skipped_ops = 0
+        self.rng = np.random
+
+    def __call__(self, r):
+        h, w = r['img_shape'][:2]
+        passes = r.setdefault('_aug', [])
+        boxes = r['gt_bboxes']
+        if boxes.shape[0] == 0:
+            op = self.COLOR_OPS[self.rng.randint(len(self.COLOR_OPS))]
+            level = self.rng.randint(1, self.magnitude)
+            f = float(level) * 1.8 / 10 + 0.1
+            kind = dict(Color=L.AUG_SATURATION, Contrast=L.AUG_CONTRAST, Brightness=L.AUG_BRIGHTNESS).get(op)
+            if kind is not None:
+                passes.append(dict(kind=kind, f=f))
+            elif op != 'Identity':
+                self.skipped_ops += 1
+            return r
+        if self.aug_type == 'default':
+            return r
+        # array_to_bb (:150-155): imgaug's BoundingBox orders its corners (x1 <= x2, y1 <= y2) on construction
+        boxes = np.stack([np.minimum(boxes[:, 0], boxes[:, 2]), np.minimum(boxes[:, 1], boxes[:, 3]),
+                          np.maximum(boxes[:, 0], boxes[:, 2]), np.maximum(boxes[:, 1], boxes[:, 3])], 1)
+        if self.rng.randint(2) == 0:           # bbox_affine_transform (:431-452): one box, the weak transform inside it
+            n = boxes.shape[0]
+            if self.weighted:
+                area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+                k = int(self.rng.choice(n, p=area / area.sum()))
+            else:
+                k = int(self.rng.randint(n))
+            x0, y0, x1, y1 = (int(v) for v in boxes[k])
+            x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, w), min(y1, h)     # (a box sticking out is clamped: the reference's
+                                                                                # negative slice index would wrap around)
+            if x1 > x0 and y1 > y0:
+                kind, val, order = _draw_affine(self.rng, weak=True)
+                passes.append(dict(kind=L.AUG_AFFINE, M=_affine_forward(kind, val, x1 - x0, y1 - y0), order=order, roi=(x0, y0, x1, y1)))
+        else:                                   # affine_transform (:454-461): the whole image and its boxes
+            kind, val, order = _draw_affine(self.rng, weak=False)
+            M = _affine_forward(kind, val, w, h)
+            passes.append(dict(kind=L.AUG_AFFINE, M=M, order=order, roi=(0, 0, w, h)))
+            b = boxes.astype(np.float64)
+            out = np.zeros_like(b)
+            for i, (bx1, by1, bx2, by2) in enumerate(b):       # imgaug: the four corners move, the box is their hull
+                c = np.array([[bx1, by1, 1], [bx2, by1, 1], [bx2, by2, 1], [bx1, by2, 1]], np.float64) @ M.T
+                out[i] = [c[:, 0].min(), c[:, 1].min(), c[:, 0].max(), c[:, 1].max()]
+            boxes = out
+        boxes = boxes.astype(np.float64)
+        boxes[:, 0::2] = np.clip(boxes[:, 0::2], 0, w)             # :519-527
+        boxes[:, 1::2] = np.clip(boxes[:, 1::2], 0, h)
+        keep = ((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])) > 0
+        r['gt_bboxes'] = boxes[keep].astype(np.float32)
+        r['gt_labels'] = r['gt_labels'][keep]
+        return r
+
+
+@PIPELINES.register_module()
+class UBAug:
+    """mmdet/datasets/pipelines/transforms.py:2098-2140 (Unbiased Teacher's strong augmentation): RandomApply(ColorJitter(0.4, 0.4,
+    0.4, 0.1), 0.8), RandomGrayscale(0.2), RandomApply(GaussianBlur(0.1 .. 2.0), 0.5), three RandomErasing.  The parameters are
+    drawn here the way torchvision draws them (ColorJitter: a random order of the four adjustments, factors U(0.6, 1.4) and hue
+    U(-0.1, 0.1); RandomErasing.get_params: ten attempts per rectangle); the image passes are Pillow's arithmetic, pinned by
+    tests/golden/ubaug_pil.npz.  The reference hands mmcv's BGR array to ToPILImage as if it were RGB: the passes treat the
+    stored channel order as RGB in the same way."""
+
+    def __init__(self):
+        self.rng = np.random
+
+    @staticmethod
+    def _erase_rect(rng, h, w, scale, ratio):
+        area = h * w
+        for _ in range(10):
+            ea = area * rng.uniform(scale[0], scale[1])
+            ar = np.exp(rng.uniform(np.log(ratio[0]), np.log(ratio[1])))
+            eh, ew = int(round(np.sqrt(ea * ar))), int(round(np.sqrt(ea / ar)))
+            if eh < h and ew < w:
+                i, j = int(rng.randint(0, h - eh + 1)), int(rng.randint(0, w - ew + 1))
+                return (j, i, j + ew, i + eh)
+        return None
+
+    def __call__(self, r):
+        h, w = r['img_shape'][:2]
+        passes, rng = r.setdefault('_aug', []), self.rng
+        if rng.rand() < 0.8:
+            fac = {L.AUG_BRIGHTNESS: rng.uniform(0.6, 1.4), L.AUG_CONTRAST: rng.uniform(0.6, 1.4), L.AUG_SATURATION: rng.uniform(0.6, 1.4),
+                   L.AUG_HUE: rng.uniform(-0.1, 0.1)}
+            kinds = [L.AUG_BRIGHTNESS, L.AUG_CONTRAST, L.AUG_SATURATION, L.AUG_HUE]
+            for i in rng.permutation(4):
+                f = float(fac[kinds[i]])
+                passes.append(dict(kind=kinds[i], f=float(int(f * 255)) if kinds[i] == L.AUG_HUE else f))
+        if rng.rand() < 0.2:
+            passes.append(dict(kind=L.AUG_GRAY))
+        if rng.rand() < 0.5:
+            sigma = float(rng.uniform(0.1, 2.0))
+            fr = blur_box_radius(sigma)
+            if fr != 0:
+                passes += [dict(kind=L.AUG_BLUR_H, f=fr)] * 3 + [dict(kind=L.AUG_BLUR_V, f=fr)] * 3
+        rects = []
+        for p_, scale, ratio in ((0.7, (0.05, 0.2), (0.3, 3.3)), (0.5, (0.02, 0.2), (0.1, 6)), (0.3, (0.02, 0.2), (0.05, 8))):
+            if rng.rand() < p_:
+                rc = self._erase_rect(rng, h, w, scale, ratio)
+                if rc is not None:
+                    rects.append(rc)
+        if rects:
+            passes.append(dict(kind=L.AUG_ERASE, rects=rects, seed=int(rng.randint(0, 2 ** 31 - 1))))
+        return r
+
+
+def blur_box_radius(radius, passes=3):
+    """Pillow BoxBlur.c `_gaussian_blur_radius` (float arithmetic as in the C source): the fractional box radius of
+    ImageFilter.GaussianBlur(radius)."""
+    radius = np.float32(radius)
+    sigma2 = np.float32(radius * radius / np.float32(passes))
+    big_l = np.float32(np.sqrt(12.0 * np.float64(sigma2) + 1.0))
+    l_ = np.float32(np.floor((np.float64(big_l) - 1.0) / 2.0))
+    a = np.float32((2 * l_ + 1) * (l_ * (l_ + 1) - 3 * sigma2))
+    a = np.float32(a / np.float32(6 * (sigma2 - (l_ + 1) * (l_ + 1))))
+    return float(np.float32(l_ + a))
+
+
 _SKIP = ('LoadImageFromFile', 'LoadAnnotations', 'DefaultFormatBundle', 'Collect', 'ImageToTensor')
-_CPU_SIDE = ('RandomAugmentBBox_Fast', 'UBAug')
 
 
 class GpuBatchPipeline:
@@ -194,8 +357,6 @@ class GpuBatchPipeline:
             t = cfg['type']
             if t in _SKIP:
                 continue
-            if t in _CPU_SIDE:
-                raise NotImplementedError(f'{t} resamples through PIL / imgaug: it runs on the CPU side, before the image is handed over')
             self.transforms.append(PIPELINES.build(cfg))
         norm = [t for t in self.transforms if isinstance(t, Normalize)]
         assert len(norm) == 1, 'the pipeline needs exactly one Normalize'
@@ -237,8 +398,49 @@ class GpuBatchPipeline:
                 it.mean[c], it.inv_std[c] = float(self.norm.mean[c]), float(inv[c])
         tab = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
         out = torch.empty(n, 3, hc, wc, dtype=torch.float32, device=self.device)
-        L.check(L.lib.dsl_image_prep(L.ptr(tab), n, L.ptr(out), hc, wc, L.stream_ptr()), 'dsl_image_prep')
+        n_pass = max(len(r.get('_aug', ())) for r in results)
+        if n_pass == 0:
+            L.check(L.lib.dsl_image_prep(L.ptr(tab), n, L.ptr(out), hc, wc, L.stream_ptr()), 'dsl_image_prep')
+        else:
+            # the unlabeled stream (RandomAugmentBBox_Fast, UBAug): Resize / PatchShuffle / Flip into uint8 canvases, one launch per
+            # augmentation pass over the batch (an image with fewer passes is copied), then Normalize / Pad
+            a = torch.empty(n, hc, wc, 3, dtype=torch.uint8, device=self.device)
+            b = torch.empty_like(a)
+            sums = torch.zeros(n, dtype=torch.int64, device=self.device)
+            L.check(L.lib.dsl_image_prep_u8(L.ptr(tab), n, L.ptr(a), hc, wc, L.stream_ptr()), 'dsl_image_prep_u8')
+            keep = [a, b, sums]
+            for k in range(n_pass):
+                its = (L.AugItem * n)()
+                need_mean = 0
+                for i, r in enumerate(results):
+                    it, ps = its[i], r.get('_aug', ())
+                    it.h, it.w = r['img_shape'][0], r['img_shape'][1]
+                    if k >= len(ps):
+                        continue
+                    ps_k = ps[k]
+                    it.kind = ps_k['kind']
+                    need_mean |= int(it.kind == L.AUG_CONTRAST)
+                    it.f[0] = float(ps_k.get('f', 0.0))
+                    if it.kind == L.AUG_AFFINE:
+                        x0, y0, x1, y1 = ps_k['roi']
+                        Mi = np.linalg.inv(ps_k['M'])
+                        for q in range(6):
+                            it.m[q] = float(Mi[q // 3, q % 3])
+                        it.roi[0], it.roi[1], it.roi[2], it.roi[3] = x0, y0, x1, y1
+                        it.order, it.cval = int(ps_k['order']), 125
+                    if it.kind == L.AUG_ERASE:
+                        it.seed = ps_k['seed']
+                        for q, rc in enumerate(ps_k['rects'][:3]):
+                            for e in range(4):
+                                it.rect[q][e] = int(rc[e])
+                at = torch.frombuffer(bytearray(bytes(its)), dtype=torch.uint8).to(self.device)
+                keep.append(at)
+                L.check(L.lib.dsl_image_aug(L.ptr(at), n, L.ptr(a), L.ptr(b), hc, wc, L.ptr(sums), need_mean, L.stream_ptr()), 'dsl_image_aug')
+                a, b = b, a
+            L.check(L.lib.dsl_image_normalize(L.ptr(a), L.ptr(tab), n, L.ptr(out), hc, wc, L.stream_ptr()), 'dsl_image_normalize')
+            srcs = srcs + keep
         self._keep = (srcs, tab)            # alive until the launch has run (stream order)
+        self.last_passes = [list(r.get('_aug', ())) for r in results]      # what was rendered (tests replay it on the oracle)
         meta_keys = ('filename', 'ori_filename', 'ori_shape', 'img_shape', 'pad_shape', 'scale_factor', 'scale_idx', 'flip',
                      'flip_direction', 'img_norm_cfg', 'PS', 'PS_place', 'PS_mode')
         metas = []

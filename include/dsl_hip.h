@@ -199,6 +199,39 @@ typedef struct dsl_image_prep_item {
 /* dst[n][3][hc][wc] fp32 <- resize (OpenCV's 8-bit fixed-point bilinear) -> PatchShuffle -> flip -> normalise, zero padded to the
  * canvas (Pad(size_divisor) and the loader's merge/pad, datasets/builder.py:236-267).  items_dev: device array of n items. */
 int dsl_image_prep(const dsl_image_prep_item* items_dev, int n, float* dst, int hc, int wc, void* stream);
+/* The same up to (not including) Normalize: the uint8 BGR images [n][hc][wc][3] (zero outside an image's new_h x new_w) that the
+ * unlabeled stream's augmentations work on. */
+int dsl_image_prep_u8(const dsl_image_prep_item* items_dev, int n, unsigned char* dst_u8, int hc, int wc, void* stream);
+
+/* One augmentation pass over a batch of uint8 canvases (src -> dst, different buffers): per image `kind` selects the pass.
+ * RandomAugmentBBox_Fast(aug_type='affine') (mmdet/datasets/pipelines/semi_aug.py:344-531: imgaug Affine, whole image or inside
+ * one box) and UBAug (transforms.py:2098-2140: torchvision ColorJitter in its random order, RandomGrayscale, GaussianBlur,
+ * three RandomErasing).  The host draws the parameters and transforms the boxes.  The colour, grayscale and blur passes are
+ * Pillow's 8-bit arithmetic (ImageEnhance / Blend.c, Convert.c, BoxBlur.c) bit for bit - pinned against Pillow's own outputs
+ * (tests/golden/ubaug_pil.npz); the stored channel order plays Pillow's (R, G, B), as the reference hands mmcv's BGR array to
+ * ToPILImage unchanged.  imgaug is not available to this build: AFFINE follows its documented convention, parity UNPINNED.
+ * ERASE writes its own N(0, 1) stream through torchvision's value mapping (mul(255).byte(): truncate, wrap). */
+enum { DSL_AUG_COPY = 0, DSL_AUG_AFFINE = 1, DSL_AUG_BRIGHTNESS = 2, DSL_AUG_CONTRAST = 3, DSL_AUG_SATURATION = 4, DSL_AUG_HUE = 5,
+       DSL_AUG_GRAY = 6, DSL_AUG_BLUR_H = 7, DSL_AUG_BLUR_V = 8, DSL_AUG_ERASE = 9 };
+typedef struct dsl_aug_item {
+  int32_t h, w;                  /* the image inside its canvas */
+  int32_t kind;
+  int32_t order;                 /* AFFINE: 0 nearest, 1 bilinear */
+  float m[6];                    /* AFFINE: output pixel (x, y) relative to roi's corner -> source position x_s = m0 x + m1 y + m2,
+                                  * y_s = m3 x + m4 y + m5 inside the roi (the inverse of the drawn transform) */
+  int32_t roi[4];                /* AFFINE: x0, y0, x1, y1 - the region replaced and sampled (whole image, or one box) */
+  int32_t cval;                  /* AFFINE: fill value (125) */
+  float f[3];                    /* f[0]: BRIGHTNESS / CONTRAST / SATURATION the enhancement factor; HUE int(factor * 255), the 8-bit
+                                  * shift; BLUR_H / BLUR_V the fractional box radius of GaussianBlur(sigma) (BoxBlur.c) */
+  int32_t rect[3][4];            /* ERASE: up to three rectangles x0, y0, x1, y1 (x1 <= x0: unused) */
+  uint32_t seed;                 /* ERASE: noise stream */
+} dsl_aug_item;
+/* luma_sums: 8 * n bytes of scratch, needed (need_mean != 0) when some item is a CONTRAST pass. */
+int dsl_image_aug(const dsl_aug_item* items_dev, int n, const unsigned char* src, unsigned char* dst, int hc, int wc,
+                  void* luma_sums, int need_mean, void* stream);
+/* Normalize + Pad of a uint8 canvas batch (the tail of dsl_image_prep): dst[n][3][hc][wc] fp32. */
+int dsl_image_normalize(const unsigned char* src_u8, const dsl_image_prep_item* items_dev, int n, float* dst, int hc, int wc,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Memory-bound fused layers

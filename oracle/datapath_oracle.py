@@ -166,3 +166,180 @@ def prepare_batch(samples, mean, std, to_rgb=True, size_divisor=32):
     for i, o in enumerate(outs):
         batch[i, :, :o.shape[1], :o.shape[2]] = o
     return batch, shapes
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The unlabeled stream's augmentations (configs/fcos_semi/RLA_*.py:93-94): UBAug (transforms.py:2098-2140) and
+# RandomAugmentBBox_Fast(aug_type='affine') (semi_aug.py:344-531).
+#   UBAug's image arithmetic is Pillow's (torchvision only draws the parameters: ColorJitter -> ImageEnhance / HSV shift,
+#   RandomGrayscale -> convert('L'), GaussianBlur -> ImageFilter.GaussianBlur): restated below from Pillow's C sources
+#   (Blend.c, Convert.c rgb2hsv / hsv2rgb, BoxBlur.c) and PINNED: tests/golden/ubaug_pil.npz holds Pillow's own outputs
+#   (tests/golden/make_golden.py ubaug; Pillow is importable in the build container).
+#   RandomErasing's noise is torch's RNG stream (unreproducible by construction): the semantics restated are the value mapping
+#   mul(255).byte() (truncate toward zero, wrap mod 256).
+#   imgaug's Affine is NOT available: the matrix convention below follows imgaug's documentation - parity UNPINNED.
+def pil_blend(deg, img, f):
+    """Image.blend(degenerate, image, f) of ImageEnhance (Blend.c): float32 deg + f * (img - deg), clipped, TRUNCATED."""
+    f = np.float32(f)
+    t = deg.astype(np.float32) + f * (img.astype(np.float32) - deg.astype(np.float32))
+    return np.clip(t, 0, 255).astype(np.uint8)
+
+
+def pil_luma(rgb):
+    r, g, b = [rgb[..., i].astype(np.int64) for i in range(3)]
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def adjust_brightness(rgb, f):
+    return pil_blend(np.zeros_like(rgb), rgb, f)
+
+
+def adjust_contrast(rgb, f):
+    mean = int(pil_luma(rgb).astype(np.float64).mean() + 0.5)
+    return pil_blend(np.full_like(rgb, mean), rgb, f)
+
+
+def adjust_saturation(rgb, f):
+    return pil_blend(np.repeat(pil_luma(rgb)[..., None], 3, -1), rgb, f)
+
+
+def to_grayscale3(rgb):
+    return np.repeat(pil_luma(rgb)[..., None], 3, -1)
+
+
+def rgb_to_hsv_u8(rgb):
+    r, g, b = [rgb[..., i].astype(np.float32) for i in range(3)]
+    mx, mn = np.maximum(np.maximum(r, g), b), np.minimum(np.minimum(r, g), b)
+    cr = (mx - mn).astype(np.float32)
+    safe = np.where(cr > 0, cr, 1).astype(np.float32)
+    rc, gc, bc = [((mx - c) / safe).astype(np.float32) for c in (r, g, b)]
+    h = np.where(r == mx, (bc - gc).astype(np.float32),
+                 np.where(g == mx, (2.0 + rc.astype(np.float64) - bc.astype(np.float64)).astype(np.float32),
+                          (4.0 + gc.astype(np.float64) - rc.astype(np.float64)).astype(np.float32))).astype(np.float32)
+    hd = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+    uh = np.where(cr > 0, np.clip((hd.astype(np.float64) * 255.0).astype(np.int64), 0, 255), 0)
+    us = np.where(cr > 0, np.clip(((cr / np.where(mx > 0, mx, 1)).astype(np.float32).astype(np.float64) * 255.0).astype(np.int64), 0, 255), 0)
+    return np.stack([uh, us, mx.astype(np.int64)], -1).astype(np.uint8)
+
+
+def hsv_to_rgb_u8(hsv):
+    H, S, V = [hsv[..., i].astype(np.float64) for i in range(3)]
+    fh, fs = H * 6.0 / 255.0, S / 255.0
+    i = np.floor(fh).astype(np.int64)
+    f = fh - i
+    rnd = lambda x: np.clip(np.floor(x + 0.5).astype(np.int64), 0, 255)
+    p, q, t = rnd(V * (1 - fs)), rnd(V * (1 - fs * f)), rnd(V * (1 - fs * (1 - f)))
+    v = V.astype(np.int64)
+    sel = i % 6
+    r = np.choose(sel, [v, q, p, p, t, v])
+    g = np.choose(sel, [t, v, v, q, p, p])
+    b = np.choose(sel, [p, p, t, v, v, q])
+    gray = S == 0
+    return np.stack([np.where(gray, v, c) for c in (r, g, b)], -1).astype(np.uint8)
+
+
+def adjust_hue(rgb, f):
+    """torchvision adjust_hue on a PIL image: the 8-bit H channel += uint8(f * 255) (wraps), back to RGB."""
+    hsv = rgb_to_hsv_u8(rgb).astype(np.int64)
+    hsv[..., 0] = (hsv[..., 0] + int(f * 255)) & 255          # int(): toward zero, as np.uint8(negative float) does
+    return hsv_to_rgb_u8(hsv.astype(np.uint8))
+
+
+def gauss_box_radius(radius, passes=3):
+    """BoxBlur.c _gaussian_blur_radius: the (fractional) box radius whose `passes`-fold box blur has the Gaussian's variance."""
+    radius = np.float32(radius)
+    sigma2 = np.float32(radius * radius / np.float32(passes))
+    L = np.float32(np.sqrt(12.0 * np.float64(sigma2) + 1.0))
+    l_ = np.float32(np.floor((np.float64(L) - 1.0) / 2.0))
+    a = np.float32((2 * l_ + 1) * (l_ * (l_ + 1) - 3 * sigma2))
+    a = np.float32(a / np.float32(6 * (sigma2 - (l_ + 1) * (l_ + 1))))
+    return np.float32(l_ + a)
+
+
+def box_blur_pass_h(img, fr):
+    """One horizontal pass of ImagingLineBoxBlur8 in direct form: 24-bit fixed point, edge pixels replicated."""
+    r = int(fr)
+    ww = int(np.uint32(np.float32(1 << 24) / np.float32(np.float32(fr) * 2 + 1)))
+    fw = ((1 << 24) - (r * 2 + 1) * ww) // 2
+    W = img.shape[1]
+    x = np.arange(W)
+    acc = np.zeros(img.shape, np.int64)
+    for k in range(-r, r + 1):
+        acc += img[:, np.clip(x + k, 0, W - 1)].astype(np.int64)
+    far = img[:, np.clip(x - r - 1, 0, W - 1)].astype(np.int64) + img[:, np.clip(x + r + 1, 0, W - 1)].astype(np.int64)
+    bulk = (acc * ww + far * fw) & 0xffffffff
+    return (((bulk + (1 << 23)) & 0xffffffff) >> 24).astype(np.uint8)
+
+
+def gaussian_blur(img, radius):
+    """ImageFilter.GaussianBlur(radius): three horizontal then three vertical box passes."""
+    fr = gauss_box_radius(radius)
+    out = img
+    if fr != 0:
+        for _ in range(3):
+            out = box_blur_pass_h(out, fr)
+        out = out.transpose(1, 0, 2)
+        for _ in range(3):
+            out = box_blur_pass_h(out, fr)
+        out = np.ascontiguousarray(out.transpose(1, 0, 2))
+    return out
+
+
+def erase_value(z):
+    """ToPILImage's mul(255).byte() of the N(0, 1) fill RandomErasing(value='random') writes: toward zero, wrap mod 256."""
+    return (np.trunc(np.asarray(z, np.float32) * np.float32(255)).astype(np.int64) & 255).astype(np.uint8)
+
+
+def affine_matrix(kind, value, w, h):
+    """Forward 3x3 matrix (input pixel -> output pixel) of ONE imgaug Affine child of AFFINE_TRANSFORM (semi_aug.py:36-62): the
+    transform acts about the image centre (w / 2 - 0.5, h / 2 - 0.5) (imgaug 0.4 `_AffineMatrixGenerator`); rotation and shear in
+    degrees, positive rotation clockwise in image coordinates; shear moves x with y.  UNPINNED (imgaug is not installable here)."""
+    cx, cy = w / 2.0 - 0.5, h / 2.0 - 0.5
+    T = lambda tx, ty: np.array([[1, 0, tx], [0, 1, ty], [0, 0, 1]], np.float64)
+    M = np.eye(3)
+    if kind == 'translate_x':
+        M = T(value * w, 0)
+    elif kind == 'translate_y':
+        M = T(0, value * h)
+    elif kind == 'rotate':
+        a = np.deg2rad(value)
+        M = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    elif kind == 'shear':
+        M = np.array([[1, -np.tan(np.deg2rad(value)), 0], [0, 1, 0], [0, 0, 1]])
+    return T(cx, cy) @ M @ T(-cx, -cy)
+
+
+def warp_affine_u8(img, M_fwd, order, cval=125):
+    """Inverse-map warp of a uint8 [H, W, C] image: order 0 nearest (round half to even), 1 bilinear in float32; constant border."""
+    h, w = img.shape[:2]
+    Mi = np.linalg.inv(M_fwd).astype(np.float32)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+    sx = Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]
+    sy = Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]
+
+    def at(xi, yi):
+        ok = (xi >= 0) & (yi >= 0) & (xi < w) & (yi < h)
+        v = img[np.clip(yi, 0, h - 1), np.clip(xi, 0, w - 1)].astype(np.float32)
+        return np.where(ok[..., None], v, np.float32(cval))
+    if order == 0:
+        return at(np.rint(sx).astype(np.int64), np.rint(sy).astype(np.int64)).astype(np.uint8)
+    x0, y0 = np.floor(sx), np.floor(sy)
+    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+    x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
+    top = at(x0, y0) * (1 - fx) + at(x0 + 1, y0) * fx
+    bot = at(x0, y0 + 1) * (1 - fx) + at(x0 + 1, y0 + 1) * fx
+    return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8)
+
+
+def affine_boxes(boxes, M_fwd, w, h):
+    """imgaug BoundingBoxesOnImage under an affine map: the 4 corners are moved, the new box is their axis-aligned hull; then
+    semi_aug.py:519-527: clip to the image, drop boxes of zero area.  Returns (boxes, keep mask)."""
+    b = np.asarray(boxes, np.float64).reshape(-1, 4)
+    out = np.zeros_like(b)
+    for i, (x1, y1, x2, y2) in enumerate(b):
+        c = np.array([[x1, y1, 1], [x2, y1, 1], [x2, y2, 1], [x1, y2, 1]], np.float64) @ M_fwd.T
+        out[i] = [c[:, 0].min(), c[:, 1].min(), c[:, 0].max(), c[:, 1].max()]
+    out[:, 0::2] = np.clip(out[:, 0::2], 0, w)
+    out[:, 1::2] = np.clip(out[:, 1::2], 0, h)
+    keep = ((out[:, 2] - out[:, 0]) * (out[:, 3] - out[:, 1])) > 0
+    return out[keep].astype(np.float32), keep

@@ -492,7 +492,47 @@ def gen_patch_shuffle():
     print('wrote patch_shuffle.json', len(cases), 'cases,', sum(c['output']['PS'] for c in cases), 'shuffled')
 
 
+def gen_ubaug():
+    """UBAug's image arithmetic (mmdet/datasets/pipelines/transforms.py:2098-2140).  torchvision is not installable here; on PIL
+    images its ColorJitter / RandomGrayscale / the class's GaussianBlur are thin wrappers of Pillow calls (torchvision
+    transforms/functional_pil.py: adjust_brightness = ImageEnhance.Brightness(img).enhance(f), adjust_contrast / adjust_saturation
+    likewise with Contrast / Color, adjust_hue = convert('HSV'), H += uint8(f * 255), convert back; to_grayscale = convert('L')
+    merged three times; transforms.py:1934-1937: img.filter(ImageFilter.GaussianBlur(radius=sigma))) - Pillow itself IS in the build
+    container, so the fixture holds Pillow's own outputs for the parameter ranges UBAug draws from."""
+    from PIL import Image, ImageEnhance, ImageFilter
+    rng = np.random.RandomState(11)
+    rgb = rng.randint(0, 256, (45, 61, 3)).astype(np.uint8)
+    rgb[:6] = rgb[:6, :, :1]                   # a band of grey pixels (saturation 0)
+    rgb[6:9] = (rgb[6:9] // 32) * 32           # and a band with few levels
+    im = Image.fromarray(rgb)
+    out = dict(rgb=rgb)
+    fac = dict(brightness=[0.6, 0.83, 1.0, 1.4], contrast=[0.6, 1.17, 1.4], saturation=[0.6, 0.99, 1.4], hue=[-0.1, -0.031, 0.0, 0.07, 0.1],
+               blur=[0.1, 0.35, 0.8, 1.0, 1.234, 1.5, 2.0])
+    for i, f in enumerate(fac['brightness']):
+        out[f'brightness_{i}'] = np.asarray(ImageEnhance.Brightness(im).enhance(f))
+    for i, f in enumerate(fac['contrast']):
+        out[f'contrast_{i}'] = np.asarray(ImageEnhance.Contrast(im).enhance(f))
+    for i, f in enumerate(fac['saturation']):
+        out[f'saturation_{i}'] = np.asarray(ImageEnhance.Color(im).enhance(f))
+    for i, f in enumerate(fac['hue']):
+        h, s_, v = im.convert('HSV').split()
+        nh = np.array(h, dtype=np.uint8)
+        with np.errstate(over='ignore'):
+            nh += np.array(f * 255).astype(np.uint8) if f >= 0 else np.uint8(int(f * 255) & 255)
+        out[f'hue_{i}'] = np.asarray(Image.merge('HSV', (Image.fromarray(nh, 'L'), s_, v)).convert('RGB'))
+    g = np.asarray(im.convert('L'))
+    out['gray'] = np.dstack([g, g, g])
+    for i, f in enumerate(fac['blur']):
+        out[f'blur_{i}'] = np.asarray(im.filter(ImageFilter.GaussianBlur(radius=f)))
+    for k, v in fac.items():
+        out['f_' + k] = np.asarray(v, np.float64)
+    save('ubaug_pil.npz', **out)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['ubaug']:
+        gen_ubaug()
+        sys.exit(0)
     if sys.argv[1:] == ['ps']:
         gen_patch_shuffle()
         sys.exit(0)

@@ -109,3 +109,17 @@ def test_normalize_formula():
     out = DO.imnormalize(img, [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], to_rgb=True)
     r = (np.float32(img[0, 0, 2]) - np.float32(123.675)) * np.float32(1.0 / np.float64(np.float32(58.395)))
     assert out.dtype == np.float32 and out[0, 0, 0] == r
+
+
+def test_ubaug_arithmetic_pinned_to_pillow(golden):
+    """The numpy restatements of Pillow's enhancement / HSV / box-blur arithmetic (what UBAug runs under torchvision) against
+    Pillow's own outputs (tests/golden/ubaug_pil.npz): bit for bit."""
+    from oracle import datapath_oracle as D
+    d = golden('ubaug_pil.npz')
+    rgb = d['rgb']
+    for name, fn in (('brightness', D.adjust_brightness), ('contrast', D.adjust_contrast), ('saturation', D.adjust_saturation),
+                     ('hue', D.adjust_hue), ('blur', D.gaussian_blur)):
+        for i, f in enumerate(d['f_' + name]):
+            assert np.array_equal(fn(rgb, float(f)), d[f'{name}_{i}']), (name, f)
+    assert np.array_equal(D.to_grayscale3(rgb), d['gray'])
+    assert D.erase_value([-0.3, 1.7, -2.2, 0.5, 3.9]).tolist() == [180, 177, 207, 127, 226]      # torch: tensor.mul(255).byte()

@@ -116,7 +116,8 @@ def test_batch_feeds_the_training_step():
     assert all(np.isfinite(float(v)) for v in losses.values()) and torch.isfinite(model.store.grad).all()
 
 
-def test_cpu_side_transforms_are_refused():
+def test_unbuilt_augmentation_modes_are_refused():
+    """RandomAugmentBBox_Fast is built for the aug_types the DSL configs use; the others fail at build time, not silently."""
     from dsl_amd.datapath import GpuBatchPipeline
-    with pytest.raises(NotImplementedError, match='CPU side'):
-        GpuBatchPipeline([dict(type='UBAug'), dict(type='Normalize', **NORM)])
+    with pytest.raises(NotImplementedError, match='aug_type'):
+        GpuBatchPipeline([dict(type='RandomAugmentBBox_Fast', aug_type='strong'), dict(type='Normalize', **NORM)])
