@@ -150,8 +150,34 @@ __device__ __forceinline__ void conv_epilogue4(const ConvK& p, long long dpix, l
 
 // Epilogue for 8 consecutive channels of one pixel: 16-byte loads / stores (used by the LDS-staged epilogue
 // of the v2 kernel).  Falls back to two 4-channel epilogues on a ragged channel tail.
+// the per-channel scale / bias of 8 consecutive output channels, loaded once per thread where a thread's channel group is fixed
+struct Affine8 {
+  f32x4 s0, s1, b0, b1;
+  bool full;                               // co + 7 < cd: the vector path applies
+};
+__device__ __forceinline__ Affine8 conv_affine8(const ConvK& p, int co) {
+  Affine8 a;
+  a.full = co + 7 < p.cd;
+  a.s0 = a.s1 = f32x4{1.f, 1.f, 1.f, 1.f};
+  a.b0 = a.b1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.full) {
+    if (p.scale) {
+      a.s0 = *reinterpret_cast<const f32x4*>(p.scale + co);
+      a.s1 = *reinterpret_cast<const f32x4*>(p.scale + co + 4);
+    }
+    if (p.bias) {
+      a.b0 = *reinterpret_cast<const f32x4*>(p.bias + co);
+      a.b1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
+    }
+  }
+  return a;
+}
+__device__ __forceinline__ void conv_epilogue8a(const ConvK& p, long long dpix, long long apix, int co, float v[8], const Affine8& a);
 __device__ __forceinline__ void conv_epilogue8(const ConvK& p, long long dpix, long long apix, int co, float v[8]) {
-  if (co + 7 >= p.cd) {
+  conv_epilogue8a(p, dpix, apix, co, v, conv_affine8(p, co));
+}
+__device__ __forceinline__ void conv_epilogue8a(const ConvK& p, long long dpix, long long apix, int co, float v[8], const Affine8& a) {
+  if (!a.full) {
     conv_epilogue4(p, dpix, apix, co, v);
     if (co + 4 < p.cd) conv_epilogue4(p, dpix, apix, co + 4, v + 4);
     return;
@@ -159,19 +185,17 @@ __device__ __forceinline__ void conv_epilogue8(const ConvK& p, long long dpix, l
   const bool mask_first = (p.flags & DSL_CONV_MASK_FIRST) != 0 && p.mask != nullptr;
   const bool mask_last = (p.flags & DSL_CONV_MASK_LAST) != 0 && p.mask != nullptr;
   if (p.scale) {
-    const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale + co), s1 = *reinterpret_cast<const f32x4*>(p.scale + co + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v[e] *= s0[e];
-      v[4 + e] *= s1[e];
+      v[e] *= a.s0[e];
+      v[4 + e] *= a.s1[e];
     }
   }
   if (p.bias) {
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + co), b1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v[e] += b0[e];
-      v[4 + e] += b1[e];
+      v[e] += a.b0[e];
+      v[4 + e] += a.b1[e];
     }
   }
   float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
@@ -642,16 +666,31 @@ __device__ __forceinline__ void sched_stage() {      // NMF x { 1 MFMA [, 1 DS r
 // SMC: the source has 8 channels per pixel (the NHWC8 image of the 7x7 stem): one 16-byte DMA lane is one TAP, a K tile
 // is 8 consecutive taps, so every lane gathers its own tap's pixel (K index = tap*8 + channel, as the stem weights
 // are packed).
-template <int BCO, int BPX, int WCO, int WPX, int NST, bool SMC = false>
-__global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p) {
+#ifdef DSL_TRACE_BUILD
+constexpr int kTraceIters = 40;
+__device__ unsigned long long g_conv_trace[8 * kTraceIters * 8 + 8];
+#endif
+
+// LW > 0: LW extra "loader" waves issue every LDS-DMA piece; the WCO x WPX MFMA waves only read fragments and multiply.  Why
+// (tools/trace_conv.py, s_memtime stamps of one workgroup): an MFMA wave that issues a DMA piece stalls 60 - 185 cycles at issue
+// while the CU's vector-memory queue drains the other waves' pieces, and the in-order wave cannot issue the MFMAs behind it -
+// seven pieces per wave per K tile kept the matrix pipe 64 % busy in the K loop of the 256 x 192 tile.
+template <int BCO, int BPX, int WCO, int WPX, int NST, bool SMC = false, int HB = 1, int LW = 0>
+__global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int T = 64 * WCO * WPX;
-  constexpr int RPP = T / 8;                 // tile rows filled per pass (8 lanes per 128-byte row)
+  constexpr int T = 64 * WCO * WPX;          // MFMA ("consumer") threads
+  constexpr int TD = LW ? 64 * LW : T;       // threads that issue the DMA
+  constexpr int RPP = TD / 8;                // tile rows filled per pass (8 lanes per 128-byte row)
   constexpr int WPASS = BCO / RPP, XPASS = BPX / RPP;
   constexpr int TILE_W = BCO * 128;
   constexpr int STAGE = (BCO + BPX) * 128;
   constexpr int PT = BPX / WPX / 32;         // 32-pixel MFMA tiles per wave
-  static_assert(BCO / WCO == 64, "each wave owns 64 couts");
+  constexpr int CT = BCO / WCO / 32;         // 32-cout MFMA tiles per wave (2 for the 8-wave tiles; 4 = the "tall wave" variants:
+                                             // LDS bytes read per MFMA are (CT + PT) / (CT * PT) KB, the bound of the large tiles)
+  static_assert(BCO == WCO * CT * 32 && CT >= 1, "cout tiles per wave");
+  // HB: cout tiles of the K tile's LAST k-step whose MFMAs are held back across the barrier (their fragments are in registers):
+  // they are what the matrix pipe runs while the first reads of the next tile are in flight
+  static_assert(HB >= 1 && HB <= CT, "held-back cout tiles");
   static_assert(BCO % RPP == 0 && BPX % RPP == 0 && (BPX / WPX) % 32 == 0, "tile/thread mismatch");
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -671,8 +710,11 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   const int co0 = (rem_t - by * p.gx) * BCO;
   const int px0 = by * BPX;
   const int totpx = p.pxstart[p.nseg];
-  const int lrow = tid >> 3;
-  const int chunk = (tid & 7) ^ ((tid >> 4) & 7);     // source chunk that belongs in LDS slot (tid & 7) of this row
+  const bool loader = LW > 0 && wave >= WCO * WPX;      // wave-uniform
+  const int dt = LW > 0 ? tid - T : tid;                // index among the DMA threads (negative in an MFMA wave when LW > 0: unused)
+  const int dwave = LW > 0 ? wave - WCO * WPX : wave;
+  const int lrow = dt >> 3;
+  const int chunk = (dt & 7) ^ ((dt >> 4) & 7);       // source chunk that belongs in LDS slot (dt & 7) of this row
 
   // buffer resources: base shifted back by `margin` so that every VALID tap has a non-negative per-lane offset
   // (the hardware range-checks the per-lane offset, not the scalar one)
@@ -694,6 +736,11 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   int r_y[XPASS], r_x[XPASS], r_hw[XPASS];            // SMC: top-left source pixel of the window, source size
 #pragma unroll
   for (int i = 0; i < XPASS; ++i) {
+    if (LW > 0 && !loader) {               // MFMA waves of the loader variant carry no DMA state
+      r_cur[i] = r_step[i] = r_mask[i] = 0;
+      r_y[i] = r_x[i] = r_hw[i] = 0;
+      continue;
+    }
     const int gp = px0 + lrow + RPP * i;
     int seg = 0, img = 0, y = 0, x = 0;
     const bool ok = gp < totpx;
@@ -769,10 +816,10 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
           v = (r_mask[j] & sel) == sel ? r_cur[j] : 0x80000000u;
           so = s_off;
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lptr_t)(stage + TILE_W + (j * RPP + wave * 8) * 128), 16, v, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lptr_t)(stage + TILE_W + (j * RPP + dwave * 8) * 128), 16, v, so, 0, 0);
       } else {
         const int i = j - XPASS;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lptr_t)(stage + (i * RPP + wave * 8) * 128), 16, wv,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lptr_t)(stage + (i * RPP + dwave * 8) * 128), 16, wv,
                                                  w_soff + i * w_pass, 0, 0);
       }
     }
@@ -798,9 +845,34 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
 #ifdef DSL_ABLATE_BUILD
   if (p.dbg & 256) return;                   // + kernel-argument loads and the per-pixel decode
 #endif
-  f32x16 acc[2][PT];
+  if constexpr (LW > 0) {
+    if (loader) {
+      // ---- loader wave: tile t goes to ring slot (t - kt0) % NST as soon as the barrier that retires the slot's previous
+      // tenant has passed; before barrier #(t - kt0) it waits until tile t has landed (counted vmcnt: later tiles stay in flight)
+      int issued = kt0;                    // first tile not yet issued
+      auto land = [&](int need) {          // every piece of tiles <= need has landed
+        const int later = issued - 1 - need;
+        if (later <= 0) wait_vmcnt<0>();
+        else if (later == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<(NST > 2 ? 2 : 1) * LPT>();
+      };
+      static_assert(NST <= 4, "land() distinguishes up to two tiles in flight behind the awaited one");
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+      for (int s_ = 0; s_ < NST - 1; ++s_)
+        if (issued < kt1) { pieces(c0_t{}, clpt_t{}); ++issued; }
+      land(kt0);
+      __builtin_amdgcn_s_barrier();
+      for (int kt = kt0; kt < kt1 - 1; ++kt) {
+        if (issued < kt1) { pieces(c0_t{}, clpt_t{}); ++issued; }
+        land(kt + 1);
+        __builtin_amdgcn_s_barrier();
+      }
+      return;
+    }
+  }
+  f32x16 acc[CT][PT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
 #pragma unroll
     for (int b = 0; b < PT; ++b)
 #pragma unroll
@@ -808,16 +880,16 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
 
   const int frow = lane & 31, fhalf = lane >> 5;
   const int fswz = (frow >> 1) & 7;
-  const int a_off = (wave_co * 64 + frow) * 128;
+  const int a_off = (wave_co * (32 * CT) + frow) * 128;
   const int b_off = TILE_W + (wave_px * (32 * PT) + frow) * 128;
-  bf16x8 fa[2][2], fb[2][PT];
+  bf16x8 fa[2][CT], fb[2][PT];
   auto lds_read = [&](const unsigned char* base, int kk, int f) {
 #ifdef DSL_ABLATE_BUILD
     if (p.dbg & 64) return;
 #endif
     const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) fa[f][ct] = *reinterpret_cast<const bf16x8*>(base + a_off + ct * 32 * 128 + coff);
+    for (int ct = 0; ct < CT; ++ct) fa[f][ct] = *reinterpret_cast<const bf16x8*>(base + a_off + ct * 32 * 128 + coff);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) fb[f][pt] = *reinterpret_cast<const bf16x8*>(base + b_off + pt * 32 * 128 + coff);
   };
@@ -829,48 +901,81 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
     for (int pt = 0; pt < PT; ++pt)
       acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
   };
-  auto mma = [&](int f) {
-    mma_half(f, 0);
-    mma_half(f, 1);
+  auto mma_upto = [&](int f, int n) {       // cout tiles [0, n) of fragment set f
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      if (ct < n) mma_half(f, ct);
   };
+  auto mma = [&](int f) { mma_upto(f, CT); };
 
   static_assert((NST - 1) * LPT <= 63, "vmcnt range");
+#ifdef DSL_TRACE_BUILD
+  // s_memtime stamps of ONE workgroup's K loop (tools/trace_conv.py): [wave][iteration][point] in the LDS behind the ring, dumped
+  // to g_conv_trace at the end.  Points: 0 loop top, 1 every pre-barrier MFMA issued, 2 own LDS reads landed, 3 next tile's DMA
+  // landed, 4 barrier passed, 5 post-barrier MFMAs issued.
+  const bool tr_on = wi == p.dbg;
+  int tr_it = 0;
+  unsigned long long* tr_lds = reinterpret_cast<unsigned long long*>(smem + NST * STAGE) + wave * (kTraceIters * 8);
+#define TR(i)                                                                                  \
+  do {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if (tr_on && tr_it < kTraceIters) {                                                        \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                              \
+      if (lane == 0) tr_lds[tr_it * 8 + (i)] = t_;                                             \
+    }                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  } while (0)
+#else
+#define TR(i) do {} while (0)
+#endif
   // prologue: NST-1 whole tiles + the first pieces of the NST-th
+  if constexpr (LW == 0) {
 #pragma unroll
-  for (int s = 0; s < NST - 1; ++s) pieces(c0_t{}, clpt_t{});
-  pieces(c0_t{}, cp0_t{});
-  wait_vmcnt<(NST - 2) * LPT + P0>();
+    for (int s = 0; s < NST - 1; ++s) pieces(c0_t{}, clpt_t{});
+    pieces(c0_t{}, cp0_t{});
+    wait_vmcnt<(NST - 2) * LPT + P0>();
+  }
   __builtin_amdgcn_s_barrier();
   lds_read(smem, 0, 0);
   int slot = 0;
   for (int kt = kt0; kt < kt1 - 1; ++kt) {
     const unsigned char* base = smem + slot * STAGE;
     const int nslot = (slot + 1 == NST) ? 0 : slot + 1;
+    TR(0);
     lds_read(base, 1, 1);
-    pieces(cp0_t{}, cp1_t{});
+    if constexpr (LW == 0) pieces(cp0_t{}, cp1_t{});
     mma(0);
     lds_read(base, 2, 0);
-    pieces(cp1_t{}, clpt_t{});
+    if constexpr (LW == 0) pieces(cp1_t{}, clpt_t{});
     mma(1);
     lds_read(base, 3, 1);
     mma(0);
-    mma_half(1, 0);
-    sched_stage<2 * PT, 2 + PT, P1 - P0>();
-    sched_stage<2 * PT, 2 + PT, LPT - P1>();
-    sched_stage<2 * PT, 2 + PT, 0>();
-    sched_stage<PT, 0, 0>();
+    mma_upto(1, CT - HB);
+    sched_stage<CT * PT, CT + PT, LW ? 0 : P1 - P0>();
+    sched_stage<CT * PT, CT + PT, LW ? 0 : LPT - P1>();
+    sched_stage<CT * PT, CT + PT, 0>();
+    sched_stage<(CT - HB) * PT, 0, 0>();
     __builtin_amdgcn_sched_barrier(0);     // keep these MFMAs in front of the waits below
+    TR(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tile kt are in registers (issued >= PT MFMAs ago)
-    wait_vmcnt<(NST - 2) * LPT>();         // tile kt+1 landed (tiles kt+2 .. kt+NST-1 may stay in flight)
+    TR(2);
+    if constexpr (LW == 0) wait_vmcnt<(NST - 2) * LPT>();     // tile kt+1 landed (tiles kt+2 .. kt+NST-1 may stay in flight)
+    TR(3);
 #ifdef DSL_ABLATE_BUILD
     if (!(p.dbg & 32))
 #endif
     __builtin_amdgcn_s_barrier();          // ... and both hold for every wave
+    TR(4);
     lds_read(smem + nslot * STAGE, 0, 0);
-    pieces(c0_t{}, cp0_t{});               // start refilling the slot tile kt just vacated with tile kt+NST
-    mma_half(1, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 + PT, 0);
-    sched_stage<PT, 0, P0>();
+    if constexpr (LW == 0) pieces(c0_t{}, cp0_t{});           // start refilling the slot tile kt just vacated with tile kt+NST
+#pragma unroll
+    for (int ct = CT - HB; ct < CT; ++ct) mma_half(1, ct);
+    __builtin_amdgcn_sched_group_barrier(0x100, CT + PT, 0);
+    sched_stage<HB * PT, 0, LW ? 0 : P0>();
+    TR(5);
+#ifdef DSL_TRACE_BUILD
+    ++tr_it;
+#endif
     slot = nslot;
   }
   {                                        // last tile
@@ -882,11 +987,20 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
     lds_read(base, 3, 1);
     mma(0);
     mma(1);
-    sched_stage<2 * PT, 2 + PT, 0>();
-    sched_stage<2 * PT, 2 + PT, 0>();
-    sched_stage<2 * PT, 2 + PT, 0>();
+    sched_stage<CT * PT, CT + PT, 0>();
+    sched_stage<CT * PT, CT + PT, 0>();
+    sched_stage<CT * PT, CT + PT, 0>();
   }
-  wait_vmcnt<0>();                         // the out-of-range tail DMAs still write (zeros) into the ring
+  if constexpr (LW == 0) wait_vmcnt<0>();  // the out-of-range tail DMAs still write (zeros) into the ring
+#ifdef DSL_TRACE_BUILD
+  if (tr_on) {
+    __syncthreads();
+    for (int i = tid; i < WCO * WPX * kTraceIters * 8; i += T)
+      g_conv_trace[i] = reinterpret_cast<const unsigned long long*>(smem + NST * STAGE)[i];
+    if (tid == 0) g_conv_trace[8 * kTraceIters * 8] = (unsigned long long)(WCO * WPX);
+  }
+#undef TR
+#endif
 #ifdef DSL_ABLATE_BUILD
   if (p.dbg & 16) return;
 #endif
@@ -898,10 +1012,10 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
       if (gp >= totpx) continue;
       float* row = p.ws + ((long long)bz * totpx + gp) * p.cd_pad;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int co = co0 + wave_co * 64 + ct * 32 + 8 * g + 4 * (lane >> 5);
+          const int co = co0 + wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * (lane >> 5);
           f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
           *reinterpret_cast<f32x4*>(row + co) = o;
         }
@@ -914,14 +1028,16 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
   constexpr int CPX = 32 * WPX;
   constexpr int GPR = BCO / 8;
   static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
+  static_assert(T % GPR == 0, "a thread keeps its channel group across the staged rows");
+  const Affine8 aff = conv_affine8(p, co0 + (tid % GPR) * 8);     // (issued here: the loads fly during the first staging round)
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     __syncthreads();
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int col = wave_co * 64 + ct * 32 + 8 * g + 4 * fhalf;
+        const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
         f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
         *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
       }
@@ -934,9 +1050,12 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_pipe_kernel(const ConvK p
       const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32 + 16);
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#ifdef DSL_ABLATE_BUILD
+      if ((p.dbg & 512) && v[0] != 12345.678f) continue;      // epilogue without the scale / bias / addend loads and the stores
+#endif
       long long dpix, apix;
       conv_out_index(p, gp, dpix, apix);
-      conv_epilogue8(p, dpix, apix, co, v);
+      conv_epilogue8a(p, dpix, apix, co, v, aff);
     }
   }
 }
@@ -2842,6 +2961,9 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
 #ifdef DSL_ABLATE_BUILD
     { const char* e = getenv("DSL_ABLATE"); k.dbg = e ? atoi(e) : 0; }
 #endif
+#ifdef DSL_TRACE_BUILD
+    { const char* e = getenv("DSL_TRACE_WG"); k.dbg = e ? atoi(e) : -1; }
+#endif
     dim3 grid(d->cd_pad / c.bco, (px + c.bpx - 1) / c.bpx, splits);
     static const bool force_v2 = getenv("DSL_CONV_V2") != nullptr;
     const bool force_v2_kernel = force_v2 || conv_v2_only(d);
@@ -2853,6 +2975,9 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
       const size_t stg = (size_t)32 * c.wpx * (c.bco * 4 + 16);
       if (stg > lds) lds = stg;
     }
+#ifdef DSL_TRACE_BUILD
+    lds += 8 * 40 * 8 * 8;                 // the stamp area behind the ring
+#endif
     int prof = -1;
     if (dsl_prof_active()) prof = dsl_prof_begin(pick == 3 ? 0 : (pick == 0 ? 1 : 2), conv_algo_flops(d, px), st, conv_algo_bytes(d, px));
 #define LAUNCH2(A, B, C_, D, S_)                                                                               \
@@ -2882,6 +3007,29 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     // vs 386 img/s: one workgroup per CU) - these launches are bound by the 64 B/clk/CU L2 -> LDS path ((BCO + BPX) x 128 B per
     // K tile: 32 KB per 512 MFMA cycles for 128 x 128), not by issue or latency; only operand reuse across taps would cut that.
     static const int kt_mode = [] { const char* e = getenv("DSL_CONV_KT"); return e ? atoi(e) : 0; }();
+    static const int tall = [] { const char* e = getenv("DSL_CONV_TALL"); return e ? atoi(e) : 0; }();
+    static const int hold = [] { const char* e = getenv("DSL_CONV_HOLD"); return e ? atoi(e) : 0; }();
+    static const int ldw = [] { const char* e = getenv("DSL_CONV_LOADER"); return e ? atoi(e) : 0; }();
+#define LAUNCH3L(A, B, C_, D, S_, L_)                                                                          \
+  do {                                                                                                        \
+    static bool attr_set3l = false;                                                                           \
+    if (!attr_set3l) {                                                                                        \
+      hipFuncSetAttribute((const void*)conv_pipe_kernel<A, B, C_, D, S_, false, 1, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)lds);                                                                          \
+      attr_set3l = true;                                                                                      \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_, false, 1, L_>), dim3(8 * k.xcd_chunk), dim3(64 * (C_ * D + L_)), lds, st, k); \
+  } while (0)
+#define LAUNCH3H(A, B, C_, D, S_, H_)                                                                          \
+  do {                                                                                                        \
+    static bool attr_set3h = false;                                                                           \
+    if (!attr_set3h) {                                                                                        \
+      hipFuncSetAttribute((const void*)conv_pipe_kernel<A, B, C_, D, S_, false, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)lds);                                                                          \
+      attr_set3h = true;                                                                                      \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_, false, H_>), dim3(8 * k.xcd_chunk), dim3(64 * C_ * D), lds, st, k); \
+  } while (0)
     const long long n_wg = (long long)grid.x * grid.y * grid.z;
     const bool use_kt = !force_v2_kernel && !smallc && (pick == 3 || pick == 5 || pick == 6 || pick == 7) &&
                         (kt_mode == 2 || (kt_mode == 1 && n_wg <= 256LL * c.occ));
@@ -2935,8 +3083,12 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
       }
     } else {
       switch (pick) {
-        case 0: LAUNCH3(256, 192, 4, 2, 2); break;
-        case 1: LAUNCH3(256, 128, 4, 2, 3); break;
+        case 0:
+          if (tall & 1) LAUNCH3(256, 192, 2, 2, 2); else if (hold) LAUNCH3H(256, 192, 4, 2, 2, 2); else if (ldw) LAUNCH3L(256, 192, 4, 2, 2, 4); else LAUNCH3(256, 192, 4, 2, 2);
+          break;
+        case 1:
+          if (tall & 2) LAUNCH3(256, 128, 2, 2, 3); else if (hold) LAUNCH3H(256, 128, 4, 2, 3, 2); else if (ldw) LAUNCH3L(256, 128, 4, 2, 3, 4); else LAUNCH3(256, 128, 4, 2, 3);
+          break;
         case 2: LAUNCH3(128, 256, 2, 4, 3); break;
         case 3: LAUNCH3(128, 128, 2, 4, 2); break;
         case 4:
@@ -3649,3 +3801,10 @@ extern "C" int dsl_conv2d_wgrad_group(const dsl_wgrad_desc* descs, int count, vo
   DSL_CHECK(descs != nullptr, "dsl_conv2d_wgrad_group: null descriptors");
   return wgrad_launch(descs, count, stream);
 }
+
+#ifdef DSL_TRACE_BUILD
+// tools/trace_conv.py: the s_memtime stamps of the traced workgroup (DSL_TRACE_WG) of the last conv_pipe launch
+extern "C" int dsl_debug_conv_trace(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * (8 * 40 * 8 + 8)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -6,7 +6,7 @@ import subprocess
 import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SHAPES = {'l3a': (1024, 256, 1, (50, 84)), 'l3b': (256, 256, 3, (50, 84)), 'l3c': (256, 1024, 1, (50, 84)),
+SHAPES = {'p3': (256, 256, 3, (100, 168)), 'l3a': (1024, 256, 1, (50, 84)), 'l3b': (256, 256, 3, (50, 84)), 'l3c': (256, 1024, 1, (50, 84)),
           'l2a': (512, 128, 1, (100, 168)), 'l2b': (128, 128, 3, (100, 168)), 'l2c': (128, 512, 1, (100, 168)),
           'l4a': (2048, 512, 1, (25, 42)), 'l4b': (512, 512, 3, (25, 42)), 'l4c': (512, 2048, 1, (25, 42)),
           # weight-row stride experiments (row stride = K * 2 bytes): 960 / 1088 / 1984 input channels vs 1024 / 2048
