@@ -105,6 +105,60 @@ def fp8_step_timing(batch, steps=20, warm=5):
                      'v_mfma_scale_f32_32x32x64_f8f6f4, everything else (and the whole backward pass) bf16; off by default in the product')
 
 
+def datapath_timing(n_img=2, reps=20):
+    """SURVEY.md section 8 row f3 beside the headline: the loader-side image work of one batch on the GPU - the labeled stream's
+    pipeline (Resize -> PatchShuffle -> RandomFlip -> Normalize -> Pad: ONE launch) and the unlabeled stream's (the same +
+    RandomAugmentBBox_Fast + UBAug: uint8 canvases, one launch per augmentation pass) - from decoded uint8 images already resident
+    in HBM to the fp32 batch the detector takes; and the CPU restatement (oracle/datapath_oracle.py) on the same images."""
+    import random
+    from dsl_amd.datapath import GpuBatchPipeline
+    from oracle import datapath_oracle as DO
+    norm = dict(mean=[102.9801, 115.9465, 122.7717], std=[1.0, 1.0, 1.0], to_rgb=False)
+    head = [dict(type='LoadImageFromFile'), dict(type='LoadAnnotations', with_bbox=True),
+            dict(type='Resize', img_scale=[(1333, 640), (1333, 800)], multiscale_mode='value', keep_ratio=True),
+            dict(type='PatchShuffle', ratio=0.5, ranges=[0.0, 1.0], mode=['flip', 'flop']), dict(type='RandomFlip', flip_ratio=0.5)]
+    tail = [dict(type='Normalize', **norm), dict(type='Pad', size_divisor=32), dict(type='DefaultFormatBundle'),
+            dict(type='Collect', keys=['img', 'gt_bboxes', 'gt_labels', 'gt_bboxes_ignore'])]
+    rng = np.random.RandomState(7)
+    samples = []
+    for i in range(n_img):                      # COCO-sized sources (640 x 480 / 480 x 640)
+        h, w = (480, 640) if i % 2 == 0 else (640, 480)
+        b = synth_boxes(rng, 7)
+        b[:, 0::2] = np.clip(b[:, 0::2] * w / 1333.0, 0, w - 1)
+        b[:, 1::2] = np.clip(b[:, 1::2] * h / 800.0, 0, h - 1)
+        samples.append(dict(img=torch.from_numpy(rng.randint(0, 256, (h, w, 3)).astype(np.uint8)).cuda(), gt_bboxes=b,
+                            gt_labels=rng.randint(0, 80, len(b)), filename=f'synth{i}.jpg'))
+    out = {}
+    for name, pipe_cfg in (('labeled', head + tail), ('unlabeled', head + [dict(type='RandomAugmentBBox_Fast', aug_type='affine'),
+                                                                              dict(type='UBAug')] + tail)):
+        pipe = GpuBatchPipeline(pipe_cfg)
+        np.random.seed(11)
+        random.seed(11)
+        for _ in range(3):
+            pipe(samples)
+        torch.cuda.synchronize()
+        ts, passes, px = [], 0, 0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            b = pipe(samples)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+            passes += max(len(p_) for p_ in pipe.last_passes)
+            px += b['img'].shape[0] * b['img'].shape[2] * b['img'].shape[3]
+        ts.sort()
+        med = ts[len(ts) // 2]
+        out[name] = dict(ms_per_batch=round(med * 1e3, 3), imgs_per_s=round(n_img / med, 1), mean_aug_launches=round(passes / reps, 1),
+                         mean_canvas_mpix=round(px / reps / 1e6, 2))
+    # the CPU restatement of the labeled stream's image work on the same two images (numpy, one thread)
+    spec = [dict(img=s_['img'].cpu().numpy(), scale=(1333, 800), ps=None, flip=bool(i & 1)) for i, s_ in enumerate(samples)]
+    t0 = time.perf_counter()
+    DO.prepare_batch(spec, norm['mean'], norm['std'], norm['to_rgb'], 32)
+    out['cpu_port_labeled'] = dict(ms_per_batch=round((time.perf_counter() - t0) * 1e3, 1), cores=1, kind='port')
+    out['note'] = ('wall time per batch of %d images including the host-side parameter draws and box arithmetic, sources resident as uint8 in '
+                   'HBM; algorithmic bytes of the labeled launch: 3 B read per source pixel + 12 B written per canvas pixel' % n_img)
+    return out
+
+
 def cpu_baseline(batch, seed=0, warmup=1, steps=2):
     """The CPU restatement of the SAME step (oracle/fcos_oracle.py, fp32 torch on the host cores), timed on a
     bounded sample: `warmup` untimed + `steps` timed full N=2 steps at 800x1344 (forward + loss + autograd backward +
@@ -383,7 +437,7 @@ def main():
                                     'its all-reduce is done (per-bucket SGD), so only traffic still in flight at step_ms is exposed'))
     if rank == 0 and world == 1 and not args.no_dsl:
         del opt
-        extra = dict(dsl_iteration=dsl_iteration_timing(), fp8_towers=fp8_step_timing(batch))
+        extra = dict(dsl_iteration=dsl_iteration_timing(), fp8_towers=fp8_step_timing(batch), datapath=datapath_timing())
         if roof is not None:        # BASELINE.json configs[2] beside the headline, also where a record that keeps `roofline` keeps it
             roof['configs2_dsl_iteration_ms'] = {k: v for k, v in extra['dsl_iteration'].items() if k.startswith('ms_per_iter')}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

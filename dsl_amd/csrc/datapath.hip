@@ -120,17 +120,21 @@ __device__ __forceinline__ unsigned hash_u32(unsigned x) {
   return x;
 }
 
+constexpr int kLumaRows = 32;            // image rows per block of aug_luma_sum_kernel: one 64-bit atomic per 256 x 32 pixels
 __global__ __launch_bounds__(256) void aug_luma_sum_kernel(const AugK p) {
   const int img = blockIdx.z;
   const dsl_aug_item it = p.items[img];
   if (it.kind != DSL_AUG_CONTRAST) return;
   __shared__ unsigned long long sh[4];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * kLumaRows;
+  if (y0 >= it.h || (int)(blockIdx.x * blockDim.x) >= it.w) return;              // block-uniform
   unsigned long long v = 0;
-  if (x < it.w && y < it.h) {
-    const unsigned char* s = p.src + (((long long)img * p.hc + y) * p.wc + x) * 3;
-    v = (unsigned long long)luma_u8(s[0], s[1], s[2]);           // the stored channel order plays RGB (the reference hands
-                                                                   // mmcv's BGR array to ToPILImage as is)
+  if (x < it.w) {
+    const int y1 = min(y0 + kLumaRows, it.h);
+    for (int y = y0; y < y1; ++y) {
+      const unsigned char* s = p.src + (((long long)img * p.hc + y) * p.wc + x) * 3;
+      v += (unsigned long long)luma_u8(s[0], s[1], s[2]);        // the stored channel order plays RGB (the reference hands
+    }                                                            // mmcv's BGR array to ToPILImage as is)
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -354,7 +358,7 @@ extern "C" int dsl_image_aug(const dsl_aug_item* items_dev, int n, const unsigne
       dsl_set_error("dsl_image_aug: memset failed");
       return -2;
     }
-    hipLaunchKernelGGL(aug_luma_sum_kernel, grid, dim3(256), 0, st, k);
+    hipLaunchKernelGGL(aug_luma_sum_kernel, dim3(grid.x, (hc + kLumaRows - 1) / kLumaRows, n), dim3(256), 0, st, k);
   }
   hipLaunchKernelGGL(image_aug_kernel, grid, dim3(256), 0, st, k);
   DSL_LAUNCH_CHECK("image_aug_kernel");

@@ -408,18 +408,18 @@ class GpuBatchPipeline:
             b = torch.empty_like(a)
             sums = torch.zeros(n, dtype=torch.int64, device=self.device)
             L.check(L.lib.dsl_image_prep_u8(L.ptr(tab), n, L.ptr(a), hc, wc, L.stream_ptr()), 'dsl_image_prep_u8')
-            keep = [a, b, sums]
+            # every pass's item table in ONE host -> device copy
+            its = (L.AugItem * (n * n_pass))()
+            need_mean = [0] * n_pass
             for k in range(n_pass):
-                its = (L.AugItem * n)()
-                need_mean = 0
                 for i, r in enumerate(results):
-                    it, ps = its[i], r.get('_aug', ())
+                    it, ps = its[k * n + i], r.get('_aug', ())
                     it.h, it.w = r['img_shape'][0], r['img_shape'][1]
                     if k >= len(ps):
                         continue
                     ps_k = ps[k]
                     it.kind = ps_k['kind']
-                    need_mean |= int(it.kind == L.AUG_CONTRAST)
+                    need_mean[k] |= int(it.kind == L.AUG_CONTRAST)
                     it.f[0] = float(ps_k.get('f', 0.0))
                     if it.kind == L.AUG_AFFINE:
                         x0, y0, x1, y1 = ps_k['roi']
@@ -433,9 +433,12 @@ class GpuBatchPipeline:
                         for q, rc in enumerate(ps_k['rects'][:3]):
                             for e in range(4):
                                 it.rect[q][e] = int(rc[e])
-                at = torch.frombuffer(bytearray(bytes(its)), dtype=torch.uint8).to(self.device)
-                keep.append(at)
-                L.check(L.lib.dsl_image_aug(L.ptr(at), n, L.ptr(a), L.ptr(b), hc, wc, L.ptr(sums), need_mean, L.stream_ptr()), 'dsl_image_aug')
+            at = torch.frombuffer(bytearray(bytes(its)), dtype=torch.uint8).to(self.device)
+            keep = [a, b, sums, at]
+            isz = C.sizeof(L.AugItem)
+            for k in range(n_pass):
+                L.check(L.lib.dsl_image_aug(at.data_ptr() + k * n * isz, n, L.ptr(a), L.ptr(b), hc, wc, L.ptr(sums), need_mean[k],
+                                            L.stream_ptr()), 'dsl_image_aug')
                 a, b = b, a
             L.check(L.lib.dsl_image_normalize(L.ptr(a), L.ptr(tab), n, L.ptr(out), hc, wc, L.stream_ptr()), 'dsl_image_normalize')
             srcs = srcs + keep
