@@ -38,15 +38,16 @@ void dsl_prof_end(int id, hipStream_t st);
 
 // ---- bf16 <-> fp32 (round to nearest even, as torch .bfloat16()) -------------------------------
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32: round to nearest even, NaN quieted) - one instruction per PAIR where the
+// integer formulation (and / compare / add / shift / select per value) costs ~7 per value; in the staged convolution epilogue
+// that was most of the ~120 VALU instructions per 16-byte store that made it issue-bound (tools/trace_conv.py).
+typedef float dsl_f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 dsl_bf16x2_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const dsl_f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dsl_bf16x2_));
 }
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 

@@ -63,6 +63,14 @@ struct PixRow {
   bool ok;
 };
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. makes every wave wait until its global
+// STORES have been acknowledged - in an epilogue that alternates "stage a slab in LDS" and "store it" that serialises the store
+// latency (1 - 2 us under load) once per slab.  The stores need no ordering against the LDS reuse: their data left the registers
+// at issue.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ void decode_pixel(const ConvK& p, int gp, int& seg, int& img, int& y, int& x) {
   seg = 0;
 #pragma unroll
@@ -235,6 +243,83 @@ __device__ __forceinline__ void conv_epilogue8a(const ConvK& p, long long dpix, 
     u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
     *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.dst) + dpix * p.ldd + co) = o;
   }
+}
+
+// single-rounding multiply / add for epilogues that must round like the general path's separate "*= scale" and "+= bias" steps
+#pragma clang fp contract(off)
+__device__ __forceinline__ float mul_nc(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_nc(float a, float b) { return a + b; }
+#pragma clang fp contract(fast)
+
+// The common case of conv_epilogue8a with everything loop-invariant taken out: destination pixel == grid pixel (ident), 8 whole
+// channels, bf16 output, the addend on the destination's own pixel grid.  Same operations in the same order (scale, bias,
+// mask-first, addend, mask-last, ReLU, round) - only the flag tests, the 64-bit index arithmetic and the pixel decode of the
+// general path are gone: the staged epilogue's item loop was ISSUE-bound on them (~190 VALU instructions and ~1 500 cycles per
+// 16-byte store, tools/trace_conv.py: 5 700 - 7 100 cycles per 64-pixel slab against ~1 000 for the stores themselves).
+struct EpiFast {
+  bool on;                                 // uniform: the launch qualifies
+  bool has_scale, has_bias, mask_first, mask_last, has_add, relu;
+  uint16_t* dst;                           // + co already applied
+  const uint16_t* add;
+  const uint16_t* mask;
+  int ldd, lda, ldm;
+};
+__device__ __forceinline__ EpiFast conv_epi_fast(const ConvK& p, int co) {
+  EpiFast e;
+  e.on = p.ident && !(p.flags & (DSL_CONV_OUT_F32 | DSL_CONV_ADD_UPSAMPLE));
+  e.has_scale = p.scale != nullptr;
+  e.has_bias = p.bias != nullptr;
+  e.mask_first = (p.flags & DSL_CONV_MASK_FIRST) != 0 && p.mask != nullptr;
+  e.mask_last = (p.flags & DSL_CONV_MASK_LAST) != 0 && p.mask != nullptr;
+  e.has_add = p.addend != nullptr;
+  e.relu = (p.flags & DSL_CONV_RELU_OUT) != 0;
+  e.dst = reinterpret_cast<uint16_t*>(p.dst) + co;
+  e.add = p.addend + co;
+  e.mask = p.mask + co;
+  e.ldd = p.ldd; e.lda = p.lda; e.ldm = p.ldm;
+  return e;
+}
+__device__ __forceinline__ void conv_epilogue8_fast(const EpiFast& e, const Affine8& a, int gp, f32x4 lo, f32x4 hi) {
+  float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  if (e.has_scale) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] *= a.s0[i]; v[4 + i] *= a.s1[i]; }
+  }
+  if (e.has_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] += a.b0[i]; v[4 + i] += a.b1[i]; }
+  }
+  float m[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  if (e.mask_first || e.mask_last) {
+    const u32x4 mm = *reinterpret_cast<const u32x4*>(e.mask + (long long)gp * e.ldm);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m[2 * i] = bflo(mm[i]) > 0.f ? 1.f : 0.f;
+      m[2 * i + 1] = bfhi(mm[i]) > 0.f ? 1.f : 0.f;
+    }
+  }
+  if (e.mask_first) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= m[i];
+  }
+  if (e.has_add) {
+    const u32x4 aa = *reinterpret_cast<const u32x4*>(e.add + (long long)gp * e.lda);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] += bflo(aa[i]);
+      v[2 * i + 1] += bfhi(aa[i]);
+    }
+  }
+  if (e.mask_last) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= m[i];
+  }
+  if (e.relu) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+  *reinterpret_cast<u32x4*>(e.dst + (long long)gp * e.ldd) = o;
 }
 
 __device__ __forceinline__ void conv_out_index(const ConvK& p, int gp, long long& dpix, long long& apix) {
@@ -615,7 +700,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_glds_kernel(const ConvK p
   static_assert(CPX * ROWB <= NST * STAGE, "epilogue staging must fit in the stage memory");
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    __syncthreads();                            // previous chunk fully read (first pass: all MFMA operands consumed)
+    lds_barrier();                            // previous chunk fully read (first pass: all MFMA operands consumed)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -624,7 +709,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_glds_kernel(const ConvK p
         f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
         *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
       }
-    __syncthreads();
+    lds_barrier();
     for (int id = tid; id < CPX * GPR; id += T) {
       const int pl = id / GPR, cg = id - pl * GPR;
       const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
@@ -668,7 +753,7 @@ __device__ __forceinline__ void sched_stage() {      // NMF x { 1 MFMA [, 1 DS r
 // are packed).
 #ifdef DSL_TRACE_BUILD
 constexpr int kTraceIters = 40;
-__device__ unsigned long long g_conv_trace[8 * kTraceIters * 8 + 8];
+__device__ unsigned long long g_conv_trace[8 * kTraceIters * 8 + 8 * 16 + 8];
 #endif
 
 // LW > 0: LW extra "loader" waves issue every LDS-DMA piece; the WCO x WPX MFMA waves only read fragments and multiply.  Why
@@ -993,13 +1078,32 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
   }
   if constexpr (LW == 0) wait_vmcnt<0>();  // the out-of-range tail DMAs still write (zeros) into the ring
 #ifdef DSL_TRACE_BUILD
-  if (tr_on) {
-    __syncthreads();
-    for (int i = tid; i < WCO * WPX * kTraceIters * 8; i += T)
-      g_conv_trace[i] = reinterpret_cast<const unsigned long long*>(smem + NST * STAGE)[i];
-    if (tid == 0) g_conv_trace[8 * kTraceIters * 8] = (unsigned long long)(WCO * WPX);
-  }
 #undef TR
+  // epilogue stamps: [wave][16] behind the K-loop stamps; 0 = epilogue entered, then per staged slab: 1 + 3 r = first barrier
+  // passed, 2 + 3 r = slab written and second barrier passed, 3 + 3 r = the slab's stores issued
+  unsigned long long* tre_lds = reinterpret_cast<unsigned long long*>(smem + NST * STAGE) + 8 * kTraceIters * 8 + wave * 16;
+#define TRE(i)                                                                                 \
+  do {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if (tr_on) {                                                                               \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                              \
+      if (lane == 0) tre_lds[(i)] = t_;                                                        \
+    }                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  } while (0)
+  TRE(0);
+  auto trace_dump = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TRE(15);                                  // every store of this wave acknowledged
+    if (tr_on) {
+      __syncthreads();
+      for (int i = tid; i < 8 * kTraceIters * 8 + 8 * 16; i += T)
+        g_conv_trace[i] = reinterpret_cast<const unsigned long long*>(smem + NST * STAGE)[i];
+      if (tid == 0) g_conv_trace[8 * kTraceIters * 8 + 8 * 16] = (unsigned long long)(WCO * WPX);
+    }
+  };
+#else
+#define TRE(i) do {} while (0)
 #endif
 #ifdef DSL_ABLATE_BUILD
   if (p.dbg & 16) return;
@@ -1030,9 +1134,78 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
   static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
   static_assert(T % GPR == 0, "a thread keeps its channel group across the staged rows");
   const Affine8 aff = conv_affine8(p, co0 + (tid % GPR) * 8);     // (issued here: the loads fly during the first staging round)
+  const EpiFast ef = conv_epi_fast(p, co0 + (tid % GPR) * 8);
+  // ---- "pure" epilogue (no addend, no mask, bf16 out, ident): scale / bias / ReLU / rounding happen in the accumulator registers
+  // (a lane owns 4 consecutive couts of one pixel per 8-cout group), the WHOLE tile is staged once as bf16 rows [pixel][BCO] and
+  // leaves as 16-byte stores without a single VALU instruction in the store loop: two barriers instead of 2 * PT, half the LDS
+  // bytes, same arithmetic in the same order as the staged fp32 path (mul_nc / add_nc: one rounding each).
+  constexpr int ROWH = BCO * 2 + 16;
+  static_assert((long long)BPX * ROWH <= (long long)NST * STAGE, "the bf16 tile fits in the ring");
+  // A ReLU mask applied LAST (the data gradients: round(v * m), m in {0, 1}) commutes with the rounding - m ? round(v) : +-0 with v's
+  // sign - so it is applied to the staged bf16 words in the store loop, bit for bit what the fp32 path produces for finite v.
+  if (ef.on && !ef.has_add && !ef.mask_first && !(ef.mask_last && ef.relu) && (p.cd & 7) == 0) {
+    lds_barrier();                           // every wave is done with the ring (its DMA has landed: wait_vmcnt<0> above)
+    // (cout group outermost: a lane keeps ONE group's scale / bias at a time - all of them at once cost 64 registers and an
+    // occupancy step on the small tiles)
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    __syncthreads();
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
+        const bool in = co0 + col + 3 < p.cd;
+        const f32x4 sc = (ef.has_scale && in) ? *reinterpret_cast<const f32x4*>(p.scale + co0 + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 bi = (ef.has_bias && in) ? *reinterpret_cast<const f32x4*>(p.bias + co0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = acc[ct][pt][4 * g + j];
+            if (ef.has_scale) v[j] = mul_nc(v[j], sc[j]);
+            if (ef.has_bias) v[j] = add_nc(v[j], bi[j]);
+            if (ef.relu) v[j] = fmaxf(v[j], 0.f);
+          }
+          const int row = wave_px * (32 * PT) + pt * 32 + frow;
+          u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(smem + row * ROWH + col * 2) = o;
+        }
+      }
+    lds_barrier();
+    TRE(2);
+    {
+      constexpr int NITP = BPX * GPR / T;
+      static_assert(BPX * GPR % T == 0, "whole items per thread");
+      const int row0 = tid / GPR, cgp = tid % GPR;
+      if (co0 + cgp * 8 < p.cd) {
+        const unsigned char* rd = smem + row0 * ROWH + cgp * 16;
+        uint16_t* out = reinterpret_cast<uint16_t*>(p.dst) + (co0 + cgp * 8);
+#pragma unroll 4
+        for (int n_ = 0; n_ < NITP; ++n_) {
+          const int gp = px0 + row0 + n_ * (T / GPR);
+          if (gp < totpx) {
+            u32x4 r = *reinterpret_cast<const u32x4*>(rd + n_ * (T / GPR) * ROWH);
+            if (ef.mask_last) {
+              const u32x4 mm = *reinterpret_cast<const u32x4*>(ef.mask + (long long)gp * ef.ldm);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                r[e] &= (bflo(mm[e]) > 0.f ? 0xffffu : 0x8000u) | (bfhi(mm[e]) > 0.f ? 0xffff0000u : 0x80000000u);
+            }
+            *reinterpret_cast<u32x4*>(out + (long long)gp * p.ldd) = r;
+          }
+        }
+      }
+    }
+    TRE(3);
+#ifdef DSL_TRACE_BUILD
+    trace_dump();
+#endif
+    return;
+  }
+  // The slab loop is NOT unrolled and the item loops are rolled: this code runs once per workgroup, straight-line copies of it per
+  // slab are cold in the instruction cache every time (tools/trace_conv.py: 5 000 - 7 000 cycles per slab whatever the body did,
+  // against ~1 000 for the same stores from warm code) - only the accumulator -> LDS writes need the slab index at compile time.
+  auto stage_slab = [&](auto pt_c) {
+    constexpr int pt = decltype(pt_c)::value;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -1041,7 +1214,35 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
         f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
         *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
       }
-    __syncthreads();
+  };
+  static_assert(PT <= 4, "slab dispatch");
+#pragma nounroll
+  for (int pt = 0; pt < PT; ++pt) {
+    lds_barrier();
+    TRE(1 + 3 * pt);
+    if (pt == 0) stage_slab(std::integral_constant<int, 0>{});
+    else if (pt == 1) stage_slab(std::integral_constant<int, (PT > 1 ? 1 : 0)>{});
+    else if (pt == 2) stage_slab(std::integral_constant<int, (PT > 2 ? 2 : 0)>{});
+    else stage_slab(std::integral_constant<int, (PT > 3 ? 3 : 0)>{});
+    lds_barrier();
+    TRE(2 + 3 * pt);
+    if (ef.on && aff.full) {                 // lean item loop (uniform test; aff.full is false only in a partial last channel group)
+      constexpr int NIT = CPX * GPR / T;     // items per thread and slab: rows T / GPR apart
+      static_assert(CPX * GPR % T == 0, "whole items per thread");
+      const int pl0 = tid / GPR;
+      const unsigned char* rd = smem + pl0 * ROWB + (tid % GPR) * 32;
+#pragma nounroll
+      for (int n_ = 0; n_ < NIT; ++n_) {
+        const int pl = pl0 + n_ * (T / GPR);
+        const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
+        if (gp < totpx)
+          conv_epilogue8_fast(ef, aff, gp, *reinterpret_cast<const f32x4*>(rd + n_ * (T / GPR) * ROWB),
+                              *reinterpret_cast<const f32x4*>(rd + n_ * (T / GPR) * ROWB + 16));
+      }
+      TRE(3 + 3 * pt);
+      continue;
+    }
+#pragma nounroll
     for (int id = tid; id < CPX * GPR; id += T) {
       const int pl = id / GPR, cg = id - pl * GPR;
       const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
@@ -1057,7 +1258,12 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
       conv_out_index(p, gp, dpix, apix);
       conv_epilogue8a(p, dpix, apix, co, v, aff);
     }
+    TRE(3 + 3 * pt);
   }
+#ifdef DSL_TRACE_BUILD
+  trace_dump();
+#endif
+#undef TRE
 }
 
 // ================================================================================================
@@ -1313,7 +1519,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_f8_kernel(const ConvK p) 
   static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1322,7 +1528,7 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_f8_kernel(const ConvK p) 
         f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
         *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
       }
-    __syncthreads();
+    lds_barrier();
     for (int id = tid; id < CPX * GPR; id += T) {
       const int pl = id / GPR, cg = id - pl * GPR;
       const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
@@ -1602,7 +1808,7 @@ __device__ __forceinline__ void conv_kt_body(const ConvK& p, unsigned char* smem
   static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1611,7 +1817,7 @@ __device__ __forceinline__ void conv_kt_body(const ConvK& p, unsigned char* smem
         f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
         *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
       }
-    __syncthreads();
+    lds_barrier();
     for (int id = tid; id < CPX * GPR; id += T) {
       const int pl = id / GPR, cg = id - pl * GPR;
       const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
@@ -2976,7 +3182,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
       if (stg > lds) lds = stg;
     }
 #ifdef DSL_TRACE_BUILD
-    lds += 8 * 40 * 8 * 8;                 // the stamp area behind the ring
+    lds += 8 * 40 * 8 * 8 + 8 * 16 * 8;    // the stamp area behind the ring
 #endif
     int prof = -1;
     if (dsl_prof_active()) prof = dsl_prof_begin(pick == 3 ? 0 : (pick == 0 ? 1 : 2), conv_algo_flops(d, px), st, conv_algo_bytes(d, px));
@@ -3805,6 +4011,6 @@ extern "C" int dsl_conv2d_wgrad_group(const dsl_wgrad_desc* descs, int count, vo
 #ifdef DSL_TRACE_BUILD
 // tools/trace_conv.py: the s_memtime stamps of the traced workgroup (DSL_TRACE_WG) of the last conv_pipe launch
 extern "C" int dsl_debug_conv_trace(unsigned long long* host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * (8 * 40 * 8 + 8)) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * (8 * 40 * 8 + 8 * 16 + 8)) == hipSuccess ? 0 : -1;
 }
 #endif

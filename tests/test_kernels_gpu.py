@@ -621,3 +621,22 @@ def test_sgd_ema_cast_packdgrad(K):
     ref = torch.zeros(256, 3, 3, 128)
     ref[..., :80] = (w * sc[:, None, None, None]).permute(3, 1, 2, 0)
     assert torch.equal(out.cpu(), ref.bfloat16())
+
+
+def test_bf16_rounding_bit_patterns(K):
+    """fp32 -> bf16 of every kernel's epilogue (common.hpp pack2bf: v_cvt_pk_bf16_f32 on gfx950) against torch's .bfloat16() on the
+    cases that separate rounding rules: exact ties up and down (round to nearest EVEN), the carry into the exponent, the largest
+    finite value (rounds to inf), denormals, signed zeros, infinities, NaNs (stay NaN), and two million random bit patterns."""
+    L, _ = K
+    g = torch.Generator().manual_seed(5)
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (1 << 21,), generator=g, dtype=torch.int64).to(torch.int32)
+    special = torch.tensor([0x3f808000, 0x3f818000, 0x3f807fff, 0x3f808001, 0x3f7f8000, 0x7f7fffff, 0x7f7f8000, 0x00000001, 0x00008000,
+                            0x00018000, 0x807fffff, 0x00000000, -0x80000000, 0x7f800000, -0x00800000, 0x7fc00000, 0x7f800001, -0x00000001,
+                            0x477fe000, 0x477ff000, 0x3effffff, 0x3f800000, 0x3f80ffff, 0x00808000], dtype=torch.int64).to(torch.int32)
+    x = torch.cat([special, bits]).view(torch.float32)
+    y = torch.empty(x.numel(), dtype=torch.bfloat16, device='cuda')
+    L.check(L.lib.dsl_cast_bf16(L.ptr(x.cuda()), L.ptr(y), x.numel(), L.stream_ptr()), 'dsl_cast_bf16')
+    got, want = y.cpu().view(torch.int16), x.bfloat16().view(torch.int16)
+    nan = torch.isnan(x)
+    assert torch.equal(got[~nan], want[~nan])
+    assert torch.isnan(y.cpu()[nan].float()).all()

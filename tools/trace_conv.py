@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from dsl_amd import _lib as L
 from dsl_amd import ops
-SHAPES = {'l3a': (1024, 256, 1, (50, 84)), 'l3b': (256, 256, 3, (50, 84)), 'l3c': (256, 1024, 1, (50, 84)), 'l2b': (128, 128, 3, (100, 168)),
+SHAPES = {'p3': (256, 256, 3, (100, 168)), 'l3a': (1024, 256, 1, (50, 84)), 'l3b': (256, 256, 3, (50, 84)), 'l3c': (256, 1024, 1, (50, 84)), 'l2b': (128, 128, 3, (100, 168)),
           'l4b': (512, 512, 3, (25, 42))}
 which = sys.argv[1] if len(sys.argv) > 1 else 'head'
 force = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -47,10 +47,11 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 print(f'{which}: {e0.elapsed_time(e1) * 100:.1f} us per launch (instrumented build)')
-buf = np.zeros(8 * 40 * 8 + 8, np.uint64)
+buf = np.zeros(8 * 40 * 8 + 8 * 16 + 8, np.uint64)
 L.lib.dsl_debug_conv_trace.argtypes = [C.c_void_p]
 assert L.lib.dsl_debug_conv_trace(buf.ctypes.data) == 0
-nw = int(buf[8 * 40 * 8])
+nw = int(buf[8 * 40 * 8 + 8 * 16])
+epi = buf[8 * 40 * 8:8 * 40 * 8 + 8 * 16].reshape(8, 16)[:nw].astype(np.int64)
 t = buf[:8 * 40 * 8].reshape(8, 40, 8)[:nw].astype(np.int64)
 iters = min(40, ci * k * k // 64 - 1)           # the loop body runs ktiles - 1 times (split-K launches: fewer - check the period line)
 t = t[:, :iters, :6]
@@ -70,3 +71,11 @@ for wv in range(nw):
     print(f'   wave {wv}:', (t[wv, 4] - base).tolist(), (t[wv, 5] - base).tolist())
 print('arrival skew at the barrier (stamp 3, max - min over waves), K tiles 2..: mean %.0f' % (t[:, 2:, 3].max(0) - t[:, 2:, 3].min(0)).mean())
 print('release skew after the barrier (stamp 4): mean %.0f' % (t[:, 2:, 4].max(0) - t[:, 2:, 4].min(0)).mean())
+
+# epilogue: stamps relative to the earliest epilogue entry
+e0 = epi[:, 0].min()
+print('epilogue stamps per wave, cycles from the first wave entering the epilogue: entry | per slab: barrier 1, slab staged + barrier 2, stores issued | all stores acknowledged')
+npt = 3 if which in ('head', 'p3') and force in (0, 1) else 2
+for wv in range(nw):
+    print(f'   wave {wv}:', int(epi[wv, 0] - e0), [[int(epi[wv, 1 + 3 * r + j] - e0) for j in range(3)] for r in range(npt)], int(epi[wv, 15] - e0))
+print('K loop end -> epilogue entry (last stamp 5 to entry, wave 0): %d' % (epi[0, 0] - t[0, iters - 1, 5]))
