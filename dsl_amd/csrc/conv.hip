@@ -1013,6 +1013,9 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
 #else
 #define TR(i) do {} while (0)
 #endif
+  // Static priority for the second-dispatched half of an 8-wave workgroup: on each SIMD the younger wave otherwise loses every
+  // issue arbitration to its partner and reaches the K loop's barrier ~750 cycles late (tools/trace_conv.py); measured + 0.75 % on the step.
+  if (WCO * WPX == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   // prologue: NST-1 whole tiles + the first pieces of the NST-th
   if constexpr (LW == 0) {
 #pragma unroll
