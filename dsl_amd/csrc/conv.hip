@@ -2053,6 +2053,30 @@ __device__ __forceinline__ u32x2 lds_tr_read_b64(unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+// ... with the constant part of the address in the instruction's 16-bit offset field (inline asm is opaque to the compiler: given
+// the whole address in a register it spends one v_add per read - 24 of the 33 VALU instructions per stage of wgrad_pipe's K loop)
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_tr_read_b64_o(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "DS offset field");
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// read (k-step kk, half hi) of a fragment column whose (stage, column) address is `base`: kk and hi are constants after unrolling
+template <int ROWB, int KK>
+__device__ __forceinline__ u32x2 lds_tr_read_kh(unsigned base, int kk, int hi) {
+  static_assert(KK <= 4, "k-steps per stage");
+  switch (kk * 2 + hi) {
+    case 0: return lds_tr_read_b64_o<0>(base);
+    case 1: return lds_tr_read_b64_o<4 * ROWB>(base);
+    case 2: return lds_tr_read_b64_o<16 * ROWB>(base);
+    case 3: return lds_tr_read_b64_o<20 * ROWB>(base);
+    case 4: return lds_tr_read_b64_o<32 * ROWB>(base);
+    case 5: return lds_tr_read_b64_o<36 * ROWB>(base);
+    case 6: return lds_tr_read_b64_o<48 * ROWB>(base);
+    default: return lds_tr_read_b64_o<52 * ROWB>(base);
+  }
+}
 struct Frag {
   u32x2 lo, hi;
 };
@@ -2223,13 +2247,13 @@ __device__ __forceinline__ void wgrad_glds_body(const WgK& p, const int bid, uns
     for (int ct = 0; ct < CT; ++ct) {
       const unsigned ad = stage_addr + a_off[ct] + kk * 16 * YB;
       fa[ct].lo = lds_tr_read_b64(ad);
-      fa[ct].hi = lds_tr_read_b64(ad + 4 * YB);
+      fa[ct].hi = lds_tr_read_b64_o<4 * YB>(ad);
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const unsigned ad = stage_addr + b_off[it] + kk * 16 * XB;
       fb[it].lo = lds_tr_read_b64(ad);
-      fb[it].hi = lds_tr_read_b64(ad + 4 * XB);
+      fb[it].hi = lds_tr_read_b64_o<4 * XB>(ad);
     }
   };
   auto mma = [&](Frag (&fa)[CT], Frag (&fb)[IT]) {
@@ -2560,23 +2584,29 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
   }
   Frag fa[2][CT], fb[2][IT];
   constexpr int NR = 2 * (CT + IT);         // fragment reads per k-step
-  auto rd = [&](unsigned stage_addr, int kk, int f, int j) {      // read j of the k-step's NR (j is a constant after unrolling)
+  // fragment column addresses of the stage being READ (one v_add per column and stage; the k-step / half offsets are immediates)
+  unsigned ra[CT], rb[IT];
+  auto set_read_stage = [&](unsigned stage_addr) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) ra[ct] = stage_addr + a_off[ct];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) rb[it] = stage_addr + b_off[it];
+  };
+  auto rd = [&](int kk, int f, int j) {      // read j of the k-step's NR (kk, j are constants after unrolling)
 #ifdef DSL_ABLATE_BUILD
     if (p.dbg & 8) return;
 #endif
     if (j < 2 * CT) {
       const int ct = j >> 1;
-      const unsigned ad = stage_addr + a_off[ct] + kk * 16 * YB + (j & 1) * 4 * YB;
-      if (j & 1) fa[f][ct].hi = lds_tr_read_b64(ad); else fa[f][ct].lo = lds_tr_read_b64(ad);
+      if (j & 1) fa[f][ct].hi = lds_tr_read_kh<YB, KK>(ra[ct], kk, 1); else fa[f][ct].lo = lds_tr_read_kh<YB, KK>(ra[ct], kk, 0);
     } else {
       const int it = (j - 2 * CT) >> 1;
-      const unsigned ad = stage_addr + b_off[it] + kk * 16 * XB + (j & 1) * 4 * XB;
-      if (j & 1) fb[f][it].hi = lds_tr_read_b64(ad); else fb[f][it].lo = lds_tr_read_b64(ad);
+      if (j & 1) fb[f][it].hi = lds_tr_read_kh<XB, KK>(rb[it], kk, 1); else fb[f][it].lo = lds_tr_read_kh<XB, KK>(rb[it], kk, 0);
     }
   };
-  auto issue = [&](unsigned stage_addr, int kk, int f) {
+  auto issue = [&](int kk, int f) {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) rd(stage_addr, kk, f, j);
+    for (int j = 0; j < NR; ++j) rd(kk, f, j);
   };
   auto wait_lds = [&](int f) {       // every outstanding LDS read of this wave has landed; the registers it wrote change HERE
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2630,7 +2660,7 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
   };
   // one k-step's MFMAs with the DMA pieces [lo, hi) of the stage issued between them: one piece behind every second MFMA
   // (everything here is pinned in source order)
-  auto block = [&](int f, int lo, int hi, unsigned rd_stage, int rd_kk) {
+  auto block = [&](int f, int lo, int hi, int rd_kk) {
     bf16x8 a[CT], b[IT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -2659,7 +2689,7 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
       // on LDS issue for as long as the block's MFMAs take: measured, the two simply added up)
 #pragma unroll
       for (int j = 0; j < NR; ++j)
-        if (j >= m * NR / NM && j < (m + 1) * NR / NM) rd(rd_stage, rd_kk, f ^ 1, j);
+        if (j >= m * NR / NM && j < (m + 1) * NR / NM) rd(rd_kk, f ^ 1, j);
       if ((m & 1) == 1 && k < hi) {
         piece(k);
         ++k;
@@ -2696,7 +2726,8 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
   wait_vmcnt<(NST - 2) * P>();                   // stage kt0 landed, and the descriptors fetched with it (stage kt0 + NST - 1's)
   __builtin_amdgcn_s_barrier();
   desc_read();
-  issue(lds_base, 0, 0);
+  set_read_stage(lds_base);
+  issue(0, 0);
 
   unsigned dbr[8];
   int slot_c = 0;
@@ -2733,8 +2764,12 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgK& p, const int bid, uns
       __builtin_amdgcn_sched_barrier(0);
       // this k-step's MFMAs, between them the fragment reads of the next k-step (the last k-step: of the next stage's first,
       // behind the barrier above) and this k-step's share of the stage's DMA pieces
-      if (kk < KK - 1) block(f, kk * P / KK, (kk + 1) * P / KK, st, kk + 1);
-      else block(f, kk * P / KK, P, lds_base + nslot * STAGE, 0);
+      if (kk < KK - 1) {
+        block(f, kk * P / KK, (kk + 1) * P / KK, kk + 1);
+      } else {
+        set_read_stage(lds_base + nslot * STAGE);
+        block(f, kk * P / KK, P, 0);
+      }
       if (kk == KK - 1) {
         advance();
         desc_read();                           // descriptors of the stage fetched next (published by the barrier above)
