@@ -760,6 +760,150 @@ __device__ unsigned long long g_conv_trace[8 * kTraceIters * 8 + 8 * 16 + 8];
 // (tools/trace_conv.py, s_memtime stamps of one workgroup): an MFMA wave that issues a DMA piece stalls 60 - 185 cycles at issue
 // while the CU's vector-memory queue drains the other waves' pieces, and the in-order wave cannot issue the MFMAs behind it -
 // seven pieces per wave per K tile kept the matrix pipe 64 % busy in the K loop of the 256 x 192 tile.
+// ================================================================================================
+// Output tile of the DMA-pipelined kernels (bf16 and fp8): accumulators -> destination.  `stamp(i)` is the trace build's
+// s_memtime hook (a no-op otherwise).  RING = bytes of LDS the K loop used (free once every wave is here).
+// ================================================================================================
+template <int BCO, int BPX, int WCO, int WPX, int CT, int PT, int RING, class Stamp>
+__device__ __forceinline__ void conv_tile_epilogue(const ConvK& p, f32x16 (&acc)[CT][PT], unsigned char* smem, const int co0, const int px0,
+                                                   const int totpx, Stamp&& stamp) {
+  constexpr int T = 64 * WCO * WPX;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_co = wave / WPX, wave_px = wave % WPX;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  // ---- epilogue staged through LDS (see conv_glds_kernel)
+  constexpr int ROWB = BCO * 4 + 16;
+  constexpr int CPX = 32 * WPX;
+  constexpr int GPR = BCO / 8;
+  static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
+  static_assert(T % GPR == 0, "a thread keeps its channel group across the staged rows");
+  const Affine8 aff = conv_affine8(p, co0 + (tid % GPR) * 8);     // (issued here: the loads fly during the first staging round)
+  const EpiFast ef = conv_epi_fast(p, co0 + (tid % GPR) * 8);
+  // ---- "pure" epilogue (no addend, no mask, bf16 out, ident): scale / bias / ReLU / rounding happen in the accumulator registers
+  // (a lane owns 4 consecutive couts of one pixel per 8-cout group), the WHOLE tile is staged once as bf16 rows [pixel][BCO] and
+  // leaves as 16-byte stores without a single VALU instruction in the store loop: two barriers instead of 2 * PT, half the LDS
+  // bytes, same arithmetic in the same order as the staged fp32 path (mul_nc / add_nc: one rounding each).
+  constexpr int ROWH = BCO * 2 + 16;
+  static_assert((long long)BPX * ROWH <= (long long)RING, "the bf16 tile fits in the ring");
+  // A ReLU mask applied LAST (the data gradients: round(v * m), m in {0, 1}) commutes with the rounding - m ? round(v) : +-0 with v's
+  // sign - so it is applied to the staged bf16 words in the store loop, bit for bit what the fp32 path produces for finite v.
+  if (ef.on && !ef.has_add && !ef.mask_first && !(ef.mask_last && ef.relu) && (p.cd & 7) == 0) {
+    lds_barrier();                           // every wave is done with the ring (its DMA has landed: wait_vmcnt<0> above)
+    // (cout group outermost: a lane keeps ONE group's scale / bias at a time - all of them at once cost 64 registers and an
+    // occupancy step on the small tiles)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
+        const bool in = co0 + col + 3 < p.cd;
+        const f32x4 sc = (ef.has_scale && in) ? *reinterpret_cast<const f32x4*>(p.scale + co0 + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 bi = (ef.has_bias && in) ? *reinterpret_cast<const f32x4*>(p.bias + co0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = acc[ct][pt][4 * g + j];
+            if (ef.has_scale) v[j] = mul_nc(v[j], sc[j]);
+            if (ef.has_bias) v[j] = add_nc(v[j], bi[j]);
+            if (ef.relu) v[j] = fmaxf(v[j], 0.f);
+          }
+          const int row = wave_px * (32 * PT) + pt * 32 + frow;
+          u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(smem + row * ROWH + col * 2) = o;
+        }
+      }
+    lds_barrier();
+    stamp(2);
+    {
+      constexpr int NITP = BPX * GPR / T;
+      static_assert(BPX * GPR % T == 0, "whole items per thread");
+      const int row0 = tid / GPR, cgp = tid % GPR;
+      if (co0 + cgp * 8 < p.cd) {
+        const unsigned char* rd = smem + row0 * ROWH + cgp * 16;
+        uint16_t* out = reinterpret_cast<uint16_t*>(p.dst) + (co0 + cgp * 8);
+#pragma unroll 4
+        for (int n_ = 0; n_ < NITP; ++n_) {
+          const int gp = px0 + row0 + n_ * (T / GPR);
+          if (gp < totpx) {
+            u32x4 r = *reinterpret_cast<const u32x4*>(rd + n_ * (T / GPR) * ROWH);
+            if (ef.mask_last) {
+              const u32x4 mm = *reinterpret_cast<const u32x4*>(ef.mask + (long long)gp * ef.ldm);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                r[e] &= (bflo(mm[e]) > 0.f ? 0xffffu : 0x8000u) | (bfhi(mm[e]) > 0.f ? 0xffff0000u : 0x80000000u);
+            }
+            *reinterpret_cast<u32x4*>(out + (long long)gp * p.ldd) = r;
+          }
+        }
+      }
+    }
+    stamp(3);
+    return;
+  }
+  // The slab loop is NOT unrolled and the item loops are rolled: this code runs once per workgroup, straight-line copies of it per
+  // slab are cold in the instruction cache every time (tools/trace_conv.py: 5 000 - 7 000 cycles per slab whatever the body did,
+  // against ~1 000 for the same stores from warm code) - only the accumulator -> LDS writes need the slab index at compile time.
+  auto stage_slab = [&](auto pt_c) {
+    constexpr int pt = decltype(pt_c)::value;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
+        f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
+      }
+  };
+  static_assert(PT <= 4, "slab dispatch");
+#pragma nounroll
+  for (int pt = 0; pt < PT; ++pt) {
+    lds_barrier();
+    stamp(1 + 3 * pt);
+    if (pt == 0) stage_slab(std::integral_constant<int, 0>{});
+    else if (pt == 1) stage_slab(std::integral_constant<int, (PT > 1 ? 1 : 0)>{});
+    else if (pt == 2) stage_slab(std::integral_constant<int, (PT > 2 ? 2 : 0)>{});
+    else stage_slab(std::integral_constant<int, (PT > 3 ? 3 : 0)>{});
+    lds_barrier();
+    stamp(2 + 3 * pt);
+    if (ef.on && aff.full) {                 // lean item loop (uniform test; aff.full is false only in a partial last channel group)
+      constexpr int NIT = CPX * GPR / T;     // items per thread and slab: rows T / GPR apart
+      static_assert(CPX * GPR % T == 0, "whole items per thread");
+      const int pl0 = tid / GPR;
+      const unsigned char* rd = smem + pl0 * ROWB + (tid % GPR) * 32;
+#pragma nounroll
+      for (int n_ = 0; n_ < NIT; ++n_) {
+        const int pl = pl0 + n_ * (T / GPR);
+        const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
+        if (gp < totpx)
+          conv_epilogue8_fast(ef, aff, gp, *reinterpret_cast<const f32x4*>(rd + n_ * (T / GPR) * ROWB),
+                              *reinterpret_cast<const f32x4*>(rd + n_ * (T / GPR) * ROWB + 16));
+      }
+      stamp(3 + 3 * pt);
+      continue;
+    }
+#pragma nounroll
+    for (int id = tid; id < CPX * GPR; id += T) {
+      const int pl = id / GPR, cg = id - pl * GPR;
+      const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
+      const int co = co0 + cg * 8;
+      if (gp >= totpx || co >= p.cd) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32 + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#ifdef DSL_ABLATE_BUILD
+      if ((p.dbg & 512) && v[0] != 12345.678f) continue;      // epilogue without the scale / bias / addend loads and the stores
+#endif
+      long long dpix, apix;
+      conv_out_index(p, gp, dpix, apix);
+      conv_epilogue8a(p, dpix, apix, co, v, aff);
+    }
+    stamp(3 + 3 * pt);
+  }
+}
+
 template <int BCO, int BPX, int WCO, int WPX, int NST, bool SMC = false, int HB = 1, int LW = 0>
 __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1130,139 +1274,12 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
     return;
   }
 
-  // ---- epilogue staged through LDS (see conv_glds_kernel)
-  constexpr int ROWB = BCO * 4 + 16;
-  constexpr int CPX = 32 * WPX;
-  constexpr int GPR = BCO / 8;
-  static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
-  static_assert(T % GPR == 0, "a thread keeps its channel group across the staged rows");
-  const Affine8 aff = conv_affine8(p, co0 + (tid % GPR) * 8);     // (issued here: the loads fly during the first staging round)
-  const EpiFast ef = conv_epi_fast(p, co0 + (tid % GPR) * 8);
-  // ---- "pure" epilogue (no addend, no mask, bf16 out, ident): scale / bias / ReLU / rounding happen in the accumulator registers
-  // (a lane owns 4 consecutive couts of one pixel per 8-cout group), the WHOLE tile is staged once as bf16 rows [pixel][BCO] and
-  // leaves as 16-byte stores without a single VALU instruction in the store loop: two barriers instead of 2 * PT, half the LDS
-  // bytes, same arithmetic in the same order as the staged fp32 path (mul_nc / add_nc: one rounding each).
-  constexpr int ROWH = BCO * 2 + 16;
-  static_assert((long long)BPX * ROWH <= (long long)NST * STAGE, "the bf16 tile fits in the ring");
-  // A ReLU mask applied LAST (the data gradients: round(v * m), m in {0, 1}) commutes with the rounding - m ? round(v) : +-0 with v's
-  // sign - so it is applied to the staged bf16 words in the store loop, bit for bit what the fp32 path produces for finite v.
-  if (ef.on && !ef.has_add && !ef.mask_first && !(ef.mask_last && ef.relu) && (p.cd & 7) == 0) {
-    lds_barrier();                           // every wave is done with the ring (its DMA has landed: wait_vmcnt<0> above)
-    // (cout group outermost: a lane keeps ONE group's scale / bias at a time - all of them at once cost 64 registers and an
-    // occupancy step on the small tiles)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
-        const bool in = co0 + col + 3 < p.cd;
-        const f32x4 sc = (ef.has_scale && in) ? *reinterpret_cast<const f32x4*>(p.scale + co0 + col) : f32x4{1.f, 1.f, 1.f, 1.f};
-        const f32x4 bi = (ef.has_bias && in) ? *reinterpret_cast<const f32x4*>(p.bias + co0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j] = acc[ct][pt][4 * g + j];
-            if (ef.has_scale) v[j] = mul_nc(v[j], sc[j]);
-            if (ef.has_bias) v[j] = add_nc(v[j], bi[j]);
-            if (ef.relu) v[j] = fmaxf(v[j], 0.f);
-          }
-          const int row = wave_px * (32 * PT) + pt * 32 + frow;
-          u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(smem + row * ROWH + col * 2) = o;
-        }
-      }
-    lds_barrier();
-    TRE(2);
-    {
-      constexpr int NITP = BPX * GPR / T;
-      static_assert(BPX * GPR % T == 0, "whole items per thread");
-      const int row0 = tid / GPR, cgp = tid % GPR;
-      if (co0 + cgp * 8 < p.cd) {
-        const unsigned char* rd = smem + row0 * ROWH + cgp * 16;
-        uint16_t* out = reinterpret_cast<uint16_t*>(p.dst) + (co0 + cgp * 8);
-#pragma unroll 4
-        for (int n_ = 0; n_ < NITP; ++n_) {
-          const int gp = px0 + row0 + n_ * (T / GPR);
-          if (gp < totpx) {
-            u32x4 r = *reinterpret_cast<const u32x4*>(rd + n_ * (T / GPR) * ROWH);
-            if (ef.mask_last) {
-              const u32x4 mm = *reinterpret_cast<const u32x4*>(ef.mask + (long long)gp * ef.ldm);
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                r[e] &= (bflo(mm[e]) > 0.f ? 0xffffu : 0x8000u) | (bfhi(mm[e]) > 0.f ? 0xffff0000u : 0x80000000u);
-            }
-            *reinterpret_cast<u32x4*>(out + (long long)gp * p.ldd) = r;
-          }
-        }
-      }
-    }
-    TRE(3);
+  // ---- epilogue (conv_tile_epilogue)
 #ifdef DSL_TRACE_BUILD
-    trace_dump();
+  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, NST * STAGE>(p, acc, smem, co0, px0, totpx, [&](int i_) { TRE(i_); });
+#else
+  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, NST * STAGE>(p, acc, smem, co0, px0, totpx, [](int) {});
 #endif
-    return;
-  }
-  // The slab loop is NOT unrolled and the item loops are rolled: this code runs once per workgroup, straight-line copies of it per
-  // slab are cold in the instruction cache every time (tools/trace_conv.py: 5 000 - 7 000 cycles per slab whatever the body did,
-  // against ~1 000 for the same stores from warm code) - only the accumulator -> LDS writes need the slab index at compile time.
-  auto stage_slab = [&](auto pt_c) {
-    constexpr int pt = decltype(pt_c)::value;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
-        f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
-      }
-  };
-  static_assert(PT <= 4, "slab dispatch");
-#pragma nounroll
-  for (int pt = 0; pt < PT; ++pt) {
-    lds_barrier();
-    TRE(1 + 3 * pt);
-    if (pt == 0) stage_slab(std::integral_constant<int, 0>{});
-    else if (pt == 1) stage_slab(std::integral_constant<int, (PT > 1 ? 1 : 0)>{});
-    else if (pt == 2) stage_slab(std::integral_constant<int, (PT > 2 ? 2 : 0)>{});
-    else stage_slab(std::integral_constant<int, (PT > 3 ? 3 : 0)>{});
-    lds_barrier();
-    TRE(2 + 3 * pt);
-    if (ef.on && aff.full) {                 // lean item loop (uniform test; aff.full is false only in a partial last channel group)
-      constexpr int NIT = CPX * GPR / T;     // items per thread and slab: rows T / GPR apart
-      static_assert(CPX * GPR % T == 0, "whole items per thread");
-      const int pl0 = tid / GPR;
-      const unsigned char* rd = smem + pl0 * ROWB + (tid % GPR) * 32;
-#pragma nounroll
-      for (int n_ = 0; n_ < NIT; ++n_) {
-        const int pl = pl0 + n_ * (T / GPR);
-        const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
-        if (gp < totpx)
-          conv_epilogue8_fast(ef, aff, gp, *reinterpret_cast<const f32x4*>(rd + n_ * (T / GPR) * ROWB),
-                              *reinterpret_cast<const f32x4*>(rd + n_ * (T / GPR) * ROWB + 16));
-      }
-      TRE(3 + 3 * pt);
-      continue;
-    }
-#pragma nounroll
-    for (int id = tid; id < CPX * GPR; id += T) {
-      const int pl = id / GPR, cg = id - pl * GPR;
-      const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
-      const int co = co0 + cg * 8;
-      if (gp >= totpx || co >= p.cd) continue;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32 + 16);
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#ifdef DSL_ABLATE_BUILD
-      if ((p.dbg & 512) && v[0] != 12345.678f) continue;      // epilogue without the scale / bias / addend loads and the stores
-#endif
-      long long dpix, apix;
-      conv_out_index(p, gp, dpix, apix);
-      conv_epilogue8a(p, dpix, apix, co, v, aff);
-    }
-    TRE(3 + 3 * pt);
-  }
 #ifdef DSL_TRACE_BUILD
   trace_dump();
 #endif
@@ -1515,36 +1532,8 @@ __global__ __launch_bounds__(64 * WCO * WPX) void conv_f8_kernel(const ConvK p) 
     return;
   }
 
-  // ---- epilogue staged through LDS (see conv_glds_kernel)
-  constexpr int ROWB = BCO * 4 + 16;
-  constexpr int CPX = 32 * WPX;
-  constexpr int GPR = BCO / 8;
-  static_assert(CPX * ROWB <= 160 * 1024, "epilogue staging must fit in LDS (the host sizes LDS as max(ring, staging))");
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    lds_barrier();
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = wave_co * 64 + ct * 32 + 8 * g + 4 * fhalf;
-        f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(smem + (wave_px * 32 + frow) * ROWB + col * 4) = o;
-      }
-    lds_barrier();
-    for (int id = tid; id < CPX * GPR; id += T) {
-      const int pl = id / GPR, cg = id - pl * GPR;
-      const int gp = px0 + (pl >> 5) * (32 * PT) + pt * 32 + (pl & 31);
-      const int co = co0 + cg * 8;
-      if (gp >= totpx || co >= p.cd) continue;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + pl * ROWB + cg * 32 + 16);
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      long long dpix, apix;
-      conv_out_index(p, gp, dpix, apix);
-      conv_epilogue8(p, dpix, apix, co, v);
-    }
-  }
+  // ---- epilogue (shared with the bf16 kernel)
+  conv_tile_epilogue<BCO, BPX, WCO, WPX, 2, PT, NST * STAGE>(p, acc, smem, co0, px0, totpx, [](int) {});
 }
 
 // NMF x { 1 MFMA, its share of the NRD fragment reads, 1 DMA piece for the first NVM }
