@@ -1013,14 +1013,22 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
   constexpr int P0 = (LPT + 1) / 3;                   // pieces issued right after the barrier (stage 3)
   constexpr int P1 = P0 + (LPT - P0 + 1) / 2;         // pieces [P0, P1) in stage 0, [P1, LPT) in stage 1
   int kt_next = kt0;               // K tile being fetched
-  int ld_slot = 0;                 // ... and the ring slot it goes to
+  // The fetched tile's parameters are STATE, recomputed once per tile when the tile is fully issued (and the tap advance only on
+  // the tile where the channel blocks wrap, behind a uniform branch): recomputing them branch-free in every pieces() call made 66
+  // SALU instructions per K tile and wave, and these in-order waves with 8 MFMAs per K tile (the 128 x 128 / 128 x 64 tiles) are
+  // bound by their own instruction count (probe: + 32 SALU or VALU per K tile = + 9 ... 12 % on the layer2-4 shapes).
+  unsigned ld_off = 0;             // byte offset of the ring slot being filled
+  unsigned t_sel = (1u << tap_r) | (0x100u << tap_s);
+  unsigned t_soff = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds * 2 + cidx * 128);
+  unsigned t_wv = w_voff;
+  int c_left = p.kc - cidx;        // tiles until the channel blocks wrap (tap advance)
   auto pieces = [&](auto lo_c, auto hi_c) {
     constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-    unsigned char* stage = smem + ld_slot * STAGE;
-    const bool live = kt_next < kt1;
-    const unsigned sel = live ? ((1u << tap_r) | (0x100u << tap_s)) : 0xffffffffu;
-    const unsigned s_off = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds * 2 + cidx * 128);
-    const unsigned wv = live ? w_voff : 0x80000000u;
+    unsigned char* stage = smem + ld_off;
+    const bool live = kt_next < kt1;      // (used by the 8-channel-source variant only)
+    const unsigned sel = t_sel;
+    const unsigned s_off = t_soff;
+    const unsigned wv = t_wv;
     int s_tr = 0, s_ts = 0;
     bool s_ok = false;
     if (SMC) {                    // this lane's tap of the K tile
@@ -1054,16 +1062,26 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
     }
     if (HI == LPT) {               // tile fully issued: advance to the next (r, s, channel-block) and ring slot
       ++kt_next;
-      ld_slot = (ld_slot + 1 == NST) ? 0 : ld_slot + 1;
+      ld_off = (ld_off + STAGE == NST * STAGE) ? 0u : ld_off + STAGE;
       w_soff += BK * 2;
-      const bool c_wrap = cidx + 1 == p.kc;
-      const bool s_wrap = c_wrap && tap_s + 1 == p.kw;
-      cidx = c_wrap ? 0 : cidx + 1;
-      tap_s = s_wrap ? 0 : (c_wrap ? tap_s + 1 : tap_s);
-      tap_r += s_wrap ? 1 : 0;
-      const unsigned adv = s_wrap ? 0xffffffffu : 0u;
+      if (--c_left != 0) {
+        t_soff += 128;             // same tap, next 64-channel block
+      } else {                     // tap advance: every kc-th tile (uniform branch)
+        c_left = p.kc;
+        const bool s_wrap = tap_s + 1 == p.kw;
+        tap_s = s_wrap ? 0 : tap_s + 1;
+        if (s_wrap) {
+          ++tap_r;
 #pragma unroll
-      for (int i = 0; i < XPASS; ++i) r_cur[i] += r_step[i] & adv;
+          for (int i = 0; i < XPASS; ++i) r_cur[i] += r_step[i];
+        }
+        t_sel = (1u << tap_r) | (0x100u << tap_s);
+        t_soff = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds * 2);
+      }
+      if (kt_next >= kt1) {        // past the last tile (the ring's tail): every lane out of range, zeros land in a slot nobody reads
+        t_sel = 0xffffffffu;
+        t_wv = 0x80000000u;
+      }
     }
   };
   using c0_t = std::integral_constant<int, 0>;
@@ -1169,11 +1187,25 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
   }
   __builtin_amdgcn_s_barrier();
   lds_read(smem, 0, 0);
-  int slot = 0;
+  unsigned slot = 0;                       // byte offset of the ring slot being read
   for (int kt = kt0; kt < kt1 - 1; ++kt) {
-    const unsigned char* base = smem + slot * STAGE;
-    const int nslot = (slot + 1 == NST) ? 0 : slot + 1;
+    const unsigned char* base = smem + slot;
+    const unsigned nslot = (slot + STAGE == NST * STAGE) ? 0u : slot + STAGE;
     TR(0);
+#ifdef DSL_ABLATE_BUILD
+    if (p.dbg & 1024) {                    // sensitivity probe: 32 extra dependent SALU instructions per K tile and wave
+      unsigned d_ = (unsigned)kt;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(d_));
+      if (d_ == 0x7fffffffu) return;
+    }
+    if (p.dbg & 2048) {                    // ... and 32 extra VALU instructions
+      unsigned d_ = (unsigned)lane;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) asm volatile("v_add_u32 %0, %0, 1" : "+v"(d_));
+      if (d_ == 0x7fffffffu) return;
+    }
+#endif
     lds_read(base, 1, 1);
     if constexpr (LW == 0) pieces(cp0_t{}, cp1_t{});
     mma(0);
@@ -1198,7 +1230,7 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
 #endif
     __builtin_amdgcn_s_barrier();          // ... and both hold for every wave
     TR(4);
-    lds_read(smem + nslot * STAGE, 0, 0);
+    lds_read(smem + nslot, 0, 0);
     if constexpr (LW == 0) pieces(c0_t{}, cp0_t{});           // start refilling the slot tile kt just vacated with tile kt+NST
 #pragma unroll
     for (int ct = CT - HB; ct < CT; ++ct) mma_half(1, ct);
@@ -1211,7 +1243,7 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
     slot = nslot;
   }
   {                                        // last tile
-    const unsigned char* base = smem + slot * STAGE;
+    const unsigned char* base = smem + slot;
     lds_read(base, 1, 1);
     mma(0);
     lds_read(base, 2, 0);
