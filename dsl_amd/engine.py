@@ -306,8 +306,8 @@ class Plan:
                     winv = self.buf(f'{tower}.{i}.winv', spec.cout_pad, dtype=torch.float32)
                     self.buf(f'{tower}.{i}.comb', spec.cout_pad, dtype=torch.float32)
                     f.quant_fp8_w(st.t32_ptr(spec.name + '.weight'), w8, winv, spec.cout, spec.cout_pad, 9 * 256, 1.0)
-        if FSIDE:
-            f.fork(FSIDE)
+        if FSIDE:        # (starting the regression tower one convolution late, so that each tower's GroupNorm runs beside the other's
+            f.fork(FSIDE)    # convolution instead of beside its GroupNorm: measured, 407.6 vs 408.9 img/s - no effect)
         for tower in ('cls_convs', 'reg_convs'):
             side = FSIDE if tower == 'reg_convs' else 0
             xin, xin8, pm = feats, feats8, (pm0 if f8 else None)
