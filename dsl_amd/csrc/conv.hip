@@ -1022,11 +1022,13 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
   unsigned t_soff = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds * 2 + cidx * 128);
   unsigned t_wv = w_voff;
   int c_left = p.kc - cidx;        // tiles until the channel blocks wrap (tap advance)
+  unsigned r_v[XPASS];             // this lane's source offsets for the CURRENT tap (out of range where the tap leaves the image):
+#pragma unroll                     // they change with the tap only, so the per-piece mask test moves into the tap advance
+  for (int i = 0; i < XPASS; ++i) r_v[i] = (r_mask[i] & t_sel) == t_sel ? r_cur[i] : 0x80000000u;
   auto pieces = [&](auto lo_c, auto hi_c) {
     constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
     unsigned char* stage = smem + ld_off;
     const bool live = kt_next < kt1;      // (used by the 8-channel-source variant only)
-    const unsigned sel = t_sel;
     const unsigned s_off = t_soff;
     const unsigned wv = t_wv;
     int s_tr = 0, s_ts = 0;
@@ -1050,7 +1052,7 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
           v = in ? r_cur[j] + (unsigned)((s_tr * sw + s_ts) * 16) : 0x80000000u;
           so = 0;
         } else {
-          v = (r_mask[j] & sel) == sel ? r_cur[j] : 0x80000000u;
+          v = r_v[j];
           so = s_off;
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lptr_t)(stage + TILE_W + (j * RPP + dwave * 8) * 128), 16, v, so, 0, 0);
@@ -1077,10 +1079,14 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
         }
         t_sel = (1u << tap_r) | (0x100u << tap_s);
         t_soff = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds * 2);
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) r_v[i] = (r_mask[i] & t_sel) == t_sel ? r_cur[i] : 0x80000000u;
       }
       if (kt_next >= kt1) {        // past the last tile (the ring's tail): every lane out of range, zeros land in a slot nobody reads
         t_sel = 0xffffffffu;
         t_wv = 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) r_v[i] = 0x80000000u;
       }
     }
   };
