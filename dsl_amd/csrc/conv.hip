@@ -1082,7 +1082,8 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
 #pragma unroll
         for (int i = 0; i < XPASS; ++i) r_v[i] = (r_mask[i] & t_sel) == t_sel ? r_cur[i] : 0x80000000u;
       }
-      if (kt_next >= kt1) {        // past the last tile (the ring's tail): every lane out of range, zeros land in a slot nobody reads
+      if (__builtin_expect(kt_next >= kt1, 0)) {   // past the last tile (the ring's tail): every lane out of range, zeros land in a slot
+        asm volatile("" ::: "memory");            // nobody reads (a real branch: if-converted it costs five instructions per tile)
         t_sel = 0xffffffffu;
         t_wv = 0x80000000u;
 #pragma unroll
