@@ -1017,7 +1017,6 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
   // the tile where the channel blocks wrap, behind a uniform branch): recomputing them branch-free in every pieces() call made 66
   // SALU instructions per K tile and wave, and these in-order waves with 8 MFMAs per K tile (the 128 x 128 / 128 x 64 tiles) are
   // bound by their own instruction count (probe: + 32 SALU or VALU per K tile = + 9 ... 12 % on the layer2-4 shapes).
-  unsigned ld_off = 0;             // byte offset of the ring slot being filled
   unsigned t_sel = (1u << tap_r) | (0x100u << tap_s);
   unsigned t_soff = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds * 2 + cidx * 128);
   unsigned t_wv = w_voff;
@@ -1025,7 +1024,8 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
   unsigned r_v[XPASS];             // this lane's source offsets for the CURRENT tap (out of range where the tap leaves the image):
 #pragma unroll                     // they change with the tap only, so the per-piece mask test moves into the tap advance
   for (int i = 0; i < XPASS; ++i) r_v[i] = (r_mask[i] & t_sel) == t_sel ? r_cur[i] : 0x80000000u;
-  auto pieces = [&](auto lo_c, auto hi_c) {
+  // ld_off: byte offset of the ring slot being filled (the K loop derives it from the slot it reads: no second ring counter)
+  auto pieces = [&](auto lo_c, auto hi_c, const unsigned ld_off) {
     constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
     unsigned char* stage = smem + ld_off;
     const bool live = kt_next < kt1;      // (used by the 8-channel-source variant only)
@@ -1064,7 +1064,6 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
     }
     if (HI == LPT) {               // tile fully issued: advance to the next (r, s, channel-block) and ring slot
       ++kt_next;
-      ld_off = (ld_off + STAGE == NST * STAGE) ? 0u : ld_off + STAGE;
       w_soff += BK * 2;
       if (--c_left != 0) {
         t_soff += 128;             // same tap, next 64-channel block
@@ -1104,6 +1103,7 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
       // ---- loader wave: tile t goes to ring slot (t - kt0) % NST as soon as the barrier that retires the slot's previous
       // tenant has passed; before barrier #(t - kt0) it waits until tile t has landed (counted vmcnt: later tiles stay in flight)
       int issued = kt0;                    // first tile not yet issued
+      unsigned l_off = 0;                  // ... and the ring slot it goes to
       auto land = [&](int need) {          // every piece of tiles <= need has landed
         const int later = issued - 1 - need;
         if (later <= 0) wait_vmcnt<0>();
@@ -1113,11 +1113,11 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
       static_assert(NST <= 4, "land() distinguishes up to two tiles in flight behind the awaited one");
 #pragma unroll
       for (int s_ = 0; s_ < NST - 1; ++s_)
-        if (issued < kt1) { pieces(c0_t{}, clpt_t{}); ++issued; }
+        if (issued < kt1) { pieces(c0_t{}, clpt_t{}, l_off); ++issued; l_off = (l_off + STAGE == NST * STAGE) ? 0u : l_off + STAGE; }
       land(kt0);
       __builtin_amdgcn_s_barrier();
       for (int kt = kt0; kt < kt1 - 1; ++kt) {
-        if (issued < kt1) { pieces(c0_t{}, clpt_t{}); ++issued; }
+        if (issued < kt1) { pieces(c0_t{}, clpt_t{}, l_off); ++issued; l_off = (l_off + STAGE == NST * STAGE) ? 0u : l_off + STAGE; }
         land(kt + 1);
         __builtin_amdgcn_s_barrier();
       }
@@ -1188,13 +1188,14 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
   // prologue: NST-1 whole tiles + the first pieces of the NST-th
   if constexpr (LW == 0) {
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s) pieces(c0_t{}, clpt_t{});
-    pieces(c0_t{}, cp0_t{});
+    for (int s = 0; s < NST - 1; ++s) pieces(c0_t{}, clpt_t{}, (unsigned)(s * STAGE));
+    pieces(c0_t{}, cp0_t{}, (unsigned)((NST - 1) * STAGE));
     wait_vmcnt<(NST - 2) * LPT + P0>();
   }
   __builtin_amdgcn_s_barrier();
   lds_read(smem, 0, 0);
   unsigned slot = 0;                       // byte offset of the ring slot being read
+  unsigned pslot = (NST - 1) * STAGE;      // ... of the slot before it: where tile kt + NST - 1 is still being fetched into
   for (int kt = kt0; kt < kt1 - 1; ++kt) {
     const unsigned char* base = smem + slot;
     const unsigned nslot = (slot + STAGE == NST * STAGE) ? 0u : slot + STAGE;
@@ -1214,10 +1215,10 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
     }
 #endif
     lds_read(base, 1, 1);
-    if constexpr (LW == 0) pieces(cp0_t{}, cp1_t{});
+    if constexpr (LW == 0) pieces(cp0_t{}, cp1_t{}, pslot);
     mma(0);
     lds_read(base, 2, 0);
-    if constexpr (LW == 0) pieces(cp1_t{}, clpt_t{});
+    if constexpr (LW == 0) pieces(cp1_t{}, clpt_t{}, pslot);
     mma(1);
     lds_read(base, 3, 1);
     mma(0);
@@ -1238,7 +1239,7 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
     __builtin_amdgcn_s_barrier();          // ... and both hold for every wave
     TR(4);
     lds_read(smem + nslot, 0, 0);
-    if constexpr (LW == 0) pieces(c0_t{}, cp0_t{});           // start refilling the slot tile kt just vacated with tile kt+NST
+    if constexpr (LW == 0) pieces(c0_t{}, cp0_t{}, slot);     // start refilling the slot tile kt just vacated with tile kt+NST
 #pragma unroll
     for (int ct = CT - HB; ct < CT; ++ct) mma_half(1, ct);
     __builtin_amdgcn_sched_group_barrier(0x100, CT + PT, 0);
@@ -1247,6 +1248,7 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
 #ifdef DSL_TRACE_BUILD
     ++tr_it;
 #endif
+    pslot = slot;
     slot = nslot;
   }
   {                                        // last tile
