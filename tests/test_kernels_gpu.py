@@ -640,3 +640,45 @@ def test_bf16_rounding_bit_patterns(K):
     nan = torch.isnan(x)
     assert torch.equal(got[~nan], want[~nan])
     assert torch.isnan(y.cpu()[nan].float()).all()
+
+
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('flavour', ['bn_relu', 'bias', 'plain', 'mask_last'])
+def test_conv_in_register_epilogue_equals_staged_epilogue(K, force, flavour):
+    """Launches without an addend take conv_tile_epilogue's in-register path (scale / bias / ReLU / rounding in the accumulator
+    registers, one bf16 staging round, a last-applied ReLU mask as an AND on the staged words).  The same launch with an addend of
+    zeros takes the staged fp32 path.  Both must produce the same BITS (x + 0 is x, except for the sign of an exact zero), and
+    both must equal the fp32 reference rounded to bf16 to within one bf16 step."""
+    L, ops = K
+    N, Ci, Co, H, W, k = 2, 128, 256, 24, 40, 3
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64}.get(force)
+    if bco and Co % bco:
+        pytest.skip('tile does not divide Cout')
+    g = torch.Generator().manual_seed(11 + force)
+    x, w = rnd(N, Ci, H, W, g=g), rnd(Co, Ci, k, k, g=g, scale=1 / math.sqrt(Ci * k * k))
+    scale, bias = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    msk = rnd(N, Co, H, W, g=g)
+    ref = F.conv2d(x, w, None, 1, 1)
+    kw = dict(flags=force << 8)
+    if flavour == 'bn_relu':
+        ref = F.relu(ref * scale[None, :, None, None] + bias[None, :, None, None])
+        kw = dict(flags=L.CONV_RELU_OUT | (force << 8), scale=scale.cuda(), bias=bias.cuda())
+    elif flavour == 'bias':
+        ref = ref + bias[None, :, None, None]
+        kw = dict(flags=force << 8, bias=bias.cuda())
+    elif flavour == 'mask_last':
+        ref = ref * (msk > 0)
+        kw = dict(flags=L.CONV_MASK_LAST | (force << 8), mask=nhwc(msk), ldm=Co)
+    outs = []
+    for staged in (False, True):
+        y = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device='cuda')
+        extra = dict(addend=torch.zeros(N, H, W, Co, dtype=torch.bfloat16, device='cuda'), lda=Co) if staged else {}
+        ops.conv2d(nhwc(x), pack_w(w, Co), y, n=N, grid=[(H, W)], src_hw=[(H, W)], dst_hw=[(H, W)], cs=Ci, cd=Co, cd_pad=Co, ldd=Co,
+                   kh=k, kw=k, stride=1, pad=1, **kw, **extra)
+        sync()
+        outs.append(y.cpu())
+    a, b = outs[0].view(torch.int16), outs[1].view(torch.int16)
+    same = (a == b) | (((a & 0x7fff) == 0) & ((b & 0x7fff) == 0))          # +0 / -0 aside
+    assert bool(same.all()), int((~same).sum())
+    got = from_nhwc(outs[0].cuda())
+    assert (got - bf(ref)).abs().max() <= 2 ** -7 * ref.abs().max()
