@@ -78,8 +78,13 @@ struct GnK {
 };
 
 constexpr int GN_PPB = 128;   // pixels per block
-constexpr int GN_TA = 1024;   // the two pure streaming (apply) passes
-constexpr int GN_T = 512;     // threads per block: 8 waves keep two waves per SIMD in flight on the ~1.4 blocks a CU gets
+// Block sizes: 256 threads.  Standalone the passes like big blocks (1024 / 512 threads: 17 + 32 us forward + backward against 25 + 39),
+// but in the step every pass runs BESIDE a convolution of the other tower or image chain whose workgroups already hold 2 waves x
+// ~190 VGPRs per SIMD and 112 KB of LDS on every CU: a 16-wave block (or gn_bwd_reduce's 53 KB of LDS at 512 threads) cannot
+// become resident until such a workgroup retires, so the pass took as long as that convolution (57 us in the trace).  Four-wave
+// blocks fit in the registers and LDS the convolution leaves: + 1.8 % on the training step (403 -> 411 img/s, same box).
+constexpr int GN_TA = 256;    // the two pure streaming (apply) passes
+constexpr int GN_T = 256;     // the two reduction passes
 
 // Sum of V-float records over the nb blocks of one (segment, image), by all T threads of the workgroup, in a fixed
 // order: thread (q, v) adds blocks q, q+Q, ... (Q = T / V), then thread v adds the Q partial sums in order.
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
         ss += a * a + b * b;
       }
   } else {
-#pragma unroll 4
+#pragma unroll 8
     for (int px = px0 + prow; px < px1; px += ppi) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long long)px * p.c + chunk * 8);
 #pragma unroll
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(GN_TA) void gn_apply_kernel(const GnK p) {
   }
   const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
   const int px1 = min(px0 + GN_PPB, hw);
-#pragma unroll 4
+#pragma unroll 8
   for (int px = px0 + prow; px < px1; px += ppi) {
     const long long o = ibase + (long long)px * p.c + chunk * 8;
     const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + o);
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(GN_T) void gn_bwd_reduce_kernel(const GnK p) {
   float s1 = 0.f, s2 = 0.f;
   const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
   const int px1 = min(px0 + GN_PPB, hw);
-#pragma unroll 4
+#pragma unroll 8
   for (int px = px0 + prow; px < px1; px += ppi) {
     const long long o = ibase + (long long)px * p.c + chunk * 8;
     const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + o);
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(GN_TA) void gn_bwd_apply_kernel(const GnK p) {
   }
   const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
   const int px1 = min(px0 + GN_PPB, hw);
-#pragma unroll 4
+#pragma unroll 8
   for (int px = px0 + prow; px < px1; px += ppi) {
     const long long o = ibase + (long long)px * p.c + chunk * 8;
     const u32x4 xv = *reinterpret_cast<const u32x4*>(p.x + o);
