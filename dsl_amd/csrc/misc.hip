@@ -120,18 +120,21 @@ __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
   const uint16_t* base = p.x + (p.off[seg] + (long long)img * hw) * p.c;
   float s = 0.f, ss = 0.f;
   const int px1 = min(px0 + GN_PPB, hw);
-  if (px1 - px0 == GN_PPB && ppi * 8 == GN_PPB) {      // full block, C = 256: all 8 loads of the thread in flight at once
-    u32x4 v[8];
+  if (px1 - px0 == GN_PPB && GN_PPB % (ppi * 8) == 0) {      // full block: eight loads of the thread in flight at a time
+    for (int b0 = 0; b0 < GN_PPB; b0 += ppi * 8) {
+      u32x4 v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const u32x4*>(base + (long long)(px0 + prow + i * ppi) * p.c + chunk * 8);
+      for (int i = 0; i < 8; ++i)
+        v[i] = *reinterpret_cast<const u32x4*>(base + (long long)(px0 + b0 + prow + i * ppi) * p.c + chunk * 8);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float a = bflo(v[i][e]), b = bfhi(v[i][e]);
-        s += a + b;
-        ss += a * a + b * b;
-      }
+        for (int e = 0; e < 4; ++e) {
+          const float a = bflo(v[i][e]), b = bfhi(v[i][e]);
+          s += a + b;
+          ss += a * a + b * b;
+        }
+    }
   } else {
 #pragma unroll 8
     for (int px = px0 + prow; px < px1; px += ppi) {
