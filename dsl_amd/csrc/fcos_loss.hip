@@ -147,8 +147,10 @@ __global__ __launch_bounds__(FIN_T) void fcos_finalize_kernel(const float* __res
   const int Q = FIN_T / V;
   const int v = threadIdx.x % V, q = threadIdx.x / V;
   float a = 0.f;
-  if (q < Q)
+  if (q < Q) {
+#pragma unroll 8                    // (the loads of eight records in flight; the additions stay in record order)
     for (int b = q; b < nblocks; b += Q) a += part[(long long)b * V + v];
+  }
   sh[threadIdx.x] = a;
   __syncthreads();
   if (threadIdx.x < V) {
