@@ -95,8 +95,10 @@ __device__ __forceinline__ void gn_sum_records(const float* __restrict__ rec0, i
   const int Q = T / V;
   const int v = threadIdx.x % V, q = threadIdx.x / V;
   float a = 0.f;
-  if (q < Q)
-    for (int b = q; b < nb; b += Q) a += rec0[(long long)b * stride + v];
+  if (q < Q) {
+#pragma unroll 8                    // eight records in flight (every block of the apply passes starts with this sum: its
+    for (int b = q; b < nb; b += Q) a += rec0[(long long)b * stride + v];     // latency is a serial prelude of the pass)
+  }
   sh[threadIdx.x] = a;
   __syncthreads();
   if (threadIdx.x < V) {
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(GN_TA) void gn_bwd_apply_kernel(const GnK p) {
           const int seg = si / p.n;
           const int nb = (p.h[seg] * p.w[seg] + GN_PPB - 1) / GN_PPB;
           const float* col = p.ws + (long long)si * p.nblk * R + 3 * p.c + 2 * g_lo + k;
+#pragma unroll 8
           for (int b = j; b < nb; b += Q1) a += col[(long long)b * R];
         }
         sh[threadIdx.x] = a;
@@ -345,7 +348,8 @@ __global__ __launch_bounds__(GN_TA) void gn_bwd_apply_kernel(const GnK p) {
         const int nb = (hw + GN_PPB - 1) / GN_PPB;
         const float rstd = p.stats[((long long)si * p.groups + g_lo + gi) * 2 + 1];
         const float m2 = tot[(si * NG + gi) * 2 + 1] / ((float)hw * (float)cpg);
-        if (ok)
+        if (ok) {
+#pragma unroll 4
           for (int b = q; b < nb; b += Q) {
             const float* rec = p.ws + ((long long)si * p.nblk + b) * R;
             const float rdb = rec[p.c + ch];
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(GN_TA) void gn_bwd_apply_kernel(const GnK p) {
             db += rdb;
             dbi += rstd * (gam * rdb - m2 * rec[2 * p.c + ch]);
           }
+        }
       }
       sh[(0 * Q + q) * GN_CW + cl] = dg;
       sh[(1 * Q + q) * GN_CW + cl] = db;

@@ -143,8 +143,10 @@ __global__ __launch_bounds__(256) void rec_sum_kernel(const float* __restrict__ 
   const int Q = 256 / V;
   const int v = threadIdx.x % V, q = threadIdx.x / V;
   float a = 0.f;
-  if (q < Q)
+  if (q < Q) {
+#pragma unroll 8
     for (int b = q; b < nblocks; b += Q) a += rec[(long long)b * V + v];
+  }
   sh[threadIdx.x] = a;
   __syncthreads();
   if (threadIdx.x < V) {
