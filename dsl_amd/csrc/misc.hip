@@ -110,6 +110,9 @@ __device__ __forceinline__ void gn_sum_records(const float* __restrict__ rec0, i
 }
 
 // pass 1 of forward: sum / sumsq per (seg, img, group) of this block's pixels -> ws record
+// (register budget: the pass must fit into what a convolution workgroup leaves free on its CU - 2 x ~190 of 512 VGPRs per SIMD are
+// taken.  With both load batches unrolled the kernel took 142 VGPRs and ran only on CUs without a convolution workgroup: 35 - 41 us
+// in the step for a 9 us pass.  Batches of four loads, not unrolled, keep it under that.)
 __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
   __shared__ float sh[2][GN_T];
   const int si = blockIdx.y, seg = si / p.n, img = si - seg * p.n;
@@ -122,14 +125,15 @@ __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
   const uint16_t* base = p.x + (p.off[seg] + (long long)img * hw) * p.c;
   float s = 0.f, ss = 0.f;
   const int px1 = min(px0 + GN_PPB, hw);
-  if (px1 - px0 == GN_PPB && GN_PPB % (ppi * 8) == 0) {      // full block: eight loads of the thread in flight at a time
-    for (int b0 = 0; b0 < GN_PPB; b0 += ppi * 8) {
-      u32x4 v[8];
+  if (px1 - px0 == GN_PPB && GN_PPB % (ppi * 4) == 0) {      // full block: four loads of the thread in flight at a time
+#pragma nounroll
+    for (int b0 = 0; b0 < GN_PPB; b0 += ppi * 4) {
+      u32x4 v[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 4; ++i)
         v[i] = *reinterpret_cast<const u32x4*>(base + (long long)(px0 + b0 + prow + i * ppi) * p.c + chunk * 8);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float a = bflo(v[i][e]), b = bfhi(v[i][e]);
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
         }
     }
   } else {
-#pragma unroll 8
+#pragma unroll 4
     for (int px = px0 + prow; px < px1; px += ppi) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long long)px * p.c + chunk * 8);
 #pragma unroll
@@ -155,7 +159,9 @@ __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const GnK p) {
   // threads [0, groups): reduce over the cpg8 chunks of the group and the ppi pixel rows
   if (threadIdx.x < p.groups) {
     float a = 0.f, b = 0.f;
+#pragma nounroll
     for (int r = 0; r < ppi; ++r)
+#pragma nounroll
       for (int k = 0; k < p.cpg8; ++k) {
         a += sh[0][r * cpr + threadIdx.x * p.cpg8 + k];
         b += sh[1][r * cpr + threadIdx.x * p.cpg8 + k];
