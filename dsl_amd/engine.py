@@ -566,7 +566,7 @@ class Plan:
         # tuning knobs (both measured: on is better): group the last segment's weight gradients too, although nothing
         # is left on the caller's stream to overlap their tail with ...
         GROUP_LAST = os.environ.get('DSL_GROUP_LAST', '1') != '0'
-        TAIL_SLOTS = int(os.environ.get('DSL_TAIL_SLOTS', '256'))
+        TAIL_SLOTS = int(os.environ.get('DSL_TAIL_SLOTS', '192'))      # (round 3, tools/exp_env.sh: 160 / 192 / 224 / 256 = 421.3 / 421.9 / 419.8 / 418.2 img/s)
         GROUP = True       # same-geometry weight gradients (tower layers, the blocks of a stage) as one launch
         # ... and all weight gradients of a segment that share a tile configuration as one multi launch
         self._multi_on = SIDE and os.environ.get('DSL_WGRAD_MULTI', '1') != '0'
