@@ -394,15 +394,18 @@ __global__ __launch_bounds__(NMS_THREADS) void det_nms_kernel(const DetK p) {
   if (threadIdx.x == 0) p.det_count[img] = s_nkept;
 }
 
-// ---- pseudo-label fuse step of the refresh (unlabel_pred_hook.py:84-171 with fuse_history=False) ------------------
+// ---- pseudo-label fuse step of the refresh (unlabel_pred_hook.py:84-171) -----------------------------------------
 // One block per image over its <= max_per_img detections: keep score >= parse_thr, truncate the coordinates toward
 // zero (int(), parse_det_results :27), round the score to 6 decimals (:35), then per class (ascending, classes
 // 0 .. num_classes-1) mmcv.ops.nms(boxes, scores, iou_threshold, score_threshold): candidates with score > nms_thr in
 // descending score order (ties: earlier detection first), greedy, suppress IoU > iou_thr (offset 0).
+// fuse_history=True (:131-141): the image's previous labels (old_*: boxes, scores and class indices as the label file
+// held them - not truncated, not thresholded by parse_thr) come first in the candidate list, the new detections after.
 struct FuseK {
-  int n, maxk, num_classes;
+  int n, maxk, num_classes, max_old, max_out;
   float parse_thr, iou_thr, nms_thr;
   const float* dets; const long long* labels; const int* count;
+  const float* old_boxes; const float* old_scores; const long long* old_labels; const int* old_count;
   float* out_boxes; float* out_scores; long long* out_labels; int* out_count;
 };
 
@@ -415,11 +418,21 @@ __global__ __launch_bounds__(FUSE_T) void pseudo_fuse_kernel(const FuseK p) {
   __shared__ int kept[FUSE_MAX];
   __shared__ int s_nk, s_flag, s_ncand, s_cls0;
   const int img = blockIdx.x;
-  const int k = min(p.count[img], min(p.maxk, FUSE_MAX));
-  for (int i = threadIdx.x; i < k; i += FUSE_T) {
-    const float* d = p.dets + ((long long)img * p.maxk + i) * 5;
+  const int ko = p.old_boxes ? min(p.old_count[img], p.max_old) : 0;
+  const int k = ko + min(p.count[img], p.maxk);          // ko + k <= FUSE_MAX (checked by the caller)
+  for (int i = threadIdx.x; i < ko; i += FUSE_T) {
+    const long long o = (long long)img * p.max_old + i;
+    const float s = p.old_scores[o];
+    const int l = (int)p.old_labels[o];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bx[i][e] = p.old_boxes[o * 4 + e];
+    sc[i] = s;
+    lb[i] = (l >= 0 && l < p.num_classes && s > p.nms_thr) ? l : -1;
+  }
+  for (int i = ko + threadIdx.x; i < k; i += FUSE_T) {
+    const float* d = p.dets + ((long long)img * p.maxk + (i - ko)) * 5;
     const float s = d[4];
-    const int l = (int)p.labels[(long long)img * p.maxk + i];
+    const int l = (int)p.labels[(long long)img * p.maxk + (i - ko)];
     const float rs = (float)(nearbyint((double)s * 1e6) / 1e6);
 #pragma unroll
     for (int e = 0; e < 4; ++e) bx[i][e] = (float)(int)d[e];
@@ -462,13 +475,13 @@ __global__ __launch_bounds__(FUSE_T) void pseudo_fuse_kernel(const FuseK p) {
     }
     __syncthreads();
   }
-  const int nk = s_nk;
+  const int nk = s_nk;      // <= max_out: max_out >= max_old + maxk
   for (int t = threadIdx.x; t < nk; t += FUSE_T) {
     const int ci = kept[t];
-    float* ob = p.out_boxes + ((long long)img * p.maxk + t) * 4;
+    float* ob = p.out_boxes + ((long long)img * p.max_out + t) * 4;
     ob[0] = bx[ci][0]; ob[1] = bx[ci][1]; ob[2] = bx[ci][2]; ob[3] = bx[ci][3];
-    p.out_scores[(long long)img * p.maxk + t] = sc[ci];
-    p.out_labels[(long long)img * p.maxk + t] = lb[ci];
+    p.out_scores[(long long)img * p.max_out + t] = sc[ci];
+    p.out_labels[(long long)img * p.max_out + t] = lb[ci];
   }
   if (threadIdx.x == 0) p.out_count[img] = nk;
 }
@@ -547,17 +560,35 @@ extern "C" int dsl_fcos_detect(const dsl_det_desc* d, void* stream) {
   return 0;
 }
 
+extern "C" int dsl_pseudo_label_fuse_history(const float* dets, const int64_t* labels, const int32_t* count, int n, int max_per_img,
+                                             const float* old_boxes, const float* old_scores, const int64_t* old_labels,
+                                             const int32_t* old_count, int max_old, int num_classes, float parse_thr, float iou_thr,
+                                             float nms_thr, float* out_boxes, float* out_scores, int64_t* out_labels,
+                                             int32_t* out_count, int max_out, void* stream) {
+  DSL_CHECK(dets && labels && count && out_boxes && out_scores && out_labels && out_count, "dsl_pseudo_label_fuse: null pointer");
+  DSL_CHECK(n >= 1 && max_per_img >= 1 && max_old >= 0 && max_per_img + max_old <= FUSE_MAX,
+            "dsl_pseudo_label_fuse: max_per_img + max_old must be in 1..%d", FUSE_MAX);
+  DSL_CHECK(max_old == 0 || (old_boxes && old_scores && old_labels && old_count), "dsl_pseudo_label_fuse_history: null pointer (old labels)");
+  DSL_CHECK(max_out >= max_per_img + max_old, "dsl_pseudo_label_fuse: max_out (%d) < max_per_img + max_old (%d)", max_out,
+            max_per_img + max_old);
+  FuseK k;
+  k.n = n; k.maxk = max_per_img; k.num_classes = num_classes; k.max_old = max_old; k.max_out = max_out;
+  k.parse_thr = parse_thr; k.iou_thr = iou_thr; k.nms_thr = nms_thr;
+  k.dets = dets; k.labels = (const long long*)labels; k.count = count;
+  k.old_boxes = max_old ? old_boxes : nullptr; k.old_scores = old_scores; k.old_labels = (const long long*)old_labels;
+  k.old_count = old_count;
+  k.out_boxes = out_boxes; k.out_scores = out_scores; k.out_labels = (long long*)out_labels; k.out_count = out_count;
+  hipLaunchKernelGGL(pseudo_fuse_kernel, dim3(n), dim3(FUSE_T), 0, (hipStream_t)stream, k);
+  DSL_LAUNCH_CHECK("pseudo_fuse_kernel");
+  return 0;
+}
+
 extern "C" int dsl_pseudo_label_fuse(const float* dets, const int64_t* labels, const int32_t* count, int n, int max_per_img,
                                      int num_classes, float parse_thr, float iou_thr, float nms_thr, float* out_boxes,
                                      float* out_scores, int64_t* out_labels, int32_t* out_count, void* stream) {
   DSL_CHECK(dets && labels && count && out_boxes && out_scores && out_labels && out_count, "dsl_pseudo_label_fuse: null pointer");
   DSL_CHECK(n >= 1 && max_per_img >= 1 && max_per_img <= FUSE_MAX, "dsl_pseudo_label_fuse: max_per_img must be in 1..%d", FUSE_MAX);
-  FuseK k;
-  k.n = n; k.maxk = max_per_img; k.num_classes = num_classes;
-  k.parse_thr = parse_thr; k.iou_thr = iou_thr; k.nms_thr = nms_thr;
-  k.dets = dets; k.labels = (const long long*)labels; k.count = count;
-  k.out_boxes = out_boxes; k.out_scores = out_scores; k.out_labels = (long long*)out_labels; k.out_count = out_count;
-  hipLaunchKernelGGL(pseudo_fuse_kernel, dim3(n), dim3(FUSE_T), 0, (hipStream_t)stream, k);
-  DSL_LAUNCH_CHECK("pseudo_fuse_kernel");
-  return 0;
+  return dsl_pseudo_label_fuse_history(dets, labels, count, n, max_per_img, nullptr, nullptr, nullptr, nullptr, 0, num_classes,
+                                       parse_thr, iou_thr, nms_thr, out_boxes, out_scores, out_labels, out_count, max_per_img,
+                                       stream);
 }

@@ -1,7 +1,7 @@
 """Pseudo labels of the unlabeled stream: the in-memory replacement of the reference's per-image JSON annotation
 files, with the reference's semantics.
 
-  parse_det_results / fuse   mmdet/runner/hooks/unlabel_pred_hook.py:20-57, 84-171 (save_results2file, fuse_history=False)
+  parse_det_results / fuse   mmdet/runner/hooks/unlabel_pred_hook.py:20-57, 84-171 (save_results2file, fuse_history False / True)
   adaptive_thresholds        unlabel_pred_hook.py:295-367 (adathres)
   split_pseudo_labels        mmdet/datasets/semicoco.py:184-291 (SemiCOCODataset._parse_ann_info)
   file formats               tools/generate_unlabel_annos_coco.py:36-58 ({imageName,targetNum,rects,tags,masks,scores}),
@@ -71,13 +71,18 @@ def parse_det_results(dets, labels, score_thr):
     return dict(rects=np.trunc(b[order, :4]).astype(np.int64), tags=l[order].astype(np.int64), scores=scores[order])
 
 
-def fuse_host(dets, labels, parse_thr, iou_thr, nms_thr=0.1, num_classes=80):
+def fuse_host(dets, labels, parse_thr, iou_thr, nms_thr=0.1, num_classes=80, old=None):
     """Host restatement of the label-file step (what dsl_pseudo_label_fuse does on the GPU): parse_det_results, then per
     class 0..num_classes-1 mmcv.ops.nms(iou_threshold, score_threshold=nms_thr) on the truncated boxes
-    (unlabel_pred_hook.py:150-166).  Used by the CPU tests and as the checker of the kernel."""
+    (unlabel_pred_hook.py:150-166).  old = dict(rects, tags, scores): fuse_history=True, the stored labels precede the new
+    detections (:131-141).  Used by the CPU tests and as the checker of the kernel."""
     e = parse_det_results(dets, labels, parse_thr)
     rects = e['rects'].astype(np.float32)
     scores = e['scores'].astype(np.float32)
+    if old is not None and len(old['scores']):
+        rects = np.concatenate([np.asarray(old['rects'], np.float32).reshape(-1, 4), rects])
+        scores = np.concatenate([np.asarray(old['scores'], np.float32), scores])
+        e = dict(tags=np.concatenate([np.asarray(old['tags'], np.int64), e['tags']]))
     out_b, out_s, out_l = [], [], []
     for c in range(num_classes):
         idx = np.nonzero((e['tags'] == c) & (scores > np.float32(nms_thr)))[0]

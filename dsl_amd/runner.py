@@ -429,7 +429,8 @@ class UnlabelPredHook(Hook):
 
     One refresh = teacher forward on the image's test view -> dsl_fcos_detect (top-k, decode, class-aware NMS, top 100)
     -> dsl_pseudo_label_fuse (score >= infer_score_thre, int() truncation, 6-decimal scores, second per-class NMS at
-    eval_config['iou'][0] with score_threshold 0.1, :20-57,150-166) -> PseudoLabelBank; nothing leaves the GPU until the
+    eval_config['iou'][0] with score_threshold 0.1, :20-57,150-166; with fuse_history=True the image's stored labels join
+    the candidates, :131-141, first_fuse=False keeps them out of the first sweep) -> PseudoLabelBank; nothing leaves the GPU until the
     loader asks the bank for that image's annotations."""
 
     def __init__(self, kwargs=None, config=None, task_type='Det', interval_mode=None, interval=None, bank=None,
@@ -445,8 +446,6 @@ class UnlabelPredHook(Hook):
         self.use_ema = bool(k.get('use_ema', True))
         self.start_point = int(k.get('start_point', 0))
         self.fuse = bool(k.get('fuse_history', False))
-        if self.fuse:
-            raise NotImplementedError('fuse_history=True (NMS against the previous labels) is not built; configs/fcos_semi use False')
         self.first_ignore = not k.get('first_fuse', True)
         self.iou = float((k.get('eval_config') or {}).get('iou', [0.6])[0])
         ec = k.get('eval_checkpoint_config') or {}
@@ -535,7 +534,7 @@ class UnlabelPredHook(Hook):
         self.refresh_names(runner, src.names[rank::world], thr=thr)
         if world > 1:
             self.bank_all_gather()
-        if self.first_ignore:
+        if self.fuse and self.first_ignore:        # after the first fuse the initial labels take part (:508-510)
             self.first_ignore = False
 
     def refresh_names(self, runner, names, thr=None):
@@ -578,9 +577,12 @@ class UnlabelPredHook(Hook):
         osc = torch.empty(n, maxk, device=dets.device)
         ol = torch.empty(n, maxk, dtype=torch.int64, device=dets.device)
         oc = torch.empty(n, dtype=torch.int32, device=dets.device)
-        L.check(L.lib.dsl_pseudo_label_fuse(L.ptr(dets), L.ptr(labels), L.ptr(count), n, maxk, self.num_classes, float(thr),
-                                            float(self.iou), 0.1, L.ptr(ob), L.ptr(osc), L.ptr(ol), L.ptr(oc), L.stream_ptr()),
-                'dsl_pseudo_label_fuse')
+        if self.fuse and not self.first_ignore:
+            ob, osc, ol = self._fuse_with_history(dets, labels, count, names, thr, oc)
+        else:
+            L.check(L.lib.dsl_pseudo_label_fuse(L.ptr(dets), L.ptr(labels), L.ptr(count), n, maxk, self.num_classes, float(thr),
+                                                float(self.iou), 0.1, L.ptr(ob), L.ptr(osc), L.ptr(ol), L.ptr(oc), L.stream_ptr()),
+                    'dsl_pseudo_label_fuse')
         ev = torch.cuda.Event()
         ev.record()
         for i, name in enumerate(names):
@@ -589,6 +591,36 @@ class UnlabelPredHook(Hook):
                 self.bank.export_json(name, self.export_dir)
         self.n_refreshed += len(names)
         return self.bank
+
+    def _fuse_with_history(self, dets, labels, count, names, thr, oc):
+        """fuse_history=True (:131-141): every image's stored labels join its new detections before the per-class NMS.  The old
+        record is read through the bank (its producing sweep is at least one refresh interval old) and goes up as one small
+        table per call; the label lists grow from round to round, so the output rows are sized old + new."""
+        n, maxk, dev = dets.shape[0], dets.shape[1], dets.device
+        olds = [self.bank[nm] if nm in self.bank else None for nm in names]
+        max_old = max([len(o['scores']) for o in olds if o is not None] + [0])
+        if max_old + maxk > 1024:
+            raise RuntimeError(f'fuse_history: {max_old} stored labels + {maxk} detections exceed the fuse step\'s 1024 candidates')
+        mo = max(max_old, 1)
+        hb, hs = torch.zeros(n, mo, 4), torch.zeros(n, mo)
+        hl, hc = torch.zeros(n, mo, dtype=torch.int64), torch.zeros(n, dtype=torch.int32)
+        for i, o in enumerate(olds):
+            if o is not None and len(o['scores']):
+                k = len(o['scores'])
+                hb[i, :k] = torch.from_numpy(np.asarray(o['rects'], np.float32).reshape(-1, 4))
+                hs[i, :k] = torch.from_numpy(np.asarray(o['scores'], np.float32))
+                hl[i, :k] = torch.from_numpy(np.asarray(o['tags'], np.int64))
+                hc[i] = k
+        db, ds, dl, dc = (t.to(dev, non_blocking=True) for t in (hb, hs, hl, hc))
+        mout = max_old + maxk
+        ob = torch.empty(n, mout, 4, device=dev)
+        osc = torch.empty(n, mout, device=dev)
+        ol = torch.empty(n, mout, dtype=torch.int64, device=dev)
+        L.check(L.lib.dsl_pseudo_label_fuse_history(L.ptr(dets), L.ptr(labels), L.ptr(count), n, maxk, L.ptr(db), L.ptr(ds), L.ptr(dl),
+                                                    L.ptr(dc), max_old, self.num_classes, float(thr), float(self.iou), 0.1, L.ptr(ob),
+                                                    L.ptr(osc), L.ptr(ol), L.ptr(oc), mout, L.stream_ptr()),
+                'dsl_pseudo_label_fuse_history')
+        return ob, osc, ol
 
     def bank_all_gather(self):
         """Every rank ends up with every rank's new records (the reference's ranks share them through the file system)."""

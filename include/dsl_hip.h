@@ -422,6 +422,17 @@ int dsl_pseudo_label_fuse(const float* dets, const int64_t* labels, const int32_
                           int num_classes, float parse_thr, float iou_thr, float nms_thr, float* out_boxes,
                           float* out_scores, int64_t* out_labels, int32_t* out_count, void* stream);
 
+/* The same step with fuse_history=True (unlabel_pred_hook.py:131-141): the image's previous labels - old_boxes
+ * [n][max_old][4], old_scores [n][max_old], old_labels [n][max_old] (class indices), old_count [n], taken as the label
+ * file held them (no truncation, no parse_thr) - precede the new detections in each class's candidate list.
+ * max_per_img + max_old <= 1024; the outputs have max_out >= max_per_img + max_old slots per image.  max_old = 0 (old
+ * pointers may be NULL) is dsl_pseudo_label_fuse. */
+int dsl_pseudo_label_fuse_history(const float* dets, const int64_t* labels, const int32_t* count, int n, int max_per_img,
+                                  const float* old_boxes, const float* old_scores, const int64_t* old_labels,
+                                  const int32_t* old_count, int max_old, int num_classes, float parse_thr, float iou_thr,
+                                  float nms_thr, float* out_boxes, float* out_scores, int64_t* out_labels,
+                                  int32_t* out_count, int max_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Op-list executor: run a prebuilt sequence of the ops above with one call (keeps the per-step
  * host cost of ~400 launches out of Python).

@@ -333,13 +333,12 @@ def gen_parse_dets():
     print('wrote parse_dets.json', [len(c['out']) for c in cases])
 
 
-def gen_fuse():
-    """The label-file step of the refresh, save_results2file (runner/hooks/unlabel_pred_hook.py:84-171, fuse=False), run
-    from its own source text on synthetic detector outputs; mmcv.ops.nms (not in the tree) is the documented mmcv 1.3.10
-    behaviour restated here: keep scores > score_threshold, sort descending, greedy, suppress IoU > iou_threshold."""
+def _fuse_namespace():
+    """save_results2file and its helpers compiled from the reference's own source text (runner/hooks/unlabel_pred_hook.py:20-171);
+    mmcv.ops.nms (not in the tree) is the documented mmcv 1.3.10 behaviour restated here: keep scores > score_threshold, sort
+    descending, greedy, suppress IoU > iou_threshold."""
     import ast
     import json
-    import tempfile
     path = os.path.join(R.REF, 'mmdet/runner/hooks/unlabel_pred_hook.py')
     tree = ast.parse(open(path).read())
     want = ('parse_det_results', 'gen_save_json_dict', 'create_dir', 'save_results2file')
@@ -368,6 +367,31 @@ def gen_fuse():
 
     ns = dict(os=os, json=json, np=np, nms=nms)
     exec(compile(ast.Module(body=fns, type_ignores=[]), path, 'exec'), ns)
+    return ns
+
+
+def _synth_dets(rng, k, C_):
+    """Clusters of overlapping boxes so that the second NMS has work to do; fractional coordinates, scores around both
+    thresholds."""
+    ctr = rng.uniform(20, 300, (max(1, k // 4), 2))
+    which = rng.randint(0, len(ctr), k)
+    wh = rng.uniform(8, 90, (k, 2))
+    c = ctr[which] + rng.normal(0, 6, (k, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1)
+    scores = np.sort(rng.uniform(0.03, 0.99, k))[::-1]
+    scores[rng.randint(0, k)] = 0.1           # exactly at infer_score_thre: kept by parse (>=), dropped by nms (>)
+    scores = np.sort(scores)[::-1]
+    dets = np.concatenate([boxes, scores[:, None]], 1).astype(np.float32)
+    labels = rng.randint(0, C_, k)
+    return dets, labels
+
+
+def gen_fuse():
+    """The label-file step of the refresh, save_results2file (runner/hooks/unlabel_pred_hook.py:84-171, fuse=False), run
+    from its own source text on synthetic detector outputs."""
+    import json
+    import tempfile
+    ns = _fuse_namespace()
     C_ = 6
     names = [f'cls{i}' for i in range(C_)] + ['background']
     id2cat = {str(i): n for i, n in enumerate(names)}
@@ -379,18 +403,7 @@ def gen_fuse():
         root = os.path.join(tmp, 'images')
         os.makedirs(root)
         k = int(rng.randint(5, 60))
-        # clusters of overlapping boxes so that the second NMS has work to do; fractional coordinates, scores around
-        # both thresholds
-        ctr = rng.uniform(20, 300, (max(1, k // 4), 2))
-        which = rng.randint(0, len(ctr), k)
-        wh = rng.uniform(8, 90, (k, 2))
-        c = ctr[which] + rng.normal(0, 6, (k, 2))
-        boxes = np.concatenate([c - wh / 2, c + wh / 2], 1)
-        scores = np.sort(rng.uniform(0.03, 0.99, k))[::-1]
-        scores[rng.randint(0, k)] = 0.1           # exactly at infer_score_thre: kept by parse (>=), dropped by nms (>)
-        scores = np.sort(scores)[::-1]
-        dets = np.concatenate([boxes, scores[:, None]], 1).astype(np.float32)
-        labels = rng.randint(0, C_, k)
+        dets, labels = _synth_dets(rng, k, C_)
         result = [dets[labels == i] for i in range(C_)]          # bbox2result (core/bbox/transforms.py:99-116)
         json.dump(dict(imageName='a.jpg', targetNum=0, rects=[], tags=[], masks=[], scores=[]),
                   open(os.path.join(tmp, 'a.jpg.json'), 'w'))
@@ -529,6 +542,50 @@ def gen_ubaug():
     save('ubaug_pil.npz', **out)
 
 
+def gen_fuse_history():
+    """save_results2file with fuse=True (:131-141): the previous contents of the image's label file join the new detections
+    before the per-class NMS.  Three rounds per case on one file, as the hook runs them (:470-510): round 1 with
+    first_ignore (first_fuse=False: the initial labels are dropped), rounds 2 and 3 fuse with what the round before wrote."""
+    import json
+    import tempfile
+    ns = _fuse_namespace()
+    C_ = 6
+    names = [f'cls{i}' for i in range(C_)] + ['background']
+    id2cat = {str(i): n for i, n in enumerate(names)}
+    cat2id = {n: i for i, n in enumerate(names)}
+    rng = np.random.RandomState(41)
+    cases = []
+    for case in range(4):
+        tmp = tempfile.mkdtemp()
+        root = os.path.join(tmp, 'images')
+        os.makedirs(root)
+        # initial labels of the file (the first training stage's predictions): fractional boxes, some scores under 0.1
+        k0 = int(rng.randint(3, 20))
+        d0, l0 = _synth_dets(rng, k0, C_)
+        init = dict(imageName='a.jpg', targetNum=k0, rects=d0[:, :4].astype(np.float64).round(3).tolist(),
+                    tags=[names[i] for i in l0], masks=[[] for _ in range(k0)], scores=d0[:, 4].astype(np.float64).round(6).tolist())
+        json.dump(init, open(os.path.join(tmp, 'a.jpg.json'), 'w'))
+        iou = [0.6, 0.5, 0.3, 0.45][case]
+        first_ignore = case % 2 == 0
+        rounds = []
+        for rd in range(3):
+            k = int(rng.randint(5, 50))
+            dets, labels = _synth_dets(rng, k, C_)
+            result = [dets[labels == i] for i in range(C_)]
+            old = json.load(open(os.path.join(tmp, 'a.jpg.json')))
+            ns['save_results2file'](result, os.path.join(root, 'a.jpg'), 400, 400, 'json', 'iteration_1.pth', 0.1, id2cat, cat2id,
+                                    root, tmp, 'Det', anno_root_path=tmp, iou=iou, fuse=True, first_ignore=(first_ignore and rd == 0))
+            out = json.load(open(os.path.join(tmp, 'a.jpg.json')))
+            rounds.append(dict(dets=dets.tolist(), labels=labels.tolist(), first_ignore=bool(first_ignore and rd == 0),
+                               old_rects=old['rects'], old_tags=[cat2id[t] for t in old['tags']], old_scores=old['scores'],
+                               rects=out['rects'], tags=[cat2id[t] for t in out['tags']], scores=out['scores'],
+                               targetNum=out['targetNum']))
+        cases.append(dict(iou=iou, rounds=rounds))
+    json.dump(dict(infer_score_thre=0.1, nms_score_thr=0.1, id2cat=id2cat, cases=cases),
+              open(os.path.join(HERE, 'fuse_hist.json'), 'w'))
+    print('wrote fuse_hist.json', [[(len(r['old_scores']), len(r['dets']), r['targetNum']) for r in c['rounds']] for c in cases])
+
+
 if __name__ == '__main__':
     if sys.argv[1:] == ['ubaug']:
         gen_ubaug()
@@ -544,6 +601,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if sys.argv[1:] == ['fuse']:
         gen_fuse()
+        sys.exit(0)
+    if sys.argv[1:] == ['fuse_hist']:
+        gen_fuse_history()
         sys.exit(0)
     if sys.argv[1:] == ['adathres']:
         gen_adathres()

@@ -23,6 +23,19 @@ def test_fuse_matches_reference_save_results2file():
         assert got['scores'].tolist() == c['scores'] and len(got['tags']) == c['targetNum']
 
 
+def test_fuse_history_matches_reference_save_results2file():
+    """fuse=True (unlabel_pred_hook.py:131-141): three successive refreshes of one label file, with and without
+    first_ignore, as the reference's own save_results2file wrote them (tests/golden/make_golden.py fuse_hist)."""
+    d = json.load(open(os.path.join(GOLDEN, 'fuse_hist.json')))
+    for c in d['cases']:
+        for r in c['rounds']:
+            old = None if r['first_ignore'] else dict(rects=r['old_rects'], tags=r['old_tags'], scores=r['old_scores'])
+            got = fuse_host(np.array(r['dets'], np.float32), np.array(r['labels']), d['infer_score_thre'], c['iou'],
+                            d['nms_score_thr'], num_classes=len(d['id2cat']) - 1, old=old)
+            assert got['rects'].tolist() == r['rects'] and got['tags'].tolist() == r['tags']
+            assert got['scores'].tolist() == r['scores'] and len(got['tags']) == r['targetNum']
+
+
 def test_bank_annotation_modes_and_files(tmp_path):
     names = [f'c{i}' for i in range(4)]
     rects = [[0, 0, 50, 40], [10, 10, 30, 30], [5, 5, 5.5, 30], [200, 200, 260, 260]]

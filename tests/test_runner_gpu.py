@@ -119,6 +119,16 @@ def test_semi_supervised_iterations(tmp_path):
     hook.update_thresholds()
     gt, gl, ig = hook.targets_for(names[0], img_wh=(190, 128))
     assert gt.shape[1] == 4 and ig.shape[1] == 4 and len(gl) == len(gt)
+    # fuse_history=True through the whole refresh: the same sweep again, now fused with what the bank holds
+    before = {n: {k: np.array(v) for k, v in bank[n].items() if k != 'stamp'} for n in names}
+    hook2 = UnlabelPredHook(infer_score_thre=0.0, use_ema=True, fuse_history=True, first_fuse=True, bank=bank)
+    hook2.refresh(runner, batches[1]['img'], batches[1]['img_metas'], names)
+    for i, n in enumerate(names):
+        ref = fuse_host(dets[i, :count[i]], labels[i, :count[i]], 0.0, hook2.iou, 0.1, num_classes=80, old=before[n])
+        e = bank[n]
+        assert e['rects'].tolist() == ref['rects'].tolist() and e['tags'].tolist() == ref['tags'].tolist()
+        assert np.array_equal(e['scores'].astype(np.float32), ref['scores'])
+        assert len(e['tags']) >= len(before[n]['tags'])       # a label is only ever replaced by a better one of its class
 
 
 def test_fuse_kernel_vs_reference_golden():
@@ -145,6 +155,77 @@ def test_fuse_kernel_vs_reference_golden():
         assert n == c['targetNum']
         assert ob[0, :n].cpu().tolist() == c['rects'] and ol[0, :n].cpu().tolist() == c['tags']
         assert osc[0, :n].cpu().numpy().tolist() == np.array(c['scores'], np.float32).tolist()
+
+
+def test_fuse_history_kernel_and_hook_vs_reference_golden():
+    """fuse_history=True: dsl_pseudo_label_fuse_history, and the hook's path around it (old labels read from the bank, the
+    first_fuse=False rule, label lists that grow from refresh to refresh), against three successive save_results2file
+    calls of the reference on one label file (tests/golden/fuse_hist.json), exactly."""
+    from dsl_amd import _lib as L
+    from dsl_amd.pseudo import PseudoLabelBank
+    from dsl_amd.runner import UnlabelPredHook
+    d = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'fuse_hist.json')))
+    C_ = len(d['id2cat']) - 1
+    maxk = 100
+
+    def up(r):
+        k = len(r['dets'])
+        dets = torch.zeros(1, maxk, 5)
+        dets[0, :k] = torch.tensor(r['dets'])
+        labels = torch.zeros(1, maxk, dtype=torch.int64)
+        labels[0, :k] = torch.tensor(r['labels'])
+        return dets.cuda(), labels.cuda(), torch.tensor([k], dtype=torch.int32, device='cuda')
+
+    for c in d['cases']:
+        # (a) the kernel on the golden's own old lists
+        for r in c['rounds']:
+            dets, labels, count = up(r)
+            ko = 0 if r['first_ignore'] else len(r['old_scores'])
+            mo, mout = max(ko, 1), ko + maxk
+            ob_, os_ = torch.zeros(1, mo, 4), torch.zeros(1, mo)
+            ol_ = torch.zeros(1, mo, dtype=torch.int64)
+            if ko:
+                ob_[0, :ko] = torch.tensor(r['old_rects'], dtype=torch.float32)
+                os_[0, :ko] = torch.tensor(r['old_scores'], dtype=torch.float64).float()
+                ol_[0, :ko] = torch.tensor(r['old_tags'])
+            ob_, os_, ol_ = ob_.cuda(), os_.cuda(), ol_.cuda()
+            oc_ = torch.tensor([ko], dtype=torch.int32, device='cuda')
+            ob, osc = torch.empty(1, mout, 4, device='cuda'), torch.empty(1, mout, device='cuda')
+            ol, oc = torch.empty(1, mout, dtype=torch.int64, device='cuda'), torch.empty(1, dtype=torch.int32, device='cuda')
+            L.check(L.lib.dsl_pseudo_label_fuse_history(L.ptr(dets), L.ptr(labels), L.ptr(count), 1, maxk, L.ptr(ob_), L.ptr(os_),
+                                                        L.ptr(ol_), L.ptr(oc_), ko, C_, d['infer_score_thre'], c['iou'],
+                                                        d['nms_score_thr'], L.ptr(ob), L.ptr(osc), L.ptr(ol), L.ptr(oc), mout,
+                                                        L.stream_ptr()))
+            torch.cuda.synchronize()
+            n = int(oc[0])
+            assert n == r['targetNum']
+            assert ob[0, :n].cpu().tolist() == r['rects'] and ol[0, :n].cpu().tolist() == r['tags']
+            assert osc[0, :n].cpu().numpy().tolist() == np.array(r['scores'], np.float32).tolist()
+        # (b) the hook's bookkeeping: the bank starts with the file's initial labels and is refreshed three times
+        r0 = c['rounds'][0]
+        bank = PseudoLabelBank(num_classes=C_, thres='adathres.json')
+        bank.put('a.jpg', r0['old_rects'], r0['old_tags'], r0['old_scores'])
+        hook = UnlabelPredHook(dict(infer_score_thre=d['infer_score_thre'], fuse_history=True, first_fuse=not r0['first_ignore'],
+                                    eval_config=dict(iou=[c['iou']]), num_classes=C_), bank=bank)
+        assert hook.first_ignore == r0['first_ignore']
+        for ri, r in enumerate(c['rounds']):
+            dets, labels, count = up(r)
+            oc = torch.empty(1, dtype=torch.int32, device='cuda')
+            if hook.fuse and not hook.first_ignore:
+                ob, osc, ol = hook._fuse_with_history(dets, labels, count, ['a.jpg'], d['infer_score_thre'], oc)
+            else:
+                ob, osc = torch.empty(1, maxk, 4, device='cuda'), torch.empty(1, maxk, device='cuda')
+                ol = torch.empty(1, maxk, dtype=torch.int64, device='cuda')
+                L.check(L.lib.dsl_pseudo_label_fuse(L.ptr(dets), L.ptr(labels), L.ptr(count), 1, maxk, C_, d['infer_score_thre'],
+                                                    c['iou'], d['nms_score_thr'], L.ptr(ob), L.ptr(osc), L.ptr(ol), L.ptr(oc),
+                                                    L.stream_ptr()))
+            ev = torch.cuda.Event()
+            ev.record()
+            bank.put_device('a.jpg', ob, osc, ol, oc, 0, ev, stamp=ri + 1)
+            hook.first_ignore = False                      # what refresh_all does after the first sweep
+            e = bank['a.jpg']
+            assert e['rects'].tolist() == r['rects'] and e['tags'].tolist() == r['tags']
+            assert e['scores'].astype(np.float32).tolist() == np.array(r['scores'], np.float32).tolist()
 
 
 def test_self_scheduled_refresh_feeds_the_next_batch():
