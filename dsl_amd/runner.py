@@ -417,7 +417,9 @@ class UnlabelPredHook(Hook):
     interval_mode=..., interval=...)`; the dict's keys may also be given as keyword arguments.  Keys read:
     infer_score_thre, first_score_thre, use_ema, start_point, preload, fuse_history / first_fuse, eval_config['iou'],
     category_info_path (dict or file with id2cat / cat2id), ada_thres_weight_settings, anno_root_path (only with
-    export=True: the reference's JSON files are then written there as well).
+    export=True: the reference's JSON files are then written there as well).  `eval_flip` is accepted and has no effect, as in
+    the reference: inference_model (:210-236,243) runs the three mirrored copies through the model and returns the
+    unflipped image's result only.
 
     Schedule (mirrors :446-469): in iteration mode the hook wakes up once `runner.iter + 1 >= start_point *
     iters_per_epoch + 1` and `(runner.iter + 1 - start_point) % interval == 0`; the first time it sweeps EVERY
