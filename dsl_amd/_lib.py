@@ -186,6 +186,12 @@ _SIGS = {
     'dsl_pack_dgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_pack_dgrad_batched': [_vp, _i, _i, _vp],
     'dsl_detect_workspace_bytes': [_vp], 'dsl_fcos_detect': [_vp, _vp],
     'dsl_pseudo_label_fuse': [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    'dsl_comm_unique_id': [_vp],
+    'dsl_comm_init_rank': [_vp, _i, _vp, _i],
+    'dsl_comm_size': [_vp],
+    'dsl_comm_destroy': [_vp],
+    'dsl_allreduce_bucket': [_vp, _vp, C.c_size_t, _vp],
+    'dsl_allreduce_buckets': [_vp, _vp, _vp, _i, _vp],
     'dsl_pseudo_label_fuse_history': [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
     'dsl_run_ops': [_vp, _i, _vp], 'dsl_stream_wait_slot': [_i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_prof_read2': [_vp, _vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
 }

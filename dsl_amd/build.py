@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdsl_hip.so')
-SOURCES = ['api.hip', 'conv.hip', 'misc.hip', 'fcos_loss.hip', 'optim.hip', 'detect.hip', 'rla.hip', 'datapath.hip', 'pair.hip']
+SOURCES = ['api.hip', 'conv.hip', 'misc.hip', 'fcos_loss.hip', 'optim.hip', 'detect.hip', 'rla.hip', 'datapath.hip', 'pair.hip', 'comm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
 
@@ -48,7 +48,7 @@ def build_lib(force=False, verbose=True):
     if force or _stale(LIB, objs):
         # -Wl,--no-undefined: a kernel whose host stub hipcc dropped (a lambda with AMDGPU builtins inside a __global__ function
         # fails its host-side instantiation silently) must fail the BUILD, not the first dlopen on the GPU box
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--no-undefined'] + objs + ['-o', LIB]
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--no-undefined'] + objs + ['-ldl', '-o', LIB]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -286,6 +286,7 @@ class FCOS(nn.Module):
         self.loss_scale = 1.0         # constant factor on every gradient (gradient accumulation: 1/k); the reported losses stay unscaled
         self._pending = []
         self._comm_stream = None
+        self.rccl = None              # parallel.RcclComm: the exchanges go through the C-ABI's communicator instead of torch.distributed
         self.comm_trace = None        # set to [] (bench.py --gpus N): per step, per gradient bucket, timed events of its all-reduce
 
     # ---- nn.Module surface redirected to the flat store ------------------------------------------
@@ -405,7 +406,7 @@ class FCOS(nn.Module):
             # (fcos_head.py:264-274) - then runs under the forward pass
             lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
             plan.assign_ops.run()
-            work = dist.all_reduce(lp.stats[:2], group=self.dist_group, async_op=True)
+            work = self._all_reduce_async(lp.stats[:2], after_current=True)
             fwd.run()
             work.wait()
         else:
@@ -426,6 +427,22 @@ class FCOS(nn.Module):
             losses['loss_sisoft'] = out[3]
         losses.vec = out[:len(losses)]      # the same scalars as ONE tensor: lets _parse_losses avoid per-key device ops
         return losses
+
+    def _all_reduce_async(self, t, after_current=False):
+        """Sum `t` over the ranks beside the caller's stream; returns an object whose wait() orders the current stream behind it.
+        after_current: the collective must see everything queued on the current stream so far (torch's process group
+        orders its own stream that way by itself)."""
+        if self.rccl is None or not t.is_cuda:
+            return dist.all_reduce(t, group=self.dist_group, async_op=True)
+        from .parallel import StreamWork
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        cs = self._comm_stream
+        if after_current:
+            cs.wait_stream(torch.cuda.current_stream())
+        t.record_stream(cs)
+        self.rccl.all_reduce(t, cs)
+        return StreamWork(cs)
 
     def _run_backward(self, plan):
         """Hand-written backward.  Data parallel: gradient bucket s (head+FPN, layer4, layer3, layer2) is all-reduced as
@@ -457,7 +474,12 @@ class FCOS(nn.Module):
                     es = torch.cuda.Event(enable_timing=True)
                     es.record()            # the bucket's named event has fired and the previous bucket's traffic is queued
                     self.comm_trace[-1]['buckets'].append(dict(mb=(hi - lo) * 4 / 1e6, start=es, done=None))
-                self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
+                if self.rccl is not None:
+                    from .parallel import StreamWork
+                    self.rccl.all_reduce(self.store.grad[lo:hi], cs)
+                    self._pending.append(StreamWork(cs))
+                else:
+                    self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
         self._rebind_grads()
 
     def wait_grads(self):
@@ -501,7 +523,10 @@ class FCOS(nn.Module):
         keys.append('loss')
         vec = torch.cat([stacked.detach(), loss.detach().reshape(1)])
         if self.world_size > 1:      # ONE all-reduce for all log vars instead of one per key
-            dist.all_reduce(vec, group=self.dist_group)
+            if self.rccl is not None and vec.is_cuda:
+                self.rccl.all_reduce(vec)
+            else:
+                dist.all_reduce(vec, group=self.dist_group)
             vec = vec / self.world_size
         if self.lazy_log:
             log_vars = OrderedDict((k, vec[i]) for i, k in enumerate(keys))

@@ -10,21 +10,76 @@ reference.  The per-step exchanges are:
     the 1/world averaging is folded into the loss kernel's gradient scale, so the buckets are plain sums;
   * one small all-reduce of the log vars (base.py:201-206 does one per key).
 The flat gradient buffer makes every bucket one contiguous range: no flatten/unflatten copies.
+
+Two carriers for the same exchanges: torch.distributed's process group (default; gloo on CPU for the tests, nccl = RCCL
+on GPUs), or `comm='rccl'` / DSL_COMM=rccl: an rcclComm_t of the C-ABI (include/dsl_hip.h dsl_comm_*,
+dsl_allreduce_bucket) - what a caller that is not PyTorch binds - with torch.distributed used once, to hand rank 0's
+unique id to the other ranks.
 """
+import ctypes as C
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
 
+class StreamWork:
+    """What dist.Work.wait() is for a collective queued on `stream`: the caller's current stream waits for it."""
+
+    def __init__(self, stream):
+        self.event = torch.cuda.Event()
+        self.event.record(stream)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class RcclComm:
+    """An RCCL communicator owned through the C-ABI (dsl_comm_init_rank on this process's current device)."""
+
+    def __init__(self, group=None):
+        from . import _lib as L
+        self.L = L
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        uid = C.create_string_buffer(128)
+        if self.rank == 0:
+            L.check(L.lib.dsl_comm_unique_id(uid), 'dsl_comm_unique_id')
+        box = [bytes(uid.raw)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        comm = C.c_void_p()
+        L.check(L.lib.dsl_comm_init_rank(C.byref(comm), self.world, C.create_string_buffer(box[0], 128), self.rank),
+                'dsl_comm_init_rank')
+        self.comm = comm
+        assert L.lib.dsl_comm_size(self.comm) == self.world
+
+    def all_reduce(self, t, stream=None):
+        """In-place fp32 sum of the contiguous tensor `t` over the ranks, queued on `stream` (default: the current one)."""
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        s = stream if stream is not None else torch.cuda.current_stream()
+        self.L.check(self.L.lib.dsl_allreduce_bucket(self.comm, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(s.cuda_stream)),
+                     'dsl_allreduce_bucket')
+        return t
+
+    def close(self):
+        if self.comm is not None and self.comm.value:
+            self.L.lib.dsl_comm_destroy(self.comm)
+        self.comm = None
+
+
 class HipDistributedDataParallel(nn.Module):
     def __init__(self, module, process_group=None, broadcast_buffers=False, find_unused_parameters=False,
-                 device_ids=None, **kw):
+                 device_ids=None, comm=None, **kw):
         super().__init__()
         assert dist.is_initialized(), 'init_process_group first (tools/train.py:116-123)'
         self.module = module
         self.group = process_group
         module.dist_group = process_group
         module.world_size = dist.get_world_size(process_group)
+        comm = comm if comm is not None else os.environ.get('DSL_COMM', 'torch')
+        assert comm in ('torch', 'rccl'), comm
+        module.rccl = RcclComm(process_group) if (comm == 'rccl' and module.store.train.is_cuda) else None
         # initial parameter broadcast from rank 0 (what DDP's constructor does)
         st = module.store
         for buf in (st.train, st.frozen):

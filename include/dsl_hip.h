@@ -434,6 +434,25 @@ int dsl_pseudo_label_fuse_history(const float* dets, const int64_t* labels, cons
                                   int32_t* out_count, int max_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Data-parallel exchange (one process per GPU, RCCL over xGMI).  Stands where the reference has
+ * MMDistributedDataParallel's gradient buckets (mmdet/apis/train.py:92-96) and reduce_mean
+ * (mmdet/core/utils/dist_utils.py:63-69).  librccl.so.1 is bound at the first call (dlopen), not at
+ * load time.  `comm` is an rcclComm_t (= ncclComm_t) passed as void*: one made here, or the caller's own.
+ *   dsl_comm_unique_id   rank 0 fills 128 bytes (ncclGetUniqueId) and hands them to every rank by its own means
+ *   dsl_comm_init_rank   ncclCommInitRank on the calling thread's current device (collective over the ranks)
+ *   dsl_comm_size        number of ranks of the communicator
+ *   dsl_allreduce_bucket in-place fp32 sum of buf[0..count) over the ranks, queued on `stream`; the 1 / world
+ *                        averaging of the gradients is folded into the loss kernel's gradient scale
+ *   dsl_allreduce_buckets  n ranges in one RCCL group call (one launch for several small buckets)
+ * ---------------------------------------------------------------------------------------- */
+int dsl_comm_unique_id(void* id128);
+int dsl_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
+int dsl_comm_size(void* comm);
+int dsl_comm_destroy(void* comm);
+int dsl_allreduce_bucket(void* comm, float* buf, size_t count, void* stream);
+int dsl_allreduce_buckets(void* comm, float* const* bufs, const size_t* counts, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Op-list executor: run a prebuilt sequence of the ops above with one call (keeps the per-step
  * host cost of ~400 launches out of Python).
  * ---------------------------------------------------------------------------------------- */

@@ -47,15 +47,17 @@ def build():
     return model.cuda()
 
 
-def _worker(rank, world, port, q, eager, out_path, backend='gloo'):
+def _worker(rank, world, port, q, eager, out_path, backend='gloo', comm='torch'):
     try:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        torch.cuda.set_device(rank if backend == 'nccl' else 0)       # nccl (= RCCL): one GPU per rank
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        one_gpu_per_rank = backend in ('nccl', 'gloo_nccl_devices')     # nccl (= RCCL): one GPU per rank
+        torch.cuda.set_device(rank if one_gpu_per_rank else 0)
+        dist.init_process_group('nccl' if backend == 'nccl' else 'gloo', rank=rank, world_size=world)
         from dsl_amd.parallel import HipDistributedDataParallel
         model = build()
         model.eager_backward = eager                 # must be the same on every rank: it changes the collective order
-        ddp = HipDistributedDataParallel(model)
+        ddp = HipDistributedDataParallel(model, comm=comm)
+        assert (model.rccl is not None) == (comm == 'rccl')
         out = ddp.train_step(make_batch(rank), None)
         out['loss'].backward()
         model.wait_grads()
@@ -74,12 +76,12 @@ def _worker(rank, world, port, q, eager, out_path, backend='gloo'):
         q.put((rank, traceback.format_exc(), False, None, None))
 
 
-def _ddp_vs_big_batch(eager, tmp_path, backend):
+def _ddp_vs_big_batch(eager, tmp_path, backend, comm='torch'):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
     out_path = str(tmp_path / 'g_ddp.pt')
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, eager, out_path, backend)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, eager, out_path, backend, comm)) for r in range(2)]
     for p in procs:
         p.start()
     try:
@@ -123,6 +125,64 @@ def test_ddp_step_equals_big_batch_rccl(tmp_path):
     communication stream behind the named events, the per-bucket optimizer path is NOT involved (gradients are compared).
     Skipped on 1-GPU boxes; on a multi-GPU node it is RCCL's first contact with this code before the scaling bench."""
     _ddp_vs_big_batch(True, tmp_path, 'nccl')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank: this box has fewer than 2')
+def test_ddp_step_equals_big_batch_cabi_communicator(tmp_path):
+    """The same check with the exchanges carried by the C-ABI's own rcclComm_t (dsl_comm_init_rank, dsl_allreduce_bucket) -
+    torch.distributed (gloo) only hands rank 0's unique id to rank 1."""
+    _ddp_vs_big_batch(True, tmp_path, 'gloo_nccl_devices', comm='rccl')
+
+
+def _one_rank_comm(port, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=0, world_size=1)
+        from dsl_amd import _lib as L
+        from dsl_amd.parallel import RcclComm, StreamWork
+        comm = RcclComm()
+        assert L.lib.dsl_comm_size(comm.comm) == 1
+        g = torch.Generator(device='cuda').manual_seed(0)
+        buf = torch.randn(1 << 20, device='cuda', generator=g)
+        want = buf.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        comm.all_reduce(buf[4096:8192 + 4096], side)           # a bucket = a contiguous range of the flat buffer
+        comm.all_reduce(buf[:2], side)                         # the (num_pos, sum centerness) pair
+        w = StreamWork(side)
+        w.wait()
+        out = buf * 1.0                                        # on the current stream, ordered behind the collective
+        torch.cuda.synchronize()
+        same = torch.equal(out, want)                          # one rank: the sum over the ranks is the operand
+        # error path: a null communicator is refused with a message, not a crash
+        rc = L.lib.dsl_allreduce_bucket(None, L.ptr(buf), 16, L.stream_ptr())
+        msg = L.lib.dsl_last_error().decode()
+        comm.close()
+        dist.destroy_process_group()
+        q.put(('ok', same, rc, msg))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((traceback.format_exc(), False, 0, ''))
+
+
+def test_cabi_communicator_one_rank():
+    """dsl_comm_unique_id / dsl_comm_init_rank / dsl_allreduce_bucket on this box's one GPU: librccl is bound at the first
+    call, a one-rank communicator comes up, all-reduces queued on a side stream leave the operand unchanged and order a
+    StreamWork waiter behind them.  (Two ranks need two GPUs: test_ddp_step_equals_big_batch_cabi_communicator.)"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_comm, args=(_free_port(), q))
+    p.start()
+    try:
+        status, same, rc, msg = q.get(timeout=240)
+    finally:
+        p.join(20)
+        if p.is_alive():
+            p.kill()
+    assert status == 'ok', status
+    assert same
+    assert rc != 0 and 'null' in msg
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank: this box has fewer than 2')
