@@ -35,7 +35,7 @@ PROF_CLASSES = 8
 MAX_MULTI = 16
 SLOT_TAIL, SLOT_PREFIX = 13, 14     # pipelined frozen prefix: 'previous backward's data-gradient chain done', 'prefix of this step done'
 SLOT_PACKS = 15      # named event: the data-gradient weight packs of the last optimizer step are complete
-(RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST) = range(2, 8)
+(RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST, RLA_REC_SUM) = range(2, 9)
 MAX_GROUP = 8
 
 
@@ -116,6 +116,10 @@ class BnPostItem(C.Structure):
                 ('pad_', C.c_int32)]
 
 
+class RecSumItem(C.Structure):
+    _fields_ = [('rec', C.c_void_p), ('out_a', C.c_void_p), ('out_b', C.c_void_p), ('nrec', C.c_int32), ('pad_', C.c_int32)]
+
+
 class PairDesc(C.Structure):
     _fields_ = [('m', C.c_int32), ('p', C.c_int32), ('a', C.c_void_p), ('lda', C.c_int32), ('relu1', C.c_int32), ('wa', C.c_void_p),
                 ('scale1', C.c_void_p), ('bias1', C.c_void_p), ('addend', C.c_void_p), ('ldadd', C.c_int32), ('ldm1', C.c_int32),
@@ -177,6 +181,7 @@ _SIGS = {
     'dsl_quant_fp8': [_vp, _vp, _l, _i, _i, _f, _vp], 'dsl_absmax': [_vp, _l, _i, _i, _vp, _i, _vp],
     'dsl_quant_fp8_dyn': [_vp, _vp, _l, _i, _i, _vp, _i, _vp], 'dsl_fp8_comb': [_vp, _vp, _i, _vp, _i, _vp], 'dsl_quant_fp8_weights': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'dsl_bn_fold': [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp], 'dsl_bn_wgrad_post': [_vp, _i, _i, _f, _vp], 'dsl_rla_op': [_vp, _vp],
+    'dsl_rec_sum_multi': [_vp, _i, _i, _vp],
     'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp], 'dsl_groupnorm_workspace_bytes': [_vp],
     'dsl_sum2x2': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], 'dsl_colsum': [_vp, _vp, _l, _i, _i, _vp],
     'dsl_fcos_points': [_vp, _vp, _vp], 'dsl_fcos_workspace_bytes': [_vp], 'dsl_fcos_assign': [_vp, _vp], 'dsl_fcos_loss': [_vp, _vp],

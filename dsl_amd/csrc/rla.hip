@@ -157,6 +157,32 @@ __global__ __launch_bounds__(256) void rec_sum_kernel(const float* __restrict__ 
   }
 }
 
+// the same for several record sets at once (one workgroup each): the recurrent path's BatchNorms of a stage whose image-split
+// backward chains wrote their block records side by side
+struct RecSumItem {
+  const float* rec; float* out_a; float* out_b;
+  int nrec, pad_;
+};
+__global__ __launch_bounds__(256) void rec_sum_multi_kernel(const RecSumItem* __restrict__ items, int V, int half) {
+  __shared__ float sh[256];
+  const RecSumItem it = items[blockIdx.x];
+  const int Q = 256 / V;
+  const int v = threadIdx.x % V, q = threadIdx.x / V;
+  float a = 0.f;
+  if (q < Q) {
+#pragma unroll 8
+    for (int b = q; b < it.nrec; b += Q) a += it.rec[(long long)b * V + v];
+  }
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < V) {
+    float t = 0.f;
+    for (int k = 0; k < Q; ++k) t += sh[k * V + threadIdx.x];
+    float* dst = threadIdx.x < half ? it.out_a + threadIdx.x : it.out_b + (threadIdx.x - half);
+    *dst = t;
+  }
+}
+
 // ---- eval-mode BN fold: scale = gamma / sqrt(var + eps), bias = beta - mean * scale --------------------------------------
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                                const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ bias, int n) {
@@ -244,14 +270,23 @@ extern "C" size_t dsl_bn_tanh_bwd_workspace_bytes(long rows, int c) {
 extern "C" int dsl_bn_tanh_bwd(const void* gt, int ldgt, const void* t, int ldt, const void* u, int ldu, const float* scale,
                                const float* mean, const float* var, float eps, void* gu, int ldgu, float* dgamma, float* dbeta,
                                void* workspace, long rows, int c, void* stream) {
-  DSL_CHECK(gt && t && u && scale && mean && var && gu && dgamma && dbeta && workspace, "dsl_bn_tanh_bwd: null pointer");
+  DSL_CHECK(gt && t && u && scale && mean && var && gu && workspace && (!dgamma == !dbeta), "dsl_bn_tanh_bwd: null pointer");
   DSL_CHECK(c % 8 == 0 && 2 * c <= 256 && 256 % (2 * c) == 0 && BT_T % (c / 8) == 0, "dsl_bn_tanh_bwd: unsupported channel count %d", c);
   const int nb = (int)((rows + BT_ROWS - 1) / BT_ROWS);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_tanh_bwd_kernel, dim3(nb), dim3(BT_T), 0, st, (const uint16_t*)gt, ldgt, (const uint16_t*)t, ldt,
                      (const uint16_t*)u, ldu, scale, mean, var, eps, (uint16_t*)gu, ldgu, (float*)workspace, (long long)rows, c / 8);
-  hipLaunchKernelGGL(rec_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, nb, 2 * c, dgamma, dbeta, c, 0);
+  if (dgamma)      // NULL: the block records stay in `workspace` for dsl_rec_sum_multi
+    hipLaunchKernelGGL(rec_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, nb, 2 * c, dgamma, dbeta, c, 0);
   DSL_LAUNCH_CHECK("bn_tanh_bwd_kernel");
+  return 0;
+}
+
+extern "C" int dsl_rec_sum_multi(const dsl_rec_sum_item* items_dev, int n, int c, void* stream) {
+  static_assert(sizeof(dsl_rec_sum_item) == sizeof(RecSumItem), "item layout");
+  DSL_CHECK(items_dev && n > 0 && c > 0 && 2 * c <= 256 && 256 % (2 * c) == 0, "dsl_rec_sum_multi: bad arguments");
+  hipLaunchKernelGGL(rec_sum_multi_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const RecSumItem*)items_dev, 2 * c, c);
+  DSL_LAUNCH_CHECK("rec_sum_multi_kernel");
   return 0;
 }
 
@@ -286,6 +321,7 @@ extern "C" int dsl_rla_op(const dsl_rla_desc* d, void* stream) {
       return dsl_bn_fold((const float*)p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], d->f[0], (float*)p[4],
                          (float*)p[5], i[0], stream);
     case DSL_RLA_BN_POST: return dsl_bn_wgrad_post((const dsl_bn_post_item*)p[0], i[0], i[1], d->f[0], stream);
+    case DSL_RLA_REC_SUM: return dsl_rec_sum_multi((const dsl_rec_sum_item*)p[0], i[0], i[1], stream);
     default: dsl_set_error("dsl_rla_op: unknown kind %d", d->kind); return -1;
   }
 }

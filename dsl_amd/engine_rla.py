@@ -153,6 +153,23 @@ def build_backward(plan, buckets, SIDE):
     bn_p = lambda bn, leaf: st.t32_ptr('bn_train.' + leaf) + st.bn_train_off[bn][0] * 4
     bn_f = lambda bn, leaf: st.frozen.data_ptr() + (st.frozen_regions['bn_train.' + leaf][0] + st.bn_train_off[bn][0]) * 4
     from .engine import OpList
+    import os
+    # Image-split data-gradient chains (as in the forward pass and in Plan's ResNet backward): the images of a batch are
+    # independent through the backbone's backward too - per-image recurrent state, eval-mode BatchNorms - so the chain of a stage
+    # runs as two chains of part-batch launches, images [0, ceil(N/2)) on the caller's stream and the rest on stream 3
+    # (DSL_RLA_SPLIT_BWD: stage indices).  What sums over the batch waits behind the JOIN at the stage's end: the weight gradients
+    # (deferred into the stage's grouped / multi launches anyway) and the (dgamma, dbeta) of the recurrent path's BatchNorms,
+    # whose block records the two chains write side by side (dsl_rec_sum_multi, one launch per stage).
+    # OFF by default - measured on the DSL iteration (N = 3: a 2 + 1 split; tools/exp_env.sh, three alternations in one box):
+    # '' 11.99 / 12.00 / 12.12 ms, '123' 12.17 / 12.16 / 12.15, '23' 12.07 / 12.13 / 12.01: unlike the forward chains and the
+    # ResNet engine's backward, the caller's stream is full of kernel time here (10.7 of 12.1 ms busy, profiles/r03_rla_timeline.txt),
+    # not of launch gaps, and the weight-gradient grids already hold the CUs a second chain would use.
+    BSPLIT = os.environ.get('DSL_RLA_SPLIT_BWD', '') if (SIDE and plan._multi_on and plan.BR and N >= 2) else ''
+    BB = plan.BR
+
+    def br_ws(d_):
+        d_.workspace, d_.workspace_bytes = L.ptr(plan.conv_ws_br), plan.conv_ws_br.numel()
+        return d_
     gh_next = None            # gradient w.r.t. the h a block PRODUCES ([px_out][64], 32 real), written by its consumer
     for s_ in (3, 2, 1):
         ol = OpList()
@@ -161,6 +178,11 @@ def build_backward(plan, buckets, SIDE):
         co, rc = cv[f'backbone.conv_outs.{s_}'], cv[f'backbone.recurrent_convs.{s_}']
         gx = plan.g_stage[s_]                 # gradient w.r.t. the stage's last output (FPN lateral + next stage), unmasked for s < 3
         g3, g2, g1, g_co, g_rc, post = [], [], [], [], [], []
+        bsplit = str(s_) in BSPLIT
+        groups = [(0, (N + 1) // 2, 0), ((N + 1) // 2, N, BB)] if bsplit else [(0, N, 0)]
+        rec_items = []
+        if bsplit:
+            ol.fork(BB)
 
         def emit(d):            # a single weight gradient: with the stage's multi launch (Plan._flush_wgrads) or on its own
             if plan._multi_on and SIDE:
@@ -173,7 +195,14 @@ def build_backward(plan, buckets, SIDE):
             (h, w), (oh, ow) = blk['in_hw'], blk['out_hw']
             cx, ldx, stride = blk['cx'], blk['ldx'], blk['stride']
             pin, pout = N * h * w, N * oh * ow
+            ihw, ohw = h * w, oh * ow
             first = s_ == 1 and b == 0                       # input comes from the frozen stage 0: no data gradient
+            rows2d = lambda t_: t_.view(-1, t_.shape[-1])
+            I = lambda t_, b_, e_: None if t_ is None else rows2d(t_)[b_ * ihw:e_ * ihw]      # rows of images [b_, e_) at the input resolution
+            O = lambda t_, b_, e_: None if t_ is None else rows2d(t_)[b_ * ohw:e_ * ohw]      # ... at the output resolution
+
+            def dg(sd, d_):
+                ol.conv(br_ws(d_) if sd else d_, side=sd)
             if blk['last']:
                 g_pre = gx                                   # masked by the lateral's data gradient already
                 g_u = None
@@ -181,73 +210,97 @@ def build_backward(plan, buckets, SIDE):
                 # ---- recurrent path: h_out = recurrent_conv(t), t = tanh(bn(u)), u = h' + conv_out(out)
                 gh = gh_next
                 g_t = plan.buf(p + '.g_t', pout, RLA_C)
-                ol.conv(plan._dgrad(rc.name, gh, g_t, N, [(oh, ow)], [(oh, ow)], cs=64, cd=RLA_C, cd_pad=rc.cin_store, k=3,
-                                    stride=1, pad=1, ldd=RLA_C))
-                g_rc.append(plan._wgrad(ol, rc, gh, blk['t'], N, [(oh, ow)], [(oh, ow)], cy=64, cd=RLA_C, emit=False, shared=1))
                 g_u = plan.buf(p + '.g_u', pout, 64, zero=True)
-                ws = plan.buf(p + '.bnws', L.lib.dsl_bn_tanh_bwd_workspace_bytes(pout, RLA_C) // 4 + 8, dtype=torch.float32)
+                g_pre = plan.buf(p + '.g_pre', pout, c4)
+                nrec = [-(-((e_ - b_) * ohw) // 256) for b_, e_, _ in groups]
+                ws = plan.buf(p + '.bnws', sum(nrec) * 2 * RLA_C + 8, dtype=torch.float32)
                 sc, _ = st.bn_ptrs(blk['bn'])
-                _rla_op(ol, L.RLA_BN_TANH_BWD, p=(g_t, blk['t'], blk['u'], sc, bn_f(blk['bn'], 'running_mean'),
-                                                  bn_f(blk['bn'], 'running_var'), g_u, bn_g(blk['bn'], 'weight'),
-                                                  bn_g(blk['bn'], 'bias'), ws),
-                        i=(RLA_C, blk['tw'], RLA_C, 64, RLA_C), f=(1e-5,), rows=pout)
+                rec0 = 0
+                for gi, (g0, ge, sd) in enumerate(groups):
+                    n_ = ge - g0
+                    dg(sd, plan._dgrad(rc.name, O(gh, g0, ge), O(g_t, g0, ge), n_, [(oh, ow)], [(oh, ow)], cs=64, cd=RLA_C,
+                                       cd_pad=rc.cin_store, k=3, stride=1, pad=1, ldd=RLA_C))
+                    whole = len(groups) == 1
+                    _rla_op(ol, L.RLA_BN_TANH_BWD,
+                            p=(O(g_t, g0, ge), O(blk['t'], g0, ge), O(blk['u'], g0, ge), sc, bn_f(blk['bn'], 'running_mean'),
+                               bn_f(blk['bn'], 'running_var'), O(g_u, g0, ge), bn_g(blk['bn'], 'weight') if whole else None,
+                               bn_g(blk['bn'], 'bias') if whole else None, ws.data_ptr() + rec0 * 2 * RLA_C * 4),
+                            i=(RLA_C, blk['tw'], RLA_C, 64, RLA_C), f=(1e-5,), rows=n_ * ohw, side=sd)
+                    rec0 += nrec[gi]
+                    # g_pre = (gx + conv_out^T g_u) * [out > 0]: every contribution to d/d(out) has arrived, mask once
+                    dg(sd, plan._dgrad(co.name, O(g_u, g0, ge), O(g_pre, g0, ge), n_, [(oh, ow)], [(oh, ow)], cs=64, cd=c4, k=1,
+                                       stride=1, pad=0, addend=O(gx, g0, ge), mask=O(blk['out'], g0, ge), ldm=blk['ld_out'],
+                                       mask_last=True, cs_real=RLA_C))
+                if len(groups) > 1:
+                    it = L.RecSumItem()
+                    it.rec, it.out_a, it.out_b, it.nrec = ws.data_ptr(), bn_g(blk['bn'], 'weight'), bn_g(blk['bn'], 'bias'), sum(nrec)
+                    rec_items.append(it)
+                g_rc.append(plan._wgrad(ol, rc, gh, blk['t'], N, [(oh, ow)], [(oh, ow)], cy=64, cd=RLA_C, emit=False, shared=1))
                 g_co.append(plan._wgrad(ol, co, g_u, blk['out'], N, [(oh, ow)], [(oh, ow)], cy=64, cd=RLA_C, emit=False,
                                         ldx=blk['ld_out'], shared=1))
-                # g_pre = (gx + conv_out^T g_u) * [out > 0]: every contribution to d/d(out) has arrived, mask once
-                g_pre = plan.buf(p + '.g_pre', pout, c4)
-                ol.conv(plan._dgrad(co.name, g_u, g_pre, N, [(oh, ow)], [(oh, ow)], cs=64, cd=c4, k=1, stride=1, pad=0,
-                                    addend=gx, mask=blk['out'], ldm=blk['ld_out'], mask_last=True, cs_real=RLA_C))
             # ---- bottleneck: out = relu(bn3(conv3(a2)) + identity)
             gA2 = plan.buf(p + '.g_a2', pout, planes)
             gA1 = plan.buf(p + '.g_a1', pin, planes)
+            if not first:
+                wT = st.wT_ptr(c1.name)                  # CRSK rows = input channels of conv1: [x (cx) | h (32) | zeros]
+                gx_prev = plan.buf(p + '.g_in', pin, cx) if b > 0 else plan.g_stage[s_ - 1]      # (holds the FPN lateral's contribution)
+                gh_prev = plan.buf(p + '.g_hin', pin, 64, zero=True)
+                add_buf = plan.buf(p + '.g_hpool', pin, 64, zero=True) if (g_u is not None and blk['pooled']) else None
+            for g0, ge, sd in groups:
+                n_ = ge - g0
+                dg(sd, plan._dgrad(c3.name, O(g_pre, g0, ge), O(gA2, g0, ge), n_, [(oh, ow)], [(oh, ow)], cs=c4, cd=planes, k=1,
+                                   stride=1, pad=0, mask=O(blk['a2'], g0, ge), mask_last=True))
+                dg(sd, plan._dgrad(c2.name, O(gA2, g0, ge), I(gA1, g0, ge), n_, [(oh, ow)], [(h, w)], cs=planes, cd=planes, k=3,
+                                   stride=stride, pad=1, mask=I(blk['a1'], g0, ge), mask_last=True))
+                if first:
+                    continue
+                # ---- gradient w.r.t. the block input (x part) and w.r.t. the incoming h
+                if b > 0:
+                    dg(sd, plan._dgrad(c1.name, I(gA1, g0, ge), I(gx_prev, g0, ge), n_, [(h, w)], [(h, w)], cs=planes, cd=cx, k=1,
+                                       stride=1, pad=0, addend=I(g_pre, g0, ge)))      # + the identity path; masked by the consumer of gx_prev
+                else:
+                    ds = cv[p + '.downsample.0']
+                    dg(sd, plan._dgrad(ds.name, O(g_pre, g0, ge), I(gx_prev, g0, ge), n_, [(oh, ow)], [(h, w)], cs=c4, cd=cx, k=1,
+                                       stride=1, pad=0, os=stride, addend=I(gx_prev, g0, ge)))
+                    dg(sd, plan._dgrad(c1.name, I(gA1, g0, ge), I(gx_prev, g0, ge), n_, [(h, w)], [(h, w)], cs=planes, cd=cx, k=1,
+                                       stride=1, pad=0, addend=I(gx_prev, g0, ge)))
+                # h part: rows [cx, cx + 64) of the pack; + the recurrent path's own h' term
+                add, lda = None, None
+                if g_u is not None:
+                    if blk['pooled']:
+                        add = I(add_buf, g0, ge)
+                        _rla_op(ol, L.RLA_AVGPOOL_BWD, p=(O(g_u, g0, ge), add), i=(64, 64, n_, h, w, RLA_C), side=sd)
+                    else:
+                        add = I(g_u, g0, ge)                 # (no pooling: input and output resolutions agree)
+                    lda = 64
+                dg(sd, plan._dgrad(c1.name, I(gA1, g0, ge), I(gh_prev, g0, ge), n_, [(h, w)], [(h, w)], cs=planes, cd=RLA_C, cd_pad=64,
+                                   k=1, stride=1, pad=0, ldd=64, addend=add, lda=lda, wptr=wT + cx * c1.cout_pad * 2))
             g3.append(plan._wgrad(ol, c3, g_pre, blk['a2'], N, [(oh, ow)], [(oh, ow)], emit=False, raw=True,
                                   db_ptr=bn_g(c3.bn, 'bias')))
-            ol.conv(plan._dgrad(c3.name, g_pre, gA2, N, [(oh, ow)], [(oh, ow)], cs=c4, cd=planes, k=1, stride=1, pad=0,
-                                mask=blk['a2'], mask_last=True))
             d2 = plan._wgrad(ol, c2, gA2, blk['a1'], N, [(oh, ow)], [(h, w)], emit=False, raw=True, db_ptr=bn_g(c2.bn, 'bias'))
             if stride == 1:
                 g2.append(d2)                # the stage's stride-1 3x3 convolutions share a geometry
             else:
                 emit(d2)
-            ol.conv(plan._dgrad(c2.name, gA2, gA1, N, [(oh, ow)], [(h, w)], cs=planes, cd=planes, k=3, stride=stride, pad=1,
-                                mask=blk['a1'], mask_last=True))
             d1 = plan._wgrad(ol, c1, gA1, blk['xh'], N, [(h, w)], [(h, w)], emit=False, raw=True, db_ptr=bn_g(c1.bn, 'bias'))
             if b > 0:
                 g1.append(d1)
             else:
                 emit(d1)
-            # ---- gradient w.r.t. the block input (x part) and w.r.t. the incoming h
-            if b == 0:
                 ds = cv[p + '.downsample.0']
                 emit(plan._wgrad(ol, ds, g_pre, blk['xh'], N, [(oh, ow)], [(h, w)], emit=False, raw=True,
                                  db_ptr=bn_g(ds.bn, 'bias'), ldx=ldx))
             if not first:
-                wT = st.wT_ptr(c1.name)                      # CRSK rows = input channels of conv1: [x (cx) | h (32) | zeros]
-                if b > 0:
-                    gx_prev = plan.buf(p + '.g_in', pin, cx)
-                    ol.conv(plan._dgrad(c1.name, gA1, gx_prev, N, [(h, w)], [(h, w)], cs=planes, cd=cx, k=1, stride=1, pad=0,
-                                        addend=g_pre))      # + the identity path; masked by the consumer of gx_prev
-                else:
-                    gx_prev = plan.g_stage[s_ - 1]           # holds the FPN lateral's contribution already
-                    ol.conv(plan._dgrad(ds.name, g_pre, gx_prev, N, [(oh, ow)], [(h, w)], cs=c4, cd=cx, k=1, stride=1, pad=0,
-                                        os=stride, addend=gx_prev))
-                    ol.conv(plan._dgrad(c1.name, gA1, gx_prev, N, [(h, w)], [(h, w)], cs=planes, cd=cx, k=1, stride=1, pad=0,
-                                        addend=gx_prev))
-                # h part: rows [cx, cx + 64) of the pack; + the recurrent path's own h' term
-                gh_prev = plan.buf(p + '.g_hin', pin, 64, zero=True)
-                add, lda = None, None
-                if g_u is not None:
-                    if blk['pooled']:
-                        add = plan.buf(p + '.g_hpool', pin, 64, zero=True)
-                        _rla_op(ol, L.RLA_AVGPOOL_BWD, p=(g_u, add), i=(64, 64, N, h, w, RLA_C))
-                    else:
-                        add = g_u
-                    lda = 64
-                ol.conv(plan._dgrad(c1.name, gA1, gh_prev, N, [(h, w)], [(h, w)], cs=planes, cd=RLA_C, cd_pad=64, k=1, stride=1,
-                                    pad=0, ldd=64, addend=add, lda=lda, wptr=wT + cx * c1.cout_pad * 2))
                 gh_next = gh_prev
                 gx = gx_prev
             post += [c1, c2, c3] + ([cv[p + '.downsample.0']] if b == 0 else [])
+        if bsplit:
+            ol.join(BB)           # both chains are done: everything below reads whole-batch tensors
+            if rec_items:
+                arr = (L.RecSumItem * len(rec_items))(*rec_items)
+                tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(plan.dev)
+                plan.bufs[f'rla.recsum.{s_}'] = tab
+                _rla_op(ol, L.RLA_REC_SUM, p=(tab,), i=(len(rec_items), RLA_C))
         # ---- the stage's weight gradients: grouped where the geometry is shared, then the BatchNorm post-pass
         post_specs = post
         for grp in (g3, g2, g1):

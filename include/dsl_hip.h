@@ -278,13 +278,20 @@ int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream);
 int dsl_avgpool2x2(const void* x, int ldx, void* y, int ldy, int n, int h, int w, int c, void* stream);
 int dsl_avgpool2x2_bwd(const void* gy, int ldgy, void* gx, int ldgx, int n, int h, int w, int c, void* stream);
 /* t = tanh(bn(u)), BN in eval mode folded to (scale, bias) (:318-320), and its backward: g_u, dgamma, dbeta (overwritten;
- * block records in `workspace`, fixed-order sums) */
+ * block records in `workspace`, fixed-order sums).  dgamma = dbeta = NULL: the records [ceil(rows / 256)][2 c] are left
+ * in `workspace` and dsl_rec_sum_multi sums them - several row ranges of one tensor (image-split backward chains on
+ * two streams) write their records side by side and are summed by one launch behind both. */
 int dsl_bn_tanh_fwd(const void* u, int ldu, const float* scale, const float* bias, void* t, int ldt, long rows, int c,
                     void* stream);
 size_t dsl_bn_tanh_bwd_workspace_bytes(long rows, int c);
 int dsl_bn_tanh_bwd(const void* gt, int ldgt, const void* t, int ldt, const void* u, int ldu, const float* scale,
                     const float* mean, const float* var, float eps, void* gu, int ldgu, float* dgamma, float* dbeta,
                     void* workspace, long rows, int c, void* stream);
+typedef struct dsl_rec_sum_item {
+  const float* rec; float* out_a; float* out_b;      /* out_a[ch] = sum_r rec[r][ch], out_b[ch] = sum_r rec[r][c + ch] */
+  int32_t nrec, pad_;
+} dsl_rec_sum_item;
+int dsl_rec_sum_multi(const dsl_rec_sum_item* items_dev, int n, int c, void* stream);      /* items: DEVICE array, one workgroup each */
 /* eval-mode BatchNorm with TRAINABLE affine parameters (norm_eval freezes the statistics only, :380-388): per-step fold
  * scale = gamma / sqrt(var + eps), bias = beta - mean * scale over n channels */
 int dsl_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
@@ -300,7 +307,7 @@ int dsl_bn_wgrad_post(const dsl_bn_post_item* items_dev, int n, int total_rows, 
 /* one of the above as an op-list entry (DSL_OP_RLA): kind selects the call, the arguments are taken in declaration order
  * from p[] (pointers), i[] (ints: strides / sizes), f[] (eps), rows */
 enum { DSL_RLA_AVGPOOL = 2, DSL_RLA_AVGPOOL_BWD = 3, DSL_RLA_BN_TANH = 4, DSL_RLA_BN_TANH_BWD = 5,
-       DSL_RLA_BN_FOLD = 6, DSL_RLA_BN_POST = 7 };
+       DSL_RLA_BN_FOLD = 6, DSL_RLA_BN_POST = 7, DSL_RLA_REC_SUM = 8 /* p[0] = items, i[0] = n, i[1] = c */ };
 typedef struct dsl_rla_desc {
   int32_t kind;
   int32_t i[8];

@@ -30,7 +30,8 @@ def test_descriptor_sizes_match_header_layout(tmp_path):
     from dsl_amd import _lib as L
     pairs = [('dsl_conv_desc', L.ConvDesc, 'lds'), ('dsl_wgrad_desc', L.WgradDesc, 'slots'),
              ('dsl_gn_desc', L.GnDesc, 'workspace_bytes'), ('dsl_fcos_desc', L.FcosDesc, 'workspace_bytes'),
-             ('dsl_det_desc', L.DetDesc, 'workspace_bytes'), ('dsl_pack_item', L.PackItem, 'tiles_co'), ('dsl_op', L.Op, 'l')]
+             ('dsl_det_desc', L.DetDesc, 'workspace_bytes'), ('dsl_pack_item', L.PackItem, 'tiles_co'), ('dsl_op', L.Op, 'l'),
+             ('dsl_rec_sum_item', L.RecSumItem, 'nrec'), ('dsl_bn_post_item', L.BnPostItem, 'row_start')]
     src = tmp_path / 'sizes.c'
     body = ''.join(f'  printf("%zu %zu\\n", sizeof({c}), offsetof({c}, {f}));\n' for c, _, f in pairs)
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dsl_hip.h"\nint main(void) {\n' + body + '  return 0;\n}\n')
