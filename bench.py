@@ -432,7 +432,8 @@ def main():
         det.comm_trace = None
         bk = [dict(mb=round(b['mb'], 1), start_ms=round(tr['t0'].elapsed_time(b['start']), 3),
                    done_ms=round(tr['t0'].elapsed_time(b['done']), 3) if b['done'] is not None else None) for b in tr['buckets']]
-        extra = dict(comm=dict(buckets=bk, step_ms=round(tr['t0'].elapsed_time(ev_end), 3),
+        extra = dict(comm=dict(carrier='C-ABI rcclComm_t (dsl_allreduce_bucket)' if det.rccl is not None else 'torch.distributed process group',
+                               buckets=bk, step_ms=round(tr['t0'].elapsed_time(ev_end), 3),
                                note='rank 0; bucket order head+FPN, layer4, layer3, layer2; the optimizer updates a bucket as soon as '
                                     'its all-reduce is done (per-bucket SGD), so only traffic still in flight at step_ms is exposed'))
     if rank == 0 and world == 1 and not args.no_dsl:
