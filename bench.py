@@ -196,7 +196,8 @@ def dsl_iteration_timing(steps=12, warm=6, variants=None):
     from dsl_amd.registry import build_detector
     from dsl_amd.runner import EMAOWNHook, OptimizerHook, SemiEpochBasedRunner, UnlabelPredHook
     out = {}
-    for refresh, rla, asyn in variants or ((False, False, False), (True, False, False), (True, False, True), (True, True, False)):
+    for refresh, rla, asyn in variants or ((False, False, False), (True, False, False), (True, False, True), (False, True, False),
+                                           (True, True, False), (True, True, True)):
         student, teacher = build_detector(model_cfg(dsl=True, rla=rla)).cuda(), build_detector(model_cfg(dsl=True, rla=rla)).cuda()
         if rla:
             import warnings
@@ -246,7 +247,7 @@ def dsl_iteration_timing(steps=12, warm=6, variants=None):
         out.setdefault('spread', {})
         if os.environ.get('DSL_BENCH_VERBOSE'):
             print(f'dsl_iteration refresh={refresh} rla={rla} async={asyn}: {dt * 1e3:.3f} ms', file=sys.stderr, flush=True)
-        key = 'ms_per_iter' if not refresh else ('ms_per_iter_with_teacher_refresh' + ('_async' if asyn else '') + ('_rla_backbone' if rla else ''))
+        key = ('ms_per_iter' if not refresh else 'ms_per_iter_with_teacher_refresh' + ('_async' if asyn else '')) + ('_rla_backbone' if rla else '')
         out[key] = round(dt * 1e3, 3)
         out['spread'][key] = [round(gaps[0], 3), round(gaps[-1], 3)]           # min / max interval, ms
         del student, teacher, runner, opt, loader
