@@ -419,7 +419,9 @@ class UnlabelPredHook(Hook):
     category_info_path (dict or file with id2cat / cat2id), ada_thres_weight_settings, anno_root_path (only with
     export=True: the reference's JSON files are then written there as well).  `eval_flip` is accepted and has no effect, as in
     the reference: inference_model (:210-236,243) runs the three mirrored copies through the model and returns the
-    unflipped image's result only.
+    unflipped image's result only.  `async_sweep` (not a reference key): the per-iteration sweep on its own stream beside the
+    student's next step; default = whenever the loader looks at least one batch ahead (same labels, same weights:
+    tests/test_runner_gpu.py::test_async_sweep_gives_the_same_labels).
 
     Schedule (mirrors :446-469): in iteration mode the hook wakes up once `runner.iter + 1 >= start_point *
     iters_per_epoch + 1` and `(runner.iter + 1 - start_point) % interval == 0`; the first time it sweeps EVERY
@@ -475,7 +477,10 @@ class UnlabelPredHook(Hook):
         self.export_dir = k.get('anno_root_path') if export else k.get('export_dir')
         self.iter_fuse_flag = False
         self.n_refreshed = 0
-        self.async_sweep = bool(k.get('async_sweep', False))        # not a key of the reference: see refresh()
+        # not a key of the reference (see refresh()): True / False, or None = asynchronous whenever the labels being refreshed are
+        # not needed by the very next batch (the loader looks >= 1 batch ahead, as the reference's `preload` does)
+        self.async_sweep = k.get('async_sweep', None)
+        self._lookahead = 0
         self._sweep_stream = None
         self._buf = {}
 
@@ -517,7 +522,8 @@ class UnlabelPredHook(Hook):
             return
         src = self._source(runner)
         depth = getattr(src, 'prefetch_depth', None)
-        names = src.upcoming(self.preload_num if depth is None else depth)
+        self._lookahead = self.preload_num if depth is None else depth
+        names = src.upcoming(self._lookahead)
         if names:
             self.refresh_names(runner, names)
 
@@ -552,7 +558,8 @@ class UnlabelPredHook(Hook):
         det = runner._det(runner.model)
         teacher = runner._det(runner.ema_model) if (self.use_ema and runner.ema_flag and runner.ema_model is not None) else det
         thr = self.infer_score_thre if thr is None else thr
-        if self.async_sweep and self.iter_fuse_flag and teacher is not det:
+        asyn = self.async_sweep if self.async_sweep is not None else self._lookahead >= 1
+        if asyn and self.iter_fuse_flag and teacher is not det:
             # (teacher is det - no EMA teacher yet, or use_ema=False - sweeps synchronously: the student's next SGD step and
             # weight re-pack would rewrite the bf16 weights / BatchNorm folds under the side stream's reads)
             # the sweep of an image the loader hands out `prefetch_depth` batches from now runs on its own stream beside the
