@@ -140,6 +140,10 @@ class OpList:
     def pack_image(self, img, out, n, h, w):
         self._add(L.OP_PACK_IMAGE, i=(n, h, w), p=(img, out))
 
+    def stem_pool(self, img, w_groups, scale, bias, out, ld_out, n, h, w):
+        """Image layout + conv1 + BN + ReLU + max pool as one kernel (dsl_stem_pool); scale / bias: raw device pointers."""
+        self._add(L.OP_STEM_POOL, i=(ld_out, n, h, w), p=(img, w_groups, out), l=(int(scale), int(bias)))
+
     def run(self):
         if not self.items:
             return
@@ -220,13 +224,29 @@ class Plan:
     def _build_forward(self):
         st, N, H, W, f = self.store, self.N, self.H, self.W, self.fwd
         cv = st.convs
-        x8 = self.buf('x8', N, H, W, 8)
-        self._img_op = len(f.items)         # bind_image() points this op at the caller's tensor
-        f.pack_image(self.img, x8, N, H, W)
         h1, w1 = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
-        s1 = self.buf('stem', N, h1, w1, 64)
-        f.conv(self._conv(cv['backbone.conv1'], x8, s1, N, [(H, W)], [(h1, w1)], relu=True, small_c=True))
         h, w = conv_out(h1, 3, 2, 1), conv_out(w1, 3, 2, 1)
+        # The frozen stem: image layout + conv1 + BN + ReLU + max pool as ONE kernel (dsl_stem_pool, csrc/stem.hip; DSL_STEM_FUSED=0:
+        # the three launches it replaced - an 8-channel bf16 copy of the image, the implicit-GEMM convolution with K = 448 stored
+        # columns for 147 real ones, the pooling pass over its 400 x 672 x 64 output)
+        fused = os.environ.get('DSL_STEM_FUSED', '1') != '0'
+        if fused:
+            s1 = None
+        else:
+            x8 = self.buf('x8', N, H, W, 8)
+            self._img_op = len(f.items)         # bind_image() points this op at the caller's tensor
+            f.pack_image(self.img, x8, N, H, W)
+            s1 = self.buf('stem', N, h1, w1, 64)
+            f.conv(self._conv(cv['backbone.conv1'], x8, s1, N, [(H, W)], [(h1, w1)], relu=True, small_c=True))
+
+        def emit_pool(out, ld):
+            """The pooled stem output into rows of `ld` elements."""
+            if fused:
+                sc, bi = st.bn_ptrs(cv['backbone.conv1'].bn)
+                self._img_op = len(f.items)
+                f.stem_pool(self.img, st.stem_groups16, sc, bi, out, ld, N, H, W)
+            else:
+                f._add(L.OP_MAXPOOL, i=(N, h1, w1, 64, ld), p=(s1, out))
         self.stage_out, self.stage_ld = [], []      # per stage: (tensor / pointer of the output's first channel, (h, w)), row stride
         # independent branches of the forward graph (a stage's downsample conv next to conv1 -> conv2; P5 -> P6 -> P7 next to
         # the P4 / P3 path) run on side stream 3: their kernels are too small to fill the chip alone
@@ -234,10 +254,10 @@ class Plan:
         self.conv_ws_br = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
         if st.backbone == 'rla':
             from . import engine_rla
-            engine_rla.build_forward(self, s1, h1, w1)
+            engine_rla.build_forward(self, emit_pool, h1, w1)
         else:
             x = self.buf('pool', N, h, w, 64)
-            f.maxpool(s1, x, N, h1, w1, 64)
+            emit_pool(x, 64)
             self._fwd_resnet(x, h, w)
         # ---- FPN (start_level=1) ----
         (c3, hw3), (c4, hw4), (c5, hw5) = self.stage_out[1], self.stage_out[2], self.stage_out[3]

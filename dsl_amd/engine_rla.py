@@ -52,15 +52,15 @@ def conv_out_hw(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-def build_forward(plan, s1, h1, w1):
-    """Stem output s1 (N, h1, w1, 64) -> maxpool into the first XH -> 16 RLA blocks; fills plan.stage_out / stage_ld and
-    plan.rla_blocks (what the backward needs)."""
+def build_forward(plan, emit_pool, h1, w1):
+    """Stem (N, h1, w1, 64) -> max pool into the first XH (emit_pool(out, ld): the plan's stem / pool ops) -> 16 RLA blocks;
+    fills plan.stage_out / stage_ld and plan.rla_blocks (what the backward needs)."""
     st, N, f = plan.store, plan.N, plan.fwd
     cv = st.convs
     h, w = conv_out_hw(h1, 3, 2, 1), conv_out_hw(w1, 3, 2, 1)
     cx = 64
     xh = plan.buf('rla.xh.0.0', N * h * w, cx + RLA_PAD, zero=True)
-    f._add(L.OP_MAXPOOL, i=(N, h1, w1, 64, cx + RLA_PAD), p=(s1, xh))
+    emit_pool(xh, cx + RLA_PAD)
     plan.rla_blocks = []
     import os
     # image-split stages (as in Plan._fwd_resnet): the images of a batch are independent through the backbone - eval-mode

@@ -343,10 +343,14 @@ class ParamStore:
         wp = torch.zeros(64, 7 * 64, device=dev)
         w = self.fview('backbone.conv1.weight')           # [64][7][7][3] -> [64][448], k = tap*8 + c
         wp[:, :392] = torch.cat([w, torch.zeros(64, 7, 7, 5, device=dev)], -1).reshape(64, 392)
+        # the same weight for dsl_stem_pool: [22 groups][64][8], group g = the (kx, c) values 8 (g % 3) .. + 8 of tap row g / 3
+        wg = torch.zeros(64, 7, 24, device=dev)
+        wg[:, :, :21] = w.reshape(64, 7, 21)
+        wg = torch.cat([wg.reshape(64, 21, 8).permute(1, 0, 2), torch.zeros(1, 64, 8, device=dev)], 0)
         # Execution plans bake the device addresses of these four tensors into their kernel descriptors: refresh IN
         # PLACE whenever the buffers already exist on this device (load_state_dict into a model that has already run)
         for name, val in (('bn_scale', torch.cat(scs)), ('bn_bias', torch.cat(bis)), ('frozen16', self.frozen.bfloat16()),
-                          ('stem16', wp.bfloat16())):
+                          ('stem16', wp.bfloat16()), ('stem_groups16', wg.bfloat16())):
             cur = getattr(self, name, None)
             if cur is not None and cur.device == val.device and cur.shape == val.shape:
                 cur.copy_(val)

@@ -240,6 +240,14 @@ int dsl_image_normalize(const unsigned char* src_u8, const dsl_image_prep_item* 
  * SingleStageDetector.extract_feat's input (detectors/single_stage.py:40-45). */
 int dsl_pack_image(const float* img_nchw, void* out_nhwc8, int n, int h, int w, void* stream);
 
+/* The frozen stem as one kernel: fp32 NCHW image -> conv1 7x7 / 2 (3 -> 64) + eval-mode BatchNorm (scale, bias) + ReLU + MaxPool
+ * 3x3 / 2 -> NHWC bf16 [n][ph][pw] rows of ld_out elements (resnet.py:598-645 _make_stem_layer, :634-638).  w_groups: conv1's
+ * weight as [22][64][8] bf16 - group g holds, for every cout, the values 8 (g % 3) .. + 8 of the 21 (kx, c) values of tap row
+ * g / 3, zero beyond (ParamStore.stem_groups16).  Same arithmetic as dsl_pack_image + dsl_conv2d + dsl_maxpool3x3s2 up to the
+ * fp32 summation order of the 147 products. */
+int dsl_stem_pool(const float* img_nchw, const void* w_groups, const float* scale, const float* bias, void* out, int ld_out,
+                  int n, int h, int w, void* stream);
+
 /* 3x3 stride-2 pad-1 max pool, NHWC bf16 (resnet.py:610,638). */
 int dsl_maxpool3x3s2(const void* x, void* y, int n, int h, int w, int c, void* stream);
 int dsl_maxpool3x3s2_ld(const void* x, void* y, int n, int h, int w, int c, int ldy, void* stream);   /* output row stride ldy >= c */
@@ -480,6 +488,8 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_FP8_COMB = 24,   /* dsl_fp8_comb(p[0] = winv, p[1] = comb, i[0] = n, p[2] = partials, i[2] = n_partials) */
        DSL_OP_QUANT_FP8_W = 23, /* dsl_quant_fp8_weights(p[0] = w, p[1] = w8, p[2] = comb, p[3] = bn_scale, i[0] = cout, i[1] = cout_pad, i[2] = k,
                                 * inv_act_scale = the float whose bits are l[1]) */
+       DSL_OP_STEM_POOL = 25,  /* dsl_stem_pool(p[0] = img, p[1] = w_groups, l[0] / l[1] = scale / bias pointers, p[2] = out, i[0] = ld_out,
+                                * i[1..3] = n, h, w) */
        DSL_OP_PROF = 21 };     /* phase mark (dsl_prof_enable(3) only, else a no-op): i[0] = class >= 4, i[1] = 0 begin | 1 end, l[0] / l[1] =
                                 * algorithmic FLOPs / bytes of the phase as IEEE doubles' bit patterns (begin only) */
 typedef struct dsl_op {

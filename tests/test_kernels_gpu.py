@@ -176,6 +176,55 @@ def test_conv_stem_small_c(K):
     assert torch.allclose(from_nhwc(y), ref, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 37, 45), (1, 64, 96), (2, 128, 192), (1, 800, 1344), (3, 70, 131)])
+def test_stem_pool_fused_kernel(K, shape):
+    """dsl_stem_pool (image layout + conv1 7x7 / 2 + BN + ReLU + max pool 3x3 / 2 in one kernel) against (a) torch fp32 on the
+    bf16-rounded operands with the stem output rounded to bf16 before the pooling - what the three launches it replaces compute -
+    and (b) those three launches themselves (dsl_pack_image, dsl_conv2d, dsl_maxpool3x3s2): same values up to the summation
+    order of the 147 products in front of one bf16 rounding; odd sizes exercise the tile edges and both paddings; the output
+    row stride is honoured (the RLA engine pools into [x | h | zeros] rows)."""
+    L, ops = K
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    x = torch.randn(N, 3, H, W, generator=g) * 50            # fp32 image, NOT pre-rounded: the kernel rounds it as pack_image does
+    w = rnd(64, 3, 7, 7, g=g, scale=0.05)
+    scale, bias = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    conv = F.conv2d(bf(x), w, None, 2, 3)
+    stem = bf(F.relu(conv * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)))
+    ref = F.max_pool2d(stem, 3, 2, 1)
+    PH, PW = ref.shape[2:]
+    wg = torch.zeros(64, 7, 24)
+    wg[:, :, :21] = w.permute(0, 2, 3, 1).reshape(64, 7, 21)
+    wg = torch.cat([wg.reshape(64, 21, 8).permute(1, 0, 2), torch.zeros(1, 64, 8)], 0).bfloat16().cuda().contiguous()
+    x_d, sc_d, bi_d = x.cuda(), scale.cuda(), bias.cuda()
+    for ld in (64, 192):
+        out = torch.full((N, PH, PW, ld), 7.0, dtype=torch.bfloat16, device='cuda')
+        L.check(L.lib.dsl_stem_pool(L.ptr(x_d), L.ptr(wg), L.ptr(sc_d), L.ptr(bi_d), L.ptr(out), ld, N, H, W, L.stream_ptr()))
+        sync()
+        got = from_nhwc(out[..., :64])
+        assert float(out[..., 64:].float().sub(7.0).abs().max() if ld > 64 else 0.0) == 0.0        # columns beyond 64 untouched
+        err = (got - ref).abs()
+        tol = 1e-2 * ref.abs() + 2e-2
+        assert bool((err <= tol).all()), (float(err.max()), float(ref.abs().max()))
+        assert float((got != ref).float().mean()) < 0.02           # ... and almost everywhere the very same bf16 value
+    # (b) the three-launch path on the same operands
+    Ho, Wo = conv.shape[2:]
+    x8 = torch.empty(N, H, W, 8, dtype=torch.bfloat16, device='cuda')
+    L.check(L.lib.dsl_pack_image(L.ptr(x_d), L.ptr(x8), N, H, W, L.stream_ptr()))
+    wp = torch.zeros(64, 7 * 64)
+    wp[:, :392] = torch.cat([w.permute(0, 2, 3, 1), torch.zeros(64, 7, 7, 5)], -1).reshape(64, 392)
+    y = torch.empty(N, Ho, Wo, 64, dtype=torch.bfloat16, device='cuda')
+    ops.conv2d(x8, wp.bfloat16().cuda(), y, n=N, grid=[(Ho, Wo)], src_hw=[(H, W)], dst_hw=[(Ho, Wo)], cs=8, cd=64, cd_pad=64,
+               ldd=64, kh=7, kw=7, stride=2, pad=3, flags=L.CONV_RELU_OUT | L.CONV_SMALL_C, scale=sc_d, bias=bi_d)
+    z = torch.empty(N, PH, PW, 64, dtype=torch.bfloat16, device='cuda')
+    L.check(L.lib.dsl_maxpool3x3s2(L.ptr(y), L.ptr(z), N, Ho, Wo, 64, L.stream_ptr()))
+    sync()
+    three = from_nhwc(z)
+    assert float((three != got).float().mean()) < 0.02
+    assert bool(((three - got).abs() <= 1e-2 * got.abs() + 2e-2).all())
+
+
 def _multiseg(tensors):      # list of NCHW fp32 -> level-major flat NHWC bf16 on device
     return torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in tensors]).bfloat16().cuda()
 
