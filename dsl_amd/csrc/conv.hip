@@ -3223,6 +3223,21 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   k.addend = (const uint16_t*)d->addend; k.mask = (const uint16_t*)d->mask;
 
   hipStream_t st = (hipStream_t)stream;
+  // ---- 3x3 / 1, 64 -> 64, BatchNorm + ReLU epilogue (layer1's middle convolutions): the activation-stationary kernel of patch3.hip
+  // (pixel tile + halo staged once, nine taps out of LDS, weights in registers) instead of nine K tiles of implicit GEMM
+  if (!smallc && !fp8 && d->mode == 0 && d->nseg == 1 && d->cs == 64 && d->cd == 64 && d->cd_pad == 64 && d->kh == 3 && d->kw == 3 &&
+      d->stride == 1 && d->pad == 1 && d->os == 1 && k.ident && (d->flags & 0xff & ~DSL_CONV_RELU_OUT) == 0 && (d->flags >> 8) == 0 &&
+      d->scale && d->bias && !d->addend && !d->mask && d->ldd % 8 == 0 && d->sh[0] == d->gh[0] && d->sw[0] == d->gw[0]) {
+    const char* e = getenv("DSL_PATCH3");
+    if (!e || atoi(e) != 0) {
+      int prof = -1;
+      if (dsl_prof_active()) prof = dsl_prof_begin(2, conv_algo_flops(d, px), st, conv_algo_bytes(d, px));
+      const int rc = dsl_conv3x3_c64_patch(d->src, k.lds, d->wgt, d->scale, d->bias, d->dst, d->ldd, d->n, d->gh[0], d->gw[0],
+                                           (d->flags & DSL_CONV_RELU_OUT) ? 1 : 0, stream);
+      dsl_prof_end(prof, st);
+      return rc;
+    }
+  }
   // ---- kernel / tile selection -------------------------------------------------------------------
   int pick, splits;
   conv_choose(d, px, k.ktiles, &pick, &splits);

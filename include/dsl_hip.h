@@ -248,6 +248,15 @@ int dsl_pack_image(const float* img_nchw, void* out_nhwc8, int n, int h, int w, 
 int dsl_stem_pool(const float* img_nchw, const void* w_groups, const float* scale, const float* bias, void* out, int ld_out,
                   int n, int h, int w, void* stream);
 
+/* Activation-stationary 3x3 / stride 1 / pad 1 convolution 64 -> 64 + folded BatchNorm (scale, bias) [+ ReLU], NHWC bf16: the middle
+ * convolution of the frozen layer1 bottlenecks (resnet.py:262-301 Bottleneck.forward: conv2 / bn2 / relu).  src: [n][h][w] rows of
+ * ld_src elements (>= 64, the first 64 are read), wgt: [64][3][3][64] bf16 (the forward layout of dsl_conv2d), dst rows of ld_dst.
+ * The pixel tile + halo is staged in LDS once and all nine taps are multiplied out of it; the weights stay in registers.  Same
+ * arithmetic as dsl_conv2d with flags DSL_CONV_RELU_OUT (same k order, same one-rounding scale / bias), which routes eligible
+ * descriptors here unless DSL_PATCH3=0. */
+int dsl_conv3x3_c64_patch(const void* src, int ld_src, const void* wgt, const float* scale, const float* bias, void* dst, int ld_dst,
+                          int n, int h, int w, int relu, void* stream);
+
 /* 3x3 stride-2 pad-1 max pool, NHWC bf16 (resnet.py:610,638). */
 int dsl_maxpool3x3s2(const void* x, void* y, int n, int h, int w, int c, void* stream);
 int dsl_maxpool3x3s2_ld(const void* x, void* y, int n, int h, int w, int c, int ldy, void* stream);   /* output row stride ldy >= c */

@@ -225,6 +225,59 @@ def test_stem_pool_fused_kernel(K, shape):
     assert bool(((three - got).abs() <= 1e-2 * got.abs() + 2e-2).all())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('relu', [1, 0])
+@pytest.mark.parametrize('shape', [(2, 32, 48), (1, 13, 21), (3, 37, 50), (1, 8, 16), (2, 200, 336)])
+def test_conv3x3_c64_patch_kernel(K, shape, relu, monkeypatch):
+    """dsl_conv3x3_c64_patch (activation-stationary 3x3 64 -> 64 + BatchNorm [+ ReLU]: tile + halo staged once, nine taps out of
+    LDS, weights in registers) against (a) torch fp32 on the bf16-rounded operands, (b) the implicit-GEMM kernels of dsl_conv2d on
+    the same operands (DSL_PATCH3=0, and a forced tile configuration): the k order and the epilogue arithmetic are the same, so
+    the outputs are expected to agree bit for bit, (c) dsl_conv2d's own routing of the eligible descriptor.  Ragged sizes exercise
+    the tile edges and the zero padding; source / destination row strides wider than 64 are honoured (the RLA engine's rows)."""
+    L, ops = K
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x, w = rnd(N, 64, H, W, g=g), rnd(64, 64, 3, 3, g=g, scale=1 / 24.0)
+    scale, bias = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.5
+    ref = F.conv2d(x, w, None, 1, 1) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    if relu:
+        ref = F.relu(ref)
+    x_d, w_d, sc_d, bi_d = nhwc(x), pack_w(w, 64), scale.cuda(), bias.cuda()
+    flags = L.CONV_RELU_OUT if relu else 0
+
+    def generic(force):
+        y = torch.empty(N, H, W, 64, dtype=torch.bfloat16, device='cuda')
+        ops.conv2d(x_d, w_d, y, n=N, grid=[(H, W)], src_hw=[(H, W)], dst_hw=[(H, W)], cs=64, cd=64, cd_pad=64, ldd=64, kh=3, kw=3,
+                   stride=1, pad=1, flags=flags | (force << 8), scale=sc_d, bias=bi_d)
+        sync()
+        return y
+
+    routed = generic(0)                              # (c) eligible descriptor, no forced tile: the patch kernel
+    monkeypatch.setenv('DSL_PATCH3', '0')
+    plain = generic(0)                               # (b) the library's own implicit-GEMM choice
+    monkeypatch.delenv('DSL_PATCH3')
+    forced = generic(6)                              # (b) 64 x 64 tile of the pipelined kernel
+    for ld_s, ld_d in ((64, 64), (128, 192)):
+        xs = torch.full((N, H, W, ld_s), 3.0, dtype=torch.bfloat16, device='cuda')
+        xs[..., :64] = x_d
+        out = torch.full((N, H, W, ld_d), 7.0, dtype=torch.bfloat16, device='cuda')
+        L.check(L.lib.dsl_conv3x3_c64_patch(L.ptr(xs), ld_s, L.ptr(w_d), L.ptr(sc_d), L.ptr(bi_d), L.ptr(out), ld_d, N, H, W, relu,
+                                            L.stream_ptr()))
+        sync()
+        if ld_d > 64:
+            assert float(out[..., 64:].float().sub(7.0).abs().max()) == 0.0         # columns beyond 64 untouched
+        got = from_nhwc(out[..., :64])
+        assert torch.allclose(got, ref, rtol=1e-2, atol=1e-2), float((got - ref).abs().max())
+        assert (got - bf(ref)).abs().max() <= 2 ** -7 * ref.abs().max()
+        assert torch.equal(out[..., :64], routed)
+        for other in (plain, forced):
+            o = from_nhwc(other)
+            assert float((o != got).float().mean()) < 0.02
+            assert bool(((o - got).abs() <= 1e-2 * got.abs() + 2e-2).all())
+        print('patch3', shape, relu, 'bit-identical to implicit GEMM:', bool(torch.equal(out[..., :64], plain)),
+              bool(torch.equal(out[..., :64], forced)))
+
+
 def _multiseg(tensors):      # list of NCHW fp32 -> level-major flat NHWC bf16 on device
     return torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in tensors]).bfloat16().cuda()
 
