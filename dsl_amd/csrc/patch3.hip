@@ -30,7 +30,9 @@ constexpr int NLD = (NCHUNK + P3_T - 1) / P3_T;   // 6 chunk loads per thread
 constexpr int KSTEPS = 36;                        // 9 taps x 64 channels / 16
 constexpr int KG = 6;                             // k-steps per software-pipeline group
 constexpr int WROW = KSTEPS * 16 + 8;             // bf16 elements per staged weight row: 576 + 8 (1 168-byte rows)
-constexpr int SMEM = 64 * WROW > 2 * PATCH + TH * TW * PIX ? 64 * WROW : 2 * PATCH + TH * TW * PIX;      // 74 752 B
+constexpr int STAGE = TH * TW * PIX;                // one staged output tile
+constexpr int SMEM = 2 * PATCH + 2 * STAGE + 256;  // two patches, two output stages, scale[64] + bias[64] as fp32: 89 216 B
+static_assert(64 * WROW <= 2 * PATCH + 2 * STAGE, "the weights pass through the patch / stage bytes, not through scale / bias");
 
 struct P3K {
   const uint16_t* src; const uint16_t* w; const float* scale; const float* bias; uint16_t* dst;
@@ -40,10 +42,15 @@ struct P3K {
 __device__ __forceinline__ float mul1(float a, float b) { return a * b; }      // (contract(off): one rounding each, as conv.hip's mul_nc / add_nc)
 __device__ __forceinline__ float add1(float a, float b) { return a + b; }
 
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for the wave's global stores to be acknowledged:
+// once per tile that is the store latency, serialised; conv.hip's lds_barrier)
+__device__ __forceinline__ void lds_barrier3() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(P3_T) void conv3x3_c64_patch_kernel(const P3K p) {
   __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM];
   uint16_t* const patch0 = smem;                  // [2][PATCH]
-  uint16_t* const stage = smem + 2 * PATCH;       // [TH * TW][PIX]
+  uint16_t* const stage0 = smem + 2 * PATCH;      // [2][TH * TW][PIX]
+  float* const sb = reinterpret_cast<float*>(smem + 2 * PATCH + 2 * STAGE);      // folded BatchNorm: scale[64], bias[64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fhalf = lane >> 5;
   // ---- weights: A fragment of k-step k, row tile mt = 16 bytes of row (32 mt + lane % 32) at k-values 16 k + 8 (lane / 32).
@@ -51,6 +58,7 @@ __global__ __launch_bounds__(P3_T) void conv3x3_c64_patch_kernel(const P3K p) {
   // straight from memory the compiler loads the 288 registers two fragments at a time, each pair behind a full memory round
   // trip (the values that live in accumulation registers are copied there as they arrive) - 36 round trips, ~ 15 of the 30 us the
   // first version of this kernel took for N = 2.
+  if (tid < 128) sb[tid] = tid < 64 ? p.scale[tid] : p.bias[tid - 64];
   {
     constexpr int NW = 64 * (KSTEPS * 2) / P3_T;  // 18 chunks of 16 bytes per thread
     u32x4 v[NW];
@@ -110,9 +118,13 @@ __global__ __launch_bounds__(P3_T) void conv3x3_c64_patch_kernel(const P3K p) {
     fetch(tile);
     land(0);
   }
+  __syncthreads();
+  // One barrier per tile: the next patch lands in the OTHER buffer before it (so the barrier that publishes the staged outputs
+  // publishes the patch too), and the staged outputs alternate between two buffers (a wave still storing tile i is not overtaken
+  // by a wave staging tile i + 1; tile i + 2's staging is behind tile i + 1's barrier).
   for (; tile < p.tiles; tile += gridDim.x, buf ^= 1) {
     const int next = tile + gridDim.x;
-    __syncthreads();                              // patch[buf] is complete; the previous tile's reads of patch[buf ^ 1] and `stage` are over
+    uint16_t* const stage = stage0 + buf * STAGE;
     if (next < p.tiles) fetch(next);              // in flight during the multiplication below
     f32x16 acc[2] = {};
     const uint16_t* pb = patch0 + buf * PATCH + boff;
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(P3_T) void conv3x3_c64_patch_kernel(const P3K p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int co = mt * 32 + 8 * i + 4 * fhalf;
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.scale + co), b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(sb + co), b4 = *reinterpret_cast<const f32x4*>(sb + 64 + co);
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -159,7 +171,8 @@ __global__ __launch_bounds__(P3_T) void conv3x3_c64_patch_kernel(const P3K p) {
         const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
         *reinterpret_cast<u32x2*>(stage + pxl * PIX + co) = o;
       }
-    __syncthreads();
+    if (next < p.tiles) land(buf ^ 1);            // (patch[buf ^ 1] was last read before the previous barrier; its loads had the whole multiplication)
+    lds_barrier3();
     {
       int t = tile;
       const int tx = t % p.tiles_x;
@@ -175,7 +188,6 @@ __global__ __launch_bounds__(P3_T) void conv3x3_c64_patch_kernel(const P3K p) {
               *reinterpret_cast<const u32x4*>(stage + px * PIX + ch * 8);
       }
     }
-    if (next < p.tiles) land(buf ^ 1);            // (patch[buf ^ 1] was last read before this iteration's first barrier)
   }
 }
 

@@ -253,7 +253,7 @@ int dsl_stem_pool(const float* img_nchw, const void* w_groups, const float* scal
  * ld_src elements (>= 64, the first 64 are read), wgt: [64][3][3][64] bf16 (the forward layout of dsl_conv2d), dst rows of ld_dst.
  * The pixel tile + halo is staged in LDS once and all nine taps are multiplied out of it; the weights stay in registers.  Same
  * arithmetic as dsl_conv2d with flags DSL_CONV_RELU_OUT (same k order, same one-rounding scale / bias), which routes eligible
- * descriptors here unless DSL_PATCH3=0. */
+ * descriptors here when DSL_PATCH3=1 (off by default: faster alone, not in the step - DESIGN 3.9). */
 int dsl_conv3x3_c64_patch(const void* src, int ld_src, const void* wgt, const float* scale, const float* bias, void* dst, int ld_dst,
                           int n, int h, int w, int relu, void* stream);
 

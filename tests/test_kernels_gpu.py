@@ -231,8 +231,8 @@ def test_stem_pool_fused_kernel(K, shape):
 def test_conv3x3_c64_patch_kernel(K, shape, relu, monkeypatch):
     """dsl_conv3x3_c64_patch (activation-stationary 3x3 64 -> 64 + BatchNorm [+ ReLU]: tile + halo staged once, nine taps out of
     LDS, weights in registers) against (a) torch fp32 on the bf16-rounded operands, (b) the implicit-GEMM kernels of dsl_conv2d on
-    the same operands (DSL_PATCH3=0, and a forced tile configuration): the k order and the epilogue arithmetic are the same, so
-    the outputs are expected to agree bit for bit, (c) dsl_conv2d's own routing of the eligible descriptor.  Ragged sizes exercise
+    the same operands (the default routing, and a forced tile configuration): the k order and the epilogue arithmetic are the same, so
+    the outputs are expected to agree bit for bit, (c) dsl_conv2d's routing of the eligible descriptor under DSL_PATCH3=1.  Ragged sizes exercise
     the tile edges and the zero padding; source / destination row strides wider than 64 are honoured (the RLA engine's rows)."""
     L, ops = K
     N, H, W = shape
@@ -252,10 +252,10 @@ def test_conv3x3_c64_patch_kernel(K, shape, relu, monkeypatch):
         sync()
         return y
 
-    routed = generic(0)                              # (c) eligible descriptor, no forced tile: the patch kernel
-    monkeypatch.setenv('DSL_PATCH3', '0')
-    plain = generic(0)                               # (b) the library's own implicit-GEMM choice
+    monkeypatch.setenv('DSL_PATCH3', '1')
+    routed = generic(0)                              # (c) eligible descriptor, no forced tile, opted in: the patch kernel
     monkeypatch.delenv('DSL_PATCH3')
+    plain = generic(0)                               # (b) the library's own implicit-GEMM choice (the default)
     forced = generic(6)                              # (b) 64 x 64 tile of the pipelined kernel
     for ld_s, ld_d in ((64, 64), (128, 192)):
         xs = torch.full((N, H, W, ld_s), 3.0, dtype=torch.bfloat16, device='cuda')
