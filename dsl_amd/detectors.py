@@ -377,7 +377,8 @@ class FCOS(nn.Module):
             plan.set_parity(plan._parity ^ 1)
             plan.bind_image(img)
             if self._prefix_stream is None:
-                self._prefix_stream = torch.cuda.Stream()
+                prio = int(os.environ.get('DSL_PREFIX_PRIO', '0'))        # -1: high-priority queue (experiment)
+                self._prefix_stream = torch.cuda.Stream(priority=prio) if prio else torch.cuda.Stream()
             if img.is_cuda:
                 img.record_stream(self._prefix_stream)
             ready = getattr(img, '_dsl_ready', None)          # event of the image's producer (dsl_amd.data.mark_ready)
