@@ -378,6 +378,9 @@ class FCOS(nn.Module):
             plan.bind_image(img)
             if self._prefix_stream is None:
                 prio = int(os.environ.get('DSL_PREFIX_PRIO', '0'))        # -1: high-priority queue (experiment)
+                # streams share four hardware queues in creation order: DSL_PREFIX_SKIP = n takes n streams from torch's pool first,
+                # which moves the prefix stream to another hardware queue (experiment)
+                self._skipped_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get('DSL_PREFIX_SKIP', '0')))]
                 self._prefix_stream = torch.cuda.Stream(priority=prio) if prio else torch.cuda.Stream()
             if img.is_cuda:
                 img.record_stream(self._prefix_stream)

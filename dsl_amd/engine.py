@@ -387,6 +387,7 @@ class Plan:
         # half-size launches: one chain's fixed per-launch costs hide under the other chain's kernels.
         SPLIT = os.environ.get('DSL_IMG_SPLIT', '3') if (self.BR and N >= 2 and not PAIR_FWD and self.training) else ''
         split_open = False
+        DS_INLINE = os.environ.get('DSL_PREFIX_DS_INLINE', '0') != '0'      # measured: 421.5 (inline) vs 425.7 img/s
 
         def br_ws(d_):
             d_.workspace, d_.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
@@ -431,12 +432,18 @@ class Plan:
                                             stage=li, b=b, planes=planes))
                     x, h, w = out, oh, ow
                     continue
+                # DSL_PREFIX_DS_INLINE=1 keeps layer1's downsample conv on the list's own stream: layer1 belongs to the pipelined frozen
+                # prefix, and side stream 3 is in order behind everything the PREVIOUS backward pass queued on it - a prefix that
+                # forks onto it ends with that pass however early it starts (tools/prefix_probe.py).  Measured: inline, the prefix
+                # is through 0.26 ms before the previous step is, and the step is 1 % SLOWER - the forward pass cannot start before
+                # the caller's stream has joined the weight gradients and SGD anyway, and the fork hides 40 us
+                use_br = self.BR if not (li == 0 and DS_INLINE) else 0
                 if b == 0:
                     dd = self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)])
-                    if self.BR:
+                    if use_br:
                         dd.workspace, dd.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
                         f.fork(self.BR)
-                    f.conv(dd, side=self.BR)
+                    f.conv(dd, side=use_br)
                 if li == 1 and b == 0:
                     self._pp['ds'] = [(dd, 0)]
                 if not pair_done:       # (else: computed by the previous block's pair launch)
@@ -445,7 +452,7 @@ class Plan:
                         self._pp['c1'] = [(d1, 0)]
                     f.conv(d1)
                 f.conv(self._conv(c2, a1, a2, N, [(oh, ow)], [(oh, ow)], relu=True))
-                if b == 0 and self.BR:
+                if b == 0 and use_br:
                     f.join(self.BR)
                 pair_done = False
                 if PAIR_FWD and b + 1 < nb and planes in (128, 256) and str(li + 1) in PAIR_FWD:
