@@ -381,7 +381,10 @@ class Plan:
         self._pp = {}           # descriptors that touch layer1's output (pipelined prefix: two buffers, patched per step)
         PAIR_FWD = os.environ.get('DSL_PAIR_FWD', '')      # stages (layer numbers) whose conv3 -> next conv1 pairs run fused, e.g. '23'
         pair_done = False
-        # Image-split stages (DSL_IMG_SPLIT, default layer3; measured: none 372.6, 3: 384.0, 34: 383.4, 4: 372.1, 23: -0.5 % vs 3): their launches are 66-132 workgroups of 15-40 us - mostly
+        # Image-split stages (DSL_IMG_SPLIT; measured in round 3's first half: none 372.6, 3: 384.0, 34: 383.4, 4: 372.1, 23: -0.5 % vs 3; re-measured on
+        # the final kernels, two boxes, both orders (profiles/r03_step_boundary.txt): 3: 416.8 / 432.1, 34: 420.3 / 435.1, 23: 420.0, 24: 420.9 (second
+        # box), 234: 420.9 / 436.2 img/s, + 1 % - not yet the default: the committed
+        # profiles / traffic counters describe the layer3 split): their launches are 66-132 workgroups of 15-40 us - mostly
         # fill, epilogue and kernel boundary on half a chip.  The images of a batch are independent through the backbone, so the
         # batch goes through these stages as TWO chains (images [0, ceil(N/2)) on the caller's stream, the rest on stream 3) of
         # half-size launches: one chain's fixed per-launch costs hide under the other chain's kernels.
