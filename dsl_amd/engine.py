@@ -383,12 +383,12 @@ class Plan:
         pair_done = False
         # Image-split stages (DSL_IMG_SPLIT; measured in round 3's first half: none 372.6, 3: 384.0, 34: 383.4, 4: 372.1, 23: -0.5 % vs 3; re-measured on
         # the final kernels, two boxes, both orders (profiles/r03_step_boundary.txt): 3: 416.8 / 432.1, 34: 420.3 / 435.1, 23: 420.0, 24: 420.9 (second
-        # box), 234: 420.9 / 436.2 img/s, + 1 % - not yet the default: the committed
-        # profiles / traffic counters describe the layer3 split): their launches are 66-132 workgroups of 15-40 us - mostly
+        # box), 234: 420.9 / 436.2 img/s -> default layer2 + layer3 + layer4, + 1 %;
+        # profiles/r03b_* are the profiles of this setting, r03_* those of the layer3 split): their launches are 66-132 workgroups of 15-40 us - mostly
         # fill, epilogue and kernel boundary on half a chip.  The images of a batch are independent through the backbone, so the
         # batch goes through these stages as TWO chains (images [0, ceil(N/2)) on the caller's stream, the rest on stream 3) of
         # half-size launches: one chain's fixed per-launch costs hide under the other chain's kernels.
-        SPLIT = os.environ.get('DSL_IMG_SPLIT', '3') if (self.BR and N >= 2 and not PAIR_FWD and self.training) else ''
+        SPLIT = os.environ.get('DSL_IMG_SPLIT', '234') if (self.BR and N >= 2 and not PAIR_FWD and self.training) else ''
         split_open = False
         DS_INLINE = os.environ.get('DSL_PREFIX_DS_INLINE', '0') != '0'      # measured: 421.5 (inline) vs 425.7 img/s
 
