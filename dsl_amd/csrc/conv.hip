@@ -11,6 +11,7 @@
 // -> the epilogue does per-pixel index math once per lane and 8/16-byte channel-contiguous
 // stores into NHWC.
 #include <stdlib.h>
+#include <algorithm>
 
 #include <mutex>
 #include <type_traits>
@@ -2933,6 +2934,29 @@ __global__ __launch_bounds__(64 * WCO * WCI) void wgrad_pipe_multi_persist_kerne
   }
 }
 
+// scheduled form (round 4, wgrad_plan_*): the host assigns every valid virtual block to a workgroup (longest-processing-time
+// first inside the block's XCD class), sched[r * gridDim.x + b] = the r-th block of workgroup b or -1; what a workgroup computes
+// for a block, and hence every result, is the same as in the stride form
+template <int BCO, int BCI, int WCO, int WCI, int KS, int NST>
+__global__ __launch_bounds__(64 * WCO * WCI) void wgrad_pipe_multi_sched_kernel(const WgMultiHdr h, const WgK* __restrict__ tab,
+                                                                               const short* __restrict__ sched, int rounds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  for (int r = 0; r < rounds; ++r) {
+    const int vb = __builtin_amdgcn_readfirstlane((int)sched[r * (int)gridDim.x + (int)blockIdx.x]);
+    if (vb < 0) break;
+    int sub = 0, start = 0;
+#pragma unroll
+    for (int s = 1; s < kMaxMulti; ++s) {
+      const bool in = s < h.nsub && vb >= h.wg_end[s - 1];
+      sub = in ? s : sub;
+      start = in ? h.wg_end[s - 1] : start;
+    }
+    const WgK p = tab[sub];
+    wgrad_pipe_body<BCO, BCI, WCO, WCI, KS, NST>(p, vb - start, smem);
+    __syncthreads();
+  }
+}
+
 // the reduce passes of a multi launch: entry e (one member of one sub-launch with more than one split) owns the blocks
 // [blk_start, blk_start + nblk)
 struct RedEnt {
@@ -3784,7 +3808,7 @@ static int wgrad_launch(const dsl_wgrad_desc* descs, int count, void* stream) {
 // multi launch: the weight gradients of several geometries (one tile configuration) as ONE grid + ONE reduce grid
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int kMaxRed = 128, kMaxColsum = 64;
+constexpr int kMaxRed = 128, kMaxColsum = 64, kSchedMax = 8192;
 struct ColsumItem { const void* x; float* out; long long rows; int c, ld, clear; };
 struct WgMultiTable {
   int magic, cfg, nsub, total_blocks;
@@ -3794,6 +3818,10 @@ struct WgMultiTable {
   ColsumItem colsum[kMaxColsum];
   WgK k[kMaxMulti];
   RedEnt red[kMaxRed];
+  // scheduled persistent launch (wgrad_plan): sched_grid workgroups, sched_rounds blocks each at most; 0 rounds = stride form
+  int sched_grid, sched_rounds;
+  int plan_makespan, plan_items;      // (stages incl. the per-item overhead; valid blocks) - what dsl_wgrad_multi_info reports
+  short sched[kSchedMax];
 };
 constexpr int kMultiMagic = 0x574d5431;
 
@@ -3856,8 +3884,177 @@ int wgrad_slots() {
   return slots;
 }
 
+// ---- launch planner of the multi launches (round 4) ----------------------------------------------------------------------
+// A multi launch is a list of work items (one output tile x one K split) of very different lengths - the FPN's run from 3 to
+// 525 64-pixel K tiles - on a persistent grid of <= `cap` workgroups.  Round 3 chose the split factors from one target length
+// (total / slots, rounded per sub-launch) and let workgroup b walk the items b, b + G, b + 2G ...: the predictors came out as
+// 144 equal items on 128 workgroups (two rounds for 16 of them: 2 x the ideal time), the FPN as 173 items whose second round
+// paired the longest with the middle ones (91 units against an ideal 64), layer3 as 2 x 108 half-length items + a reduce pass
+// where 108 whole ones fit one round without any partial tile.  The planner simulates what the grid will do: for every
+// candidate vector of split factors it assigns the items to workgroups (longest first, each to the least loaded workgroup of
+// the item's XCD class, so a block keeps the L2 its neighbours use), takes the longest workgroup's sum (+ a fixed cost per
+// item: ring fill and the tile's stores) and adds the reduce pass the split partials would need; the cheapest vector wins and
+// its assignment becomes the launch's schedule table.  Results do not depend on the schedule: an item computes the same tile
+// from the same stages whoever runs it, and the reduce pass folds the splits in split order.
+struct PlanSub { int stages, tiles, max_sp; long long tile_elems; };      // K stages of the kernel's unit, output tiles (all members), elements per tile set
+int wgrad_plan_mode() {
+  static const int v = [] { const char* e = getenv("DSL_WGRAD_PLAN"); return e ? atoi(e) : 1; }();
+  return v;
+}
+inline int plan_norm_splits(int stages, int sp) {      // no empty split: sp -> ceil(stages / ceil(stages / sp))
+  if (sp < 1) sp = 1;
+  const int tps = (stages + sp - 1) / sp;
+  return (stages + tps - 1) / tps;
+}
+// LPT assignment of the valid blocks of the launch (sub-launches in table order) to G workgroups.  Returns the makespan in
+// stages (incl. `ovh` per item); sched (may be null) gets G * rounds entries.
+long long plan_simulate(const PlanSub* subs, const int* splits, int nsub, int G, int ovh, short* sched, int sched_cap, int* rounds_out,
+                        int* items_out) {
+  struct It { int cost, vb; };
+  std::vector<It> cls[8];
+  int base = 0, items = 0;
+  for (int i = 0; i < nsub; ++i) {
+    const int witems = subs[i].tiles * splits[i];
+    const int chunk = (witems + 7) / 8;
+    const int tps = (subs[i].stages + splits[i] - 1) / splits[i];
+    for (int bid = 0; bid < chunk * 8; ++bid) {
+      const int xcd = bid & 7, jj = bid >> 3, w = xcd * chunk + jj;
+      if (jj >= chunk || w >= witems) continue;
+      const int sp = w / subs[i].tiles;
+      const int k0 = sp * tps, k1 = std::min(k0 + tps, subs[i].stages);
+      if (k1 <= k0) continue;
+      cls[xcd].push_back({ovh + (k1 - k0), base + bid});
+      ++items;
+    }
+    base += chunk * 8;
+  }
+  const int per = G / 8;
+  long long makespan = 0;
+  int rounds = 0;
+  std::vector<long long> load(G, 0);
+  std::vector<std::vector<int>> mine(G);
+  for (int x = 0; x < 8; ++x) {
+    std::stable_sort(cls[x].begin(), cls[x].end(), [](const It& a, const It& b) { return a.cost > b.cost; });
+    for (const It& it : cls[x]) {
+      int best = x;
+      for (int j = 1; j < per; ++j)
+        if (load[x + 8 * j] < load[best]) best = x + 8 * j;
+      load[best] += it.cost;
+      mine[best].push_back(it.vb);
+    }
+  }
+  for (int b = 0; b < G; ++b) {
+    makespan = std::max(makespan, load[b]);
+    rounds = std::max(rounds, (int)mine[b].size());
+  }
+  if (sched) {
+    if ((long long)rounds * G > sched_cap) { rounds = 0; }      // does not fit the table: the caller falls back to the stride form
+    else {
+      for (int i = 0; i < rounds * G; ++i) sched[i] = -1;
+      for (int b = 0; b < G; ++b)
+        for (size_t r = 0; r < mine[b].size(); ++r) sched[r * G + b] = (short)mine[b][r];
+    }
+  }
+  if (rounds_out) *rounds_out = rounds;
+  if (items_out) *items_out = items;
+  return makespan;
+}
+// microseconds per stage / fixed stages per item of a tile configuration (fits of round 3's traces: the towers' direct tiles run
+// 1 400 32-pixel stages in 868 us alone; the predictors' 128 x 256 items 198 stages in ~85 us)
+inline double plan_stage_us(int cfg) { return cfg == 1 ? 0.62 : 0.43; }
+inline int plan_ovh(int cfg) { return cfg == 1 ? 8 : 8; }
+struct PlanOut { int splits[kMaxMulti]; int grid, makespan, items; double us; };
+void wgrad_plan(const PlanSub* subs, int nsub, int cfg, int cap, PlanOut* out) {
+  const int ovh = plan_ovh(cfg);
+  long long total = 0;
+  int smax = 1;
+  for (int i = 0; i < nsub; ++i) { total += (long long)subs[i].stages * subs[i].tiles; smax = std::max(smax, subs[i].stages); }
+  // candidate target lengths: every value ceil(stages_i / j) that changes some sub-launch's split factor, within a window around
+  // the balanced length, plus "no split at all"
+  const long long bal = std::max<long long>(8, (total + cap - 1) / cap);
+  std::vector<int> cand;
+  cand.push_back(smax);
+  for (int i = 0; i < nsub; ++i)
+    for (int j = 1; j <= subs[i].max_sp; ++j) {
+      const int l = (subs[i].stages + j - 1) / j;
+      if (l >= bal / 3 && l <= bal * 4) cand.push_back(l);
+    }
+  std::sort(cand.begin(), cand.end());
+  cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+  double best = 1e30;
+  std::vector<std::vector<int>> seen;
+  for (int l : cand) {
+    std::vector<int> sp(nsub);
+    long long items = 0;
+    for (int i = 0; i < nsub; ++i) {
+      int v = (subs[i].stages + l - 1) / l;
+      if (v > subs[i].max_sp) v = subs[i].max_sp;
+      sp[i] = plan_norm_splits(subs[i].stages, v);
+      items += (long long)sp[i] * subs[i].tiles;
+    }
+    if (std::find(seen.begin(), seen.end(), sp) != seen.end()) continue;
+    seen.push_back(sp);
+    // the smallest grid that reaches the best makespan (an XCD class may hold more items than items / 8)
+    int G = (int)std::min<long long>(cap, (items + 7) / 8 * 8);
+    if (G < 8) G = 8;
+    int n_items = 0;
+    long long ms = plan_simulate(subs, sp.data(), nsub, cap, ovh, nullptr, 0, nullptr, &n_items);
+    {
+      int g = G;
+      for (; g < cap; g += 8)
+        if (plan_simulate(subs, sp.data(), nsub, g, ovh, nullptr, 0, nullptr, nullptr) <= ms) break;
+      G = g;
+    }
+    double red_bytes = 0;
+    for (int i = 0; i < nsub; ++i)
+      if (sp[i] > 1) red_bytes += (double)(sp[i] + 1) * subs[i].tile_elems * 4.0;      // partials written, read back, dW written
+    const double us = ms * plan_stage_us(cfg) + (red_bytes > 0 ? 6.0 + red_bytes / 3.0e6 : 0.0);
+    if (us < best) {
+      best = us;
+      for (int i = 0; i < nsub; ++i) out->splits[i] = sp[i];
+      out->grid = G; out->makespan = (int)ms; out->items = n_items; out->us = us;
+    }
+  }
+}
+long long wgrad_px(const dsl_wgrad_desc* d) {
+  long long px = 0;
+  for (int s = 0; s < d->nseg; ++s) px += (long long)d->n * d->gh[s] * d->gw[s];
+  return px;
+}
+bool wgrad_multi_v3(const dsl_wgrad_desc* descs, const int* counts, int nsub, int cfg) {
+  bool v3 = true;
+  int off = 0;
+  for (int s = 0; s < nsub; ++s) { v3 = v3 && wgrad_v3_ok(&descs[off], cfg); off += counts[s]; }
+  return v3;
+}
+// the planner's view of a launch's sub-launches (in the caller's order)
+void wgrad_plan_subs(const dsl_wgrad_desc* descs, const int* counts, int nsub, int ks, PlanSub* subs) {
+  int off = 0;
+  for (int s = 0; s < nsub; ++s) {
+    int ktiles, tiles, bco;
+    wgrad_geometry(&descs[off], &ktiles, &tiles, &bco);
+    const long long px = wgrad_px(&descs[off]);
+    subs[s].stages = (int)((px + ks - 1) / ks);
+    subs[s].tiles = tiles * counts[s];
+    subs[s].max_sp = std::max(1, subs[s].stages / (256 / ks));          // at least 256 pixels of K per split (round 3's rule)
+    subs[s].tile_elems = (long long)counts[s] * (long long)wgrad_cy_pad(&descs[off]) * ((long long)descs[off].kh * descs[off].kw * descs[off].cs);
+    off += counts[s];
+  }
+}
+
 // split factors of a multi launch: every workgroup gets at most ~1/slots of the launch's K-tile iterations
 int wgrad_multi_splits(const dsl_wgrad_desc* descs, const int* counts, int nsub, int* splits) {
+  {
+    const int cfg0 = wgrad_pick(descs);
+    if (wgrad_plan_mode() && cfg0 >= 1 && cfg0 <= 3 && wgrad_persist() && wgrad_multi_v3(descs, counts, nsub, cfg0)) {
+      PlanSub subs[kMaxMulti];
+      wgrad_plan_subs(descs, counts, nsub, kWgV3KS, subs);
+      PlanOut po;
+      wgrad_plan(subs, nsub, cfg0, (wgrad_slots() + 7) / 8 * 8, &po);
+      for (int s = 0; s < nsub; ++s) splits[s] = po.splits[s];
+      return 0;
+    }
+  }
   long long total = 0;
   int off = 0;
   for (int s = 0; s < nsub; ++s) {
@@ -4000,6 +4197,91 @@ extern "C" int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* cou
   t->hdr.nsub = nsub;
   t->total_blocks = blocks;
   t->red_blocks = red_blocks;
+  if (wgrad_plan_mode() && t->v3 && t->cfg <= 3 && wgrad_persist()) {
+    // the schedule of the persistent grid, for the sub-launches in TABLE order (that is the block numbering the kernel sees)
+    PlanSub subs[kMaxMulti], tsubs[kMaxMulti];
+    int tsplits[kMaxMulti];
+    wgrad_plan_subs(descs, counts, nsub, kWgV3KS, subs);
+    long long items = 0;
+    for (int i = 0; i < nsub; ++i) { tsubs[i] = subs[order[i]]; tsplits[i] = splits[order[i]]; items += (long long)tsplits[i] * tsubs[i].tiles; }
+    const int cap_ = (wgrad_slots() + 7) / 8 * 8;
+    int G = (int)std::min<long long>(cap_, (items + 7) / 8 * 8);
+    if (G < 8) G = 8;
+    {
+      const long long ms_cap = plan_simulate(tsubs, tsplits, nsub, cap_, plan_ovh(t->cfg), nullptr, 0, nullptr, nullptr);
+      for (; G < cap_; G += 8)
+        if (plan_simulate(tsubs, tsplits, nsub, G, plan_ovh(t->cfg), nullptr, 0, nullptr, nullptr) <= ms_cap) break;
+    }
+    int rounds = 0, n_items = 0;
+    const long long ms = plan_simulate(tsubs, tsplits, nsub, G, plan_ovh(t->cfg), t->sched, kSchedMax, &rounds, &n_items);
+    if (blocks < 32767 && rounds > 0) { t->sched_grid = G; t->sched_rounds = rounds; }
+    t->plan_makespan = (int)ms; t->plan_items = n_items;
+  }
+  return 0;
+}
+
+// Planner probe (tests, tools; no device needed): sub-launch s has stages[s] K stages, tiles[s] output tiles (all members) and
+// tile_elems[s] elements per tile set; returns the chosen split factors and info = {grid, makespan, items, makespan of round
+// 3's rule under the stride walk, its items}
+extern "C" int dsl_wgrad_plan_probe(const int* stages, const int* tiles, const long long* tile_elems, int nsub, int cfg, int cap,
+                                    int* splits_out, int* info) {
+  DSL_CHECK(stages && tiles && nsub >= 1 && nsub <= kMaxMulti && cfg >= 1 && cfg <= 3 && cap >= 8 && cap % 8 == 0, "dsl_wgrad_plan_probe: bad arguments");
+  PlanSub subs[kMaxMulti];
+  for (int s = 0; s < nsub; ++s) {
+    subs[s].stages = stages[s]; subs[s].tiles = tiles[s]; subs[s].max_sp = std::max(1, stages[s] / 8);
+    subs[s].tile_elems = tile_elems ? tile_elems[s] : 0;
+  }
+  PlanOut po;
+  wgrad_plan(subs, nsub, cfg, cap, &po);
+  for (int s = 0; s < nsub; ++s) splits_out[s] = po.splits[s];
+  info[0] = po.grid; info[1] = po.makespan; info[2] = po.items;
+  {   // self-check of the schedule table the launch would use: every valid block exactly once, no holes in a workgroup's list
+    std::vector<short> sched(kSchedMax);
+    int rounds = 0, n_items = 0, total_blocks = 0;
+    plan_simulate(subs, po.splits, nsub, po.grid, plan_ovh(cfg), sched.data(), kSchedMax, &rounds, &n_items);
+    for (int s = 0; s < nsub; ++s) total_blocks += (subs[s].tiles * po.splits[s] + 7) / 8 * 8;
+    if (rounds > 0) {
+      std::vector<int> hit(total_blocks, 0);
+      int seen_items = 0;
+      for (int b = 0; b < po.grid; ++b) {
+        bool ended = false;
+        for (int r = 0; r < rounds; ++r) {
+          const int vb = sched[r * po.grid + b];
+          if (vb < 0) { ended = true; continue; }
+          DSL_CHECK(!ended && vb < total_blocks && (vb & 7) == (b & 7) && hit[vb]++ == 0, "dsl_wgrad_plan_probe: bad schedule entry (workgroup %d round %d block %d)", b, r, vb);
+          ++seen_items;
+        }
+      }
+      DSL_CHECK(seen_items == n_items && n_items == po.items, "dsl_wgrad_plan_probe: schedule holds %d of %d items", seen_items, n_items);
+    }
+  }
+  // round 3: one target length, stride walk of the blocks in "longest per workgroup first" order
+  long long total = 0;
+  for (int s = 0; s < nsub; ++s) total += (long long)((stages[s] + 1) / 2) * tiles[s];
+  long long lmax = std::max<long long>(4, (total + cap - 1) / cap);
+  int osp[kMaxMulti], ord[kMaxMulti];
+  for (int s = 0; s < nsub; ++s) {
+    const int kt = (stages[s] + 1) / 2;
+    int sp = (int)((kt + lmax - 1) / lmax);
+    sp = std::max(1, std::min(sp, std::max(1, kt / 4)));
+    osp[s] = sp; ord[s] = s;
+  }
+  for (int i = 1; i < nsub; ++i)
+    for (int j = i; j > 0 && (stages[ord[j]] + osp[ord[j]] - 1) / osp[ord[j]] > (stages[ord[j - 1]] + osp[ord[j - 1]] - 1) / osp[ord[j - 1]]; --j) std::swap(ord[j], ord[j - 1]);
+  std::vector<long long> load(cap, 0);
+  int base = 0, oitems = 0;
+  for (int i = 0; i < nsub; ++i) {
+    const int s = ord[i], witems = tiles[s] * osp[s], chunk = (witems + 7) / 8, tps = (stages[s] + osp[s] - 1) / osp[s];
+    for (int bid = 0; bid < chunk * 8; ++bid) {
+      const int xcd = bid & 7, jj = bid >> 3, w = xcd * chunk + jj;
+      if (jj >= chunk || w >= witems) continue;
+      const int sp = w / tiles[s], k0 = sp * tps, k1 = std::min(k0 + tps, stages[s]);
+      if (k1 > k0) { load[(base + bid) % cap] += plan_ovh(cfg) + k1 - k0; ++oitems; }
+    }
+    base += chunk * 8;
+  }
+  info[3] = (int)*std::max_element(load.begin(), load.end());
+  info[4] = oitems;
   return 0;
 }
 
@@ -4036,7 +4318,27 @@ extern "C" int dsl_conv2d_wgrad_multi(const void* table_host, const void* table_
     hipLaunchKernelGGL((KERNEL<A, B, C_, D, KS_, S_>), grid, dim3(64 * C_ * D), lds2, st, t->hdr, ktab);              \
   } while (0)
   const int cap = (wgrad_slots() + 7) / 8 * 8;
-  if (t->v3 && wgrad_persist() && t->total_blocks > cap) {
+  if (t->v3 && t->sched_rounds > 0) {
+    const short* sched = (const short*)((const unsigned char*)table_dev + offsetof(WgMultiTable, sched));
+    const dim3 sgrid(t->sched_grid);
+#define LAUNCHS(A, B, C_, D, KS_, S_)                                                                                \
+  do {                                                                                                               \
+    static bool a_ = false;                                                                                          \
+    if (!a_) {                                                                                                       \
+      hipFuncSetAttribute((const void*)wgrad_pipe_multi_sched_kernel<A, B, C_, D, KS_, S_>,                          \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                    \
+      a_ = true;                                                                                                     \
+    }                                                                                                                \
+    hipLaunchKernelGGL((wgrad_pipe_multi_sched_kernel<A, B, C_, D, KS_, S_>), sgrid, dim3(64 * C_ * D), lds2, st, t->hdr, ktab,   \
+                       sched, t->sched_rounds);                                                                      \
+  } while (0)
+    switch (t->cfg) {
+      case 1: LAUNCHS(256, 256, 2, 4, 32, 4); break;
+      case 2: LAUNCHS(256, 128, 4, 2, 32, 5); break;
+      default: LAUNCHS(128, 256, 2, 4, 32, 5); break;
+    }
+#undef LAUNCHS
+  } else if (t->v3 && wgrad_persist() && t->total_blocks > cap) {
     const dim3 pgrid(cap);
 #define LAUNCHP(A, B, C_, D, KS_, S_)                                                                                \
   do {                                                                                                               \

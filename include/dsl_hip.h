@@ -143,6 +143,14 @@ int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* counts, int ns
                           void* table_host, size_t table_bytes);
 int dsl_conv2d_wgrad_multi(const void* table_host, const void* table_dev, void* stream);
 int dsl_wgrad_multi_info(const void* table_host, double* flops, double* bytes, int* blocks, int* red_blocks, int* nsub);
+/* The launch planner behind dsl_wgrad_multi_build, callable without a device (tests, tools): sub-launch s has stages[s] K stages
+ * (32 pixels each), tiles[s] output tiles over all its members and tile_elems[s] fp32 elements per split (may be NULL);
+ * cfg = tile configuration 1..3, cap = workgroups of the persistent grid (a multiple of 8).  The planner picks the split
+ * factors by simulating the grid: items go longest first to the least loaded workgroup of their XCD class, cost = the longest
+ * workgroup's stages (+ a fixed cost per item) + the reduce pass the partial tiles need.  splits_out[nsub]; info[5] =
+ * {grid, makespan in stages, work items, makespan of round 3's rule (one target length, stride walk), its work items}. */
+int dsl_wgrad_plan_probe(const int* stages, const int* tiles, const long long* tile_elems, int nsub, int cfg, int cap,
+                         int* splits_out, int* info);
 
 /* fp8 forward path (BASELINE.json configs[4], first slice; the reference trains in fp32 and has no such path).
  * dsl_quant_fp8: y[r][c] = e4m3(clamp(x[r][c] * scale, +-448)) for a bf16 [rows][ld_x] tensor -> fp8 [rows][c] (c % 16 == 0).
