@@ -79,12 +79,12 @@ def fp8_step_timing(batch, steps=20, warm=5):
     from dsl_amd.optim import FlatSGD
     from dsl_amd.registry import build_detector
     model = build_detector(model_cfg(fp8=True)).cuda()
-    model.lazy_log = True
-    model.eager_backward = True
     opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
-    mark_ready(batch['img'])
+    ev = torch.cuda.Event()
+    ev.record()                       # the batch is resident: its producer's event, handed over with every batch (mark_ready is one-shot)
 
     def step():
+        mark_ready(batch['img'], event=ev)
         out = model.train_step(batch, opt)
         out['loss'].backward()
         opt.step()
@@ -103,6 +103,65 @@ def fp8_step_timing(batch, steps=20, warm=5):
     return dict(imgs_per_s=round(len(batch['img_metas']) / dt, 1), ms_per_step=round(dt * 1e3, 3), final_losses=losses,
                 note='same step, batch and optimizer as the headline; forward of the 8 tower convolutions in OCP e4m3 on '
                      'v_mfma_scale_f32_32x32x64_f8f6f4, everything else (and the whole backward pass) bf16; off by default in the product')
+
+
+class _ResidentLoader:
+    """A loader (dsl_amd/data.py contract: __iter__ / __len__ yielding batch dicts) that yields ONE HBM-resident batch n times and
+    stamps the wall clock (device drained) in front of batch `warm` and behind the last one."""
+
+    def __init__(self, batch, n, warm):
+        self.batch, self.n, self.warm, self.t0, self.t1 = batch, n, warm, None, None
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        from dsl_amd.data import mark_ready
+        ev = torch.cuda.Event()
+        ev.record()                            # the batch is resident in HBM: written (at the latest) by what is queued up to here
+        for i in range(self.n):
+            if i == self.warm:
+                torch.cuda.synchronize()
+                self.t0 = time.perf_counter()
+            mark_ready(self.batch['img'], event=ev)      # the producer's event with every batch (dsl_amd.data.mark_ready is one-shot)
+            yield self.batch
+        torch.cuda.synchronize()
+        self.t1 = time.perf_counter()
+
+
+def train_detector_timing(batch, steps=20, warm=5):
+    """The headline's step through the PRODUCT entry point: dsl_amd.apis.train_detector on the training sections of
+    configs/fcos_semi/r50_caffe_mslonger_tricks_0.Xdata.py (restated here - the GPU box has no reference tree; tests/test_boundary_cpu.py
+    builds the real file): SGD lr 0.01 momentum 0.9 wd 1e-4 bias_lr_mult 2 / bias_decay_mult 0, grad_clip None, step lr policy with
+    linear warm-up, EpochBasedRunner, TextLoggerHook every 10 iterations (its host read of the log vars included), checkpoint hook
+    (interval beyond the run).  Same model, batch and optimizer settings as the timed region of main()."""
+    from dsl_amd import detectors  # noqa: F401
+    from dsl_amd.apis import train_detector
+    from dsl_amd.registry import Config, build_detector
+    import tempfile
+    model = build_detector(model_cfg())
+    loader = _ResidentLoader(batch, warm + steps, warm)
+    with tempfile.TemporaryDirectory() as wd:
+        cfg = Config(dict(
+            model=model_cfg(), data=dict(samples_per_gpu=len(batch['img_metas']), workers_per_gpu=2),
+            optimizer=dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=0.0001, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.)),
+            optimizer_config=dict(grad_clip=None),
+            lr_config=dict(policy='step', warmup='linear', warmup_iters=500, warmup_ratio=1.0 / 3, step=[50, 80]),
+            runner=dict(type='EpochBasedRunner', max_epochs=1), checkpoint_config=dict(interval=1000),
+            log_config=dict(interval=10, hooks=[dict(type='TextLoggerHook')]), custom_hooks=[dict(type='NumClassCheckHook')],
+            log_level='ERROR', load_from=None, resume_from=None, workflow=[('train', 1)], work_dir=wd))
+        runner = train_detector(model, [loader], cfg, distributed=False, validate=False)
+    dt = (loader.t1 - loader.t0) / steps
+    det = runner._det(runner.model)
+    out = dict(imgs_per_s=round(len(batch['img_metas']) / dt, 1), ms_per_step=round(dt * 1e3, 3),
+               detector_flags=dict(lazy_log=det.lazy_log, eager_backward=det.eager_backward, pipeline_prefix=det.pipeline_prefix,
+                                   deferred_head_update=bool(getattr(det.store, 'defer_head', False))),
+               hooks=[type(h).__name__ for h in runner._hooks],
+               note='dsl_amd.apis.train_detector + EpochBasedRunner + the config\'s hooks on the same resident batch; the lr schedule is '
+                    'in its warm-up, every 10th iteration the logger reads the log vars back')
+    del runner, model
+    torch.cuda.empty_cache()
+    return out
 
 
 def datapath_timing(n_img=2, reps=20):
@@ -206,8 +265,6 @@ def dsl_iteration_timing(steps=12, warm=6, variants=None):
                 student.init_weights()
                 teacher.init_weights()
                 teacher.load_state_dict(student.state_dict())
-        student.lazy_log = True
-        student.eager_backward = True
         opt = FlatSGD(student, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
                       grad_clip=dict(max_norm=35, norm_type=2))
         bank = PseudoLabelBank(num_classes=80, thres='adathres.json')
@@ -290,8 +347,9 @@ def main():
     from dsl_amd.registry import build_detector
 
     model = build_detector(model_cfg()).cuda()      # random init, reference style, same seed on every rank
-    model.lazy_log = True
-    model.eager_backward = True      # backward kernels are queued right behind the loss kernel (see FCOS.eager_backward)
+    # (no attribute is set here that dsl_amd.apis.train_detector does not set: lazy log vars, the eager backward and the pipelined
+    # frozen prefix are the detector's defaults - the headline is the product path; extra.train_detector times the same step
+    # through train_detector + the runner's hooks)
     if os.environ.get('DSL_BENCH_PIPE', '1') == '0':      # A/B knob; the product default (on) is what the headline uses
         model.pipeline_prefix = False
     if world > 1:
@@ -300,9 +358,14 @@ def main():
     opt = FlatSGD(det, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
     batch = synth_batch(rank, args.imgs_per_gpu)
     from dsl_amd.data import mark_ready
-    mark_ready(batch['img'])         # inputs are resident in HBM before the timed region: the producer's event is this one
+    ready = torch.cuda.Event()
+    ready.record()          # inputs are resident in HBM before the timed region: this is their producer's event; a loader hands it over
+                            # with every batch (mark_ready is one-shot per batch).  (No stream of its own for the "loader": a new stream
+                            # takes one of the four hardware queues and re-shuffles which of the step's streams share one - measured,
+                            # profiles/r04_streams.txt: 350 instead of 425 img/s.)
 
     def step():
+        mark_ready(batch['img'], event=ready)
         out = model.train_step(batch, opt)
         out['loss'].backward()
         opt.step()
@@ -394,9 +457,17 @@ def main():
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
             gbs = by[0] / (ms[0] * 1e-3) / 1e9
             intensity = fl[0] / by[0]
-            # the roof that binds this class: below the ridge of 2500 TFLOP/s / 8 TB/s = 312 FLOP per algorithmic byte it is HBM
-            hbm = intensity < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-            roof = dict(bound='hbm' if hbm else 'mfma', kernel=DOMINANT + ' (forward + data-gradient implicit GEMM, 8-wave 128x128 '
+            # Which roof?  By arithmetic intensity the class sits below the ridge (2500 TFLOP/s / 8 TB/s = 312 FLOP per algorithmic
+            # byte), i.e. HBM would bind it - but a class that reaches < 25 % of BOTH roofs is bound by neither: its launches are
+            # 66-132 workgroups of 4-36 K tiles, i.e. launch, pipeline fill, epilogue and kernel boundary.  The
+            # review's convention ("MFMA for convs"): the MFMA view is the primary `frac` of a convolution class,
+            # `bound` says "latency" in that case, and the HBM view stays beside it.
+            hbm_roof = intensity < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            latency = ach / PEAK_BF16_TFLOPS < 0.25 and gbs / PEAK_HBM_GBS < 0.25
+            hbm = False
+            roof = dict(bound='latency' if latency else ('hbm' if hbm_roof else 'mfma'),
+                        roof_by_arithmetic_intensity='hbm' if hbm_roof else 'mfma',
+                        kernel=DOMINANT + ' (forward + data-gradient implicit GEMM, 8-wave 128x128 '
                         'tile: the backbone / predictor convolutions; largest share of the step)',
                         achieved=round(gbs if hbm else ach, 1), peak=PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS,
                         unit='GB/s' if hbm else 'TFLOP/s', frac=round(gbs / PEAK_HBM_GBS if hbm else ach / PEAK_BF16_TFLOPS, 4),
@@ -433,13 +504,33 @@ def main():
         det.comm_trace = None
         bk = [dict(mb=round(b['mb'], 1), start_ms=round(tr['t0'].elapsed_time(b['start']), 3),
                    done_ms=round(tr['t0'].elapsed_time(b['done']), 3) if b['done'] is not None else None) for b in tr['buckets']]
+        # attribution: the same steps with every collective skipped (gradients then wrong - timing only, after everything that is reported)
+        devs = [None] * world
+        dist.all_gather_object(devs, dict(rank=rank, device=torch.cuda.current_device(), name=torch.cuda.get_device_name()))
+        det.comm_off = True
+        for _ in range(2):
+            step()
+        dt_off, _ = timed(max(5, args.steps // 2))
+        det.comm_off = False
+        t_off = torch.tensor([dt_off], device='cuda')
+        dist.all_reduce(t_off, op=dist.ReduceOp.MAX)
+        order = 'layer4, layer3, layer2, head+FPN (deferred: under the next forward pass)' if getattr(det.store, 'defer_head', False) \
+            else 'head+FPN, layer4, layer3, layer2'
         extra = dict(comm=dict(carrier='C-ABI rcclComm_t (dsl_allreduce_bucket)' if det.rccl is not None else 'torch.distributed process group',
+                               backend=dist.get_backend(), rccl_ranks=int(L.lib.dsl_comm_size(det.rccl.comm)) if det.rccl is not None else dist.get_world_size(),
+                               devices=devs, grad_dtype='bf16' if det.grad_bf16 else 'fp32',
+                               wgrad_slots=int(os.environ.get('DSL_WGRAD_SLOTS', '128')),
                                buckets=bk, step_ms=round(tr['t0'].elapsed_time(ev_end), 3),
-                               note='rank 0; bucket order head+FPN, layer4, layer3, layer2; the optimizer updates a bucket as soon as '
-                                    'its all-reduce is done (per-bucket SGD), so only traffic still in flight at step_ms is exposed'))
+                               ms_per_step_comm_disabled=round(float(t_off) / max(5, args.steps // 2) * 1e3, 3),
+                               ms_per_step=round(dt / args.steps * 1e3, 3),
+                               note='rank 0; bucket order ' + order + '; the optimizer updates a bucket as soon as its all-reduce is done '
+                                    '(per-bucket SGD), so only traffic still in flight at step_ms is exposed; ms_per_step_comm_disabled = the '
+                                    'same loop with every collective skipped (max over ranks): the difference to ms_per_step is what '
+                                    'communication costs, the difference to the 1-GPU figure is what running beside other ranks costs'))
     if rank == 0 and world == 1 and not args.no_dsl:
         del opt
-        extra = dict(dsl_iteration=dsl_iteration_timing(), fp8_towers=fp8_step_timing(batch), datapath=datapath_timing())
+        extra = dict(train_detector=train_detector_timing(batch), dsl_iteration=dsl_iteration_timing(), fp8_towers=fp8_step_timing(batch),
+                     datapath=datapath_timing())
         if roof is not None:        # BASELINE.json configs[2] beside the headline, also where a record that keeps `roofline` keeps it
             roof['configs2_dsl_iteration_ms'] = {k: v for k, v in extra['dsl_iteration'].items() if k.startswith('ms_per_iter')}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

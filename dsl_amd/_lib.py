@@ -36,6 +36,8 @@ PROF_CLASSES = 8
 MAX_MULTI = 16
 SLOT_TAIL, SLOT_PREFIX = 13, 14     # pipelined frozen prefix: 'previous backward's data-gradient chain done', 'prefix of this step done'
 SLOT_PACKS = 15      # named event: the data-gradient weight packs of the last optimizer step are complete
+SUMSQ_PARTS = 256
+SLOT_HEADW = 12      # named event: the head + FPN bucket of the last optimizer step is updated (deferred head update)
 (RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST, RLA_REC_SUM) = range(2, 9)
 MAX_GROUP = 8
 
@@ -200,8 +202,10 @@ _SIGS = {
     'dsl_comm_destroy': [_vp],
     'dsl_allreduce_bucket': [_vp, _vp, C.c_size_t, _vp],
     'dsl_allreduce_buckets': [_vp, _vp, _vp, _i, _vp],
+    'dsl_allreduce_bucket_bf16': [_vp, _vp, C.c_size_t, _vp],
+    'dsl_cast_f32': [_vp, _vp, _l, _vp], 'dsl_sumsq_partial': [_vp, _l, _vp, _vp], 'dsl_sumsq_fold': [_vp, _i, _vp, _vp],
     'dsl_pseudo_label_fuse_history': [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
-    'dsl_run_ops': [_vp, _i, _vp], 'dsl_stream_wait_slot': [_i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_prof_read2': [_vp, _vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
+    'dsl_run_ops': [_vp, _i, _vp], 'dsl_stream_wait_slot': [_i, _vp], 'dsl_stream_record_slot': [_i, _vp], 'dsl_side_stream': [_i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_prof_read2': [_vp, _vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
 }
 MISSING = []
 for _name, _args in _SIGS.items():

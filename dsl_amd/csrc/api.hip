@@ -196,6 +196,31 @@ extern "C" int dsl_stream_wait_slot(int slot, void* stream) {
   return 0;
 }
 
+// Record named event slot `slot` on `stream` (what a DSL_OP_RECORD inside an op list does, for a stream the library does not
+// own): the optimizer marks "the head + FPN bucket is updated" on its own stream, and the next forward list waits for exactly
+// that slot in front of the FPN (deferred head update).
+extern "C" int dsl_stream_record_slot(int slot, void* stream) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  DSL_CHECK(dev >= 0 && dev < 16 && slot >= 0 && slot < 16, "dsl_stream_record_slot: bad device %d / slot %d", dev, slot);
+  side_init(dev);
+  DSL_CHECK(hipEventRecord(g_named[dev][slot], (hipStream_t)stream) == hipSuccess, "dsl_stream_record_slot: hipEventRecord failed");
+  g_named_set[dev][slot] = true;
+  return 0;
+}
+
+// The library's side stream `id` (1..3) of the current device, for callers that have to queue their own work in order with it:
+// the optimizer puts the deferred bucket's update on side stream 1, right behind the weight gradients it waits for (a stream of
+// its own may share a hardware queue with another of the step's streams and then runs behind THAT stream's backlog).
+extern "C" int dsl_side_stream(int id, void** stream_out) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  DSL_CHECK(dev >= 0 && dev < 16 && id >= 1 && id <= kSide && stream_out, "dsl_side_stream: bad device %d / stream id %d", dev, id);
+  side_init(dev);
+  *stream_out = (void*)g_side[dev][id - 1];
+  return 0;
+}
+
 // ---- live kernel timing ----------------------------------------------------------------------------
 namespace {
 struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };

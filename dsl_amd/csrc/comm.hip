@@ -112,6 +112,14 @@ extern "C" int dsl_allreduce_bucket(void* comm, float* buf, size_t count, void* 
   return 0;
 }
 
+extern "C" int dsl_allreduce_bucket_bf16(void* comm, void* buf, size_t count, void* stream) {
+  DSL_CHECK(comm && (buf || count == 0), "dsl_allreduce_bucket_bf16: null pointer");
+  if (count == 0) return 0;
+  RCCL_OR_FAIL(r);
+  RCCL_CALL(r, "ncclAllReduce", r->all_reduce(buf, buf, count, ncclBfloat16, ncclSum, (ncclComm_t)comm, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int dsl_allreduce_buckets(void* comm, float* const* bufs, const size_t* counts, int n, void* stream) {
   DSL_CHECK(comm && bufs && counts && n >= 0, "dsl_allreduce_buckets: bad arguments");
   RCCL_OR_FAIL(r);

@@ -199,6 +199,37 @@ extern "C" int dsl_cast_bf16(const float* x, void* y, long n, void* stream) {
   return 0;
 }
 
+// bf16 -> fp32 (the way back of a bf16 gradient bucket, dsl_amd/parallel.py grad_dtype='bf16')
+__global__ void uncast_kernel(const uint16_t* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(x + 4 * i);
+    *reinterpret_cast<f32x4*>(y + 4 * i) = f32x4{bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1])};
+  }
+}
+extern "C" int dsl_cast_f32(const void* x_bf16, float* y, long n, void* stream) {
+  DSL_CHECK(x_bf16 && y && n % 4 == 0, "dsl_cast_f32: bad arguments");
+  hipLaunchKernelGGL(uncast_kernel, dim3(nblocks(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16, y, (long long)n);
+  DSL_LAUNCH_CHECK("uncast_kernel");
+  return 0;
+}
+
+// Gradient norm in pieces (data parallel with clipping): dsl_sumsq_partial writes DSL_SUMSQ_PARTS block sums of x[0 .. n) to
+// `partials` - one call per gradient bucket, on the stream that bucket's all-reduce completes on - and dsl_sumsq_fold adds
+// n_partials of them up in index order; only the fold and the optimizer step remain behind the last bucket.  Fixed order, no atomics.
+extern "C" int dsl_sumsq_partial(const float* x, long n, float* partials, void* stream) {
+  DSL_CHECK(x && partials && n >= 0, "dsl_sumsq_partial: bad arguments");
+  hipLaunchKernelGGL(sumsq_part_kernel, dim3(DSL_SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, x, (long long)n, partials);
+  DSL_LAUNCH_CHECK("sumsq_part_kernel");
+  return 0;
+}
+extern "C" int dsl_sumsq_fold(const float* partials, int n_partials, float* out, void* stream) {
+  DSL_CHECK(partials && out && n_partials > 0, "dsl_sumsq_fold: bad arguments");
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_partials, out);
+  DSL_LAUNCH_CHECK("sumsq_fold_kernel");
+  return 0;
+}
+
 extern "C" int dsl_pack_dgrad(const float* w, const float* scale, void* out, int cout, int cout_pad, int taps, int cin,
                               void* stream) {
   DSL_CHECK(w && out && cout > 0 && cout_pad >= cout && taps > 0 && cin > 0, "dsl_pack_dgrad: bad arguments");

@@ -21,15 +21,19 @@ import numpy as np
 import torch
 
 
-def mark_ready(img, stream=None):
+def mark_ready(img, stream=None, event=None):
     """Attaches the producer's event to a batch image tensor: recorded now on `stream` (default: the current stream).  A loader
     that renders batches on its own stream calls this after its last kernel; FCOS.forward_train then starts the frozen prefix of
     the forward pass (image layout, stem, layer1) behind THAT event instead of behind everything queued on the training
-    stream - i.e. under the tail of the previous step's backward pass (FCOS.pipeline_prefix)."""
+    stream - i.e. under the tail of the previous step's backward pass (FCOS.pipeline_prefix).
+    The mark is ONE-SHOT and belongs to this tensor object: forward_train consumes it (a buffer that is refilled in place needs a
+    new mark_ready per batch - without one the prefix is ordered behind the caller's stream, which is always correct), and a
+    view or copy of the tensor (.contiguous(), slicing, append_half_scale's cat) does not carry it."""
     if img.is_cuda:
-        ev = torch.cuda.Event()
-        ev.record(stream if stream is not None else torch.cuda.current_stream(img.device))
-        img._dsl_ready = ev
+        if event is None:
+            event = torch.cuda.Event()
+            event.record(stream if stream is not None else torch.cuda.current_stream(img.device))
+        img._dsl_ready = event          # `event`: one the producer recorded itself (a resident batch: once, when it was written)
     return img
 
 

@@ -218,7 +218,7 @@ class _TrainStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, det, plan):
-        ctx.det, ctx.plan, ctx.eager = det, plan, det.eager_backward
+        ctx.det, ctx.plan, ctx.eager = det, plan, bool(getattr(det, '_eager_now', False))      # were the backward lists queued already?
         ctx.n_losses = 4 if plan.lossplan.desc.soft_weight != 0.0 else 3
         return plan.lossplan.losses.clone()
 
@@ -269,13 +269,18 @@ class FCOS(nn.Module):
         self.dist_group = None        # set by the DDP wrapper
         self.world_size = 1
         self.CLASSES = None
-        self.lazy_log = False         # True: log_vars stay device tensors (no per-iteration host sync)
-        # True: queue the backward kernel lists directly behind the loss kernel instead of when `loss.backward()`
-        # reaches the autograd bridge (the gradient of the summed loss is 1 either way - the bridge ignores its
-        # incoming gradient - so only the launch order changes: the host-side loss parsing then overlaps the GPU's
-        # backward instead of sitting between forward and backward).  For loops that always call loss.backward()
-        # once per train_step, as mmcv's OptimizerHook does.
-        self.eager_backward = False
+        # Product defaults = what bench.py measures (round 4; both were opt-in and only bench.py set them):
+        # lazy_log True: train_step's log_vars stay 0-dim device tensors; the host reads them when it logs (TextLoggerHook: every
+        # `interval` iterations, float(v)) instead of once per iteration between the forward and the backward pass
+        # (detectors/base.py:175-208 calls .item() per key per iteration).  False: python floats, one host sync per iteration.
+        self.lazy_log = True
+        # eager_backward True: INSIDE train_step the backward kernel lists are queued right behind the loss kernel (and the few
+        # log-variable ops) instead of when `loss.backward()` reaches the autograd bridge.  The gradient of the summed loss is 1
+        # either way - the bridge ignores its incoming gradient - so only the launch order changes.  For loops that call
+        # loss.backward() once per train_step, as mmcv's OptimizerHook does (mmdet/apis/train.py:126-176); a caller that scales the
+        # loss tensor instead of FCOS.loss_scale must set this False (DSL_CHECK_BACKWARD_GRAD=1 checks the incoming gradient).
+        # A direct forward_train() call (no train_step around it) stays lazy unless eager_backward == 'always'.
+        self.eager_backward = True
         self._in_train_step, self._deferred_plan = False, None
         # The frozen prefix of the forward pass - image layout, stem, pool, layer1 - runs on its own stream; when the batch's image
         # tensor carries its producer's event (dsl_amd.data.mark_ready: resident inputs, a loader that renders on its own stream)
@@ -288,6 +293,12 @@ class FCOS(nn.Module):
         self._comm_stream = None
         self.rccl = None              # parallel.RcclComm: the exchanges go through the C-ABI's communicator instead of torch.distributed
         self.comm_trace = None        # set to [] (bench.py --gpus N): per step, per gradient bucket, timed events of its all-reduce
+        # data-parallel options (set by HipDistributedDataParallel)
+        self.grad_bf16 = False        # gradient buckets cross xGMI as bf16 copies (half the bytes); master gradient, norm, update stay fp32
+        self.comm_off = False         # DSL_COMM=none / bench.py's attribution probe: every collective skipped (timing only - WRONG gradients)
+        self.clip_partials = None     # [buckets * SUMSQ_PARTS] floats: FlatSGD with grad_clip asks for the norm in pieces, per bucket
+        self._partials_valid = False
+        self._g16 = None
 
     # ---- nn.Module surface redirected to the flat store ------------------------------------------
     def init_weights(self):
@@ -309,6 +320,7 @@ class FCOS(nn.Module):
         return self
 
     def state_dict(self, destination=None, prefix='', keep_vars=False):
+        self.store.wait_pending()
         out = OrderedDict() if destination is None else destination
         for k, v in self.store.named_views().items():
             out[prefix + k] = v
@@ -385,11 +397,25 @@ class FCOS(nn.Module):
             if img.is_cuda:
                 img.record_stream(self._prefix_stream)
             ready = getattr(img, '_dsl_ready', None)          # event of the image's producer (dsl_amd.data.mark_ready)
+            if ready is not None:
+                # one-shot: a loader that refills this tensor in place has to mark it again (a stale, long-fired event would let the
+                # prefix start before the new contents are written)
+                try:
+                    del img._dsl_ready
+                except AttributeError:
+                    pass
+            staged = plan._img_ref is None                     # bind_image copied the batch into plan.img on the CALLER's stream
             if getattr(self, '_prefix_plan', None) is not plan:
                 # first use of this plan (or the first step at all): SLOT_TAIL was never recorded, so nothing orders the prefix
                 # stream behind the caller's stream, which wrote the frozen packs (store.refresh) and possibly the image
                 self._prefix_stream.wait_stream(torch.cuda.current_stream())
                 self._prefix_plan = plan
+            elif staged:
+                # a CPU / non-fp32 / non-contiguous batch: the staging copy was queued on the caller's stream just now - whatever
+                # the producer's event says, the prefix must not read plan.img before that copy has landed (round-3 advisor)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._prefix_stream.wait_event(ev)
             elif ready is not None:
                 self._prefix_stream.wait_event(ready)
             elif img.is_cuda:
@@ -410,9 +436,10 @@ class FCOS(nn.Module):
             # (fcos_head.py:264-274) - then runs under the forward pass
             lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
             plan.assign_ops.run()
-            work = self._all_reduce_async(lp.stats[:2], after_current=True)
+            work = None if self.comm_off else self._all_reduce_async(lp.stats[:2], after_current=True)
             fwd.run()
-            work.wait()
+            if work is not None:
+                work.wait()
         else:
             # one process: target upload + assignment go behind the forward pass on the caller's stream, into the time it
             # would otherwise spend waiting for the regression tower on the side stream
@@ -420,11 +447,15 @@ class FCOS(nn.Module):
             lp.set_targets(gt_bboxes, gt_labels, gt_bboxes_ignore)
             plan.assign_ops.run()
         plan.loss_ops.run()
+        eager_now = False
         if self.eager_backward and torch.is_grad_enabled():
             if self._in_train_step:       # train_step queues it behind its log-variable ops (they only need the loss kernel)
                 self._deferred_plan = plan
-            else:
+                eager_now = True
+            elif self.eager_backward == 'always':
                 self._run_backward(plan)
+                eager_now = True
+        self._eager_now = eager_now
         out = _TrainStepFn.apply(self._anchor, self, plan)
         losses = _LossDict(loss_cls=out[0], loss_bbox=out[1], loss_centerness=out[2])
         if sw != 0.0:
@@ -456,34 +487,62 @@ class FCOS(nn.Module):
         hooks do at mmdet/apis/train.py:92-96); only the last, smallest bucket (layer2, 5 MB) is exposed."""
         self._pending = []
         self._last_bwd_infos = [info for _, info in plan.bwd_segments]      # bucket ranges / event slots, for the optimizer
-        ddp = self.world_size > 1
+        ddp = self.world_size > 1 and not self.comm_off
         on_gpu = self.store.grad.is_cuda
         if ddp and on_gpu and self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream()
+        self._partials_valid = False
+        nb = 0
         for ol, info in plan.bwd_segments:
             ol.run()
-            if not ddp:
+            if not ddp or info['bucket'] is None:       # (bucket None: the deferred head update - its bucket completes with a later list)
                 continue
             lo, hi = info['bucket']
             if not on_gpu:            # host tensors (the gloo unit test of the bucket order): nothing to order against
                 self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
                 continue
             from . import _lib as L
+            from .parallel import StreamWork
             cs = self._comm_stream
-            L.check(min(L.lib.dsl_stream_wait_slot(info['slot'], C_void(cs.cuda_stream)), 0), 'dsl_stream_wait_slot')
+            csp = C_void(cs.cuda_stream)
+            L.check(min(L.lib.dsl_stream_wait_slot(info['slot'], csp), 0), 'dsl_stream_wait_slot')
             if info['main']:
                 cs.wait_stream(torch.cuda.current_stream())
+            g = self.store.grad[lo:hi]
             with torch.cuda.stream(cs):
                 if self.comm_trace:
                     es = torch.cuda.Event(enable_timing=True)
                     es.record()            # the bucket's named event has fired and the previous bucket's traffic is queued
-                    self.comm_trace[-1]['buckets'].append(dict(mb=(hi - lo) * 4 / 1e6, start=es, done=None))
-                if self.rccl is not None:
-                    from .parallel import StreamWork
-                    self.rccl.all_reduce(self.store.grad[lo:hi], cs)
-                    self._pending.append(StreamWork(cs))
+                    self.comm_trace[-1]['buckets'].append(dict(mb=(hi - lo) * (2 if self.grad_bf16 else 4) / 1e6, start=es, done=None))
+                work = None
+                if self.grad_bf16:
+                    # the bucket crosses xGMI as a bf16 copy (RCCL's own ring then adds in bf16 per hop; the fp32 master gradient
+                    # gets the result back): cast -> all-reduce -> cast back, all on the communication stream
+                    if self._g16 is None or self._g16.device != g.device:
+                        self._g16 = torch.empty(self.store.grad.numel(), dtype=torch.bfloat16, device=g.device)
+                    g16 = self._g16[lo:hi]
+                    L.check(L.lib.dsl_cast_bf16(L.ptr(g), L.ptr(g16), hi - lo, csp), 'dsl_cast_bf16')
+                    if self.rccl is not None:
+                        L.check(L.lib.dsl_allreduce_bucket_bf16(self.rccl.comm, L.ptr(g16), hi - lo, csp), 'dsl_allreduce_bucket_bf16')
+                    else:
+                        dist.all_reduce(g16, group=self.dist_group, async_op=True).wait()      # (orders cs behind the collective)
+                    L.check(L.lib.dsl_cast_f32(L.ptr(g16), L.ptr(g), hi - lo, csp), 'dsl_cast_f32')
+                elif self.rccl is not None:
+                    self.rccl.all_reduce(g, cs)
                 else:
-                    self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
+                    work = dist.all_reduce(g, group=self.dist_group, async_op=True)
+                if self.clip_partials is not None:
+                    # the clipping norm of the REDUCED bucket, as soon as it has arrived: only the fold + the update stay behind the
+                    # last bucket (FlatSGD.step)
+                    if work is not None:
+                        work.wait()
+                        work = None
+                    L.check(L.lib.dsl_sumsq_partial(L.ptr(g), hi - lo, C_void(self.clip_partials.data_ptr() + nb * L.SUMSQ_PARTS * 4), csp),
+                            'dsl_sumsq_partial')
+                self._pending.append(work if work is not None else StreamWork(cs))
+            nb += 1
+        self._partials_valid = bool(ddp and on_gpu and self.clip_partials is not None and 0 < nb * 256 <= self.clip_partials.numel())
+        self._n_partials = nb * 256
         self._rebind_grads()
 
     def wait_grads(self):
@@ -505,6 +564,7 @@ class FCOS(nn.Module):
 
     def simple_test(self, img, img_metas, rescale=False):
         from .sweep import simple_test
+        self.store.wait_pending()          # a deferred head update of the last optimizer step (the training forward waits in its op list)
         return simple_test(self, img, img_metas, rescale)
 
     def _parse_losses(self, losses):
@@ -526,7 +586,7 @@ class FCOS(nn.Module):
         log_vars['loss'] = loss
         keys.append('loss')
         vec = torch.cat([stacked.detach(), loss.detach().reshape(1)])
-        if self.world_size > 1:      # ONE all-reduce for all log vars instead of one per key
+        if self.world_size > 1 and not self.comm_off:      # ONE all-reduce for all log vars instead of one per key
             if self.rccl is not None and vec.is_cuda:
                 self.rccl.all_reduce(vec)
             else:

@@ -167,6 +167,13 @@ class Plan:
         if store.dirty:
             store.refresh()
         self.store, self.N, self.H, self.W, self.training = store, N, H, W, training
+        # Deferred head update (set on the store by an optimizer that updates bucket by bucket, FlatSGD): the towers'
+        # weight-gradient group - 423 GFLOP, a third of the backward pass's weight-gradient work - leaves the backward pass and runs
+        # LAST on the weight-gradient stream, under the NEXT step's backbone forward (half of the chip idles there: two chains of
+        # 33-66-workgroup launches), followed by the head + FPN bucket's optimizer step; the forward list waits for that update where
+        # it first reads the bucket (SLOT_HEADW, in front of the FPN).  Same kernels, same arithmetic, same bits.
+        self.defer = bool(training and getattr(store, 'defer_head', False) and store.backbone != 'rla'
+                          and os.environ.get('DSL_SIDE', '1') != '0' and not single_stream)
         dev = store.device
         self.dev = dev
         self.bufs = {}
@@ -280,6 +287,11 @@ class Plan:
             return cd_
         feats = self.buf('feats', self.M, 256)
         self.feat_seg = [feats.data_ptr() + self.seg_off[i] * 256 * 2 for i in range(5)]
+        if self.defer:
+            # the FPN's and the head's parameters (one optimizer bucket) may still be on their way: the previous step's tower weight
+            # gradients and that bucket's update run beside this step's backbone (no-op until the slot is first recorded).  The wait
+            # also orders this step's head, which overwrites the towers' activations, behind the weight gradients that read them
+            f.wait(L.SLOT_HEADW, stream=0)
         fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
         p6r = self.buf('p6r', N, hw6[0], hw6[1], 256)
         f.conv(self._conv(lc[2], c5, lat[2], N, [hw5], [hw5], lds=ld5))
@@ -527,6 +539,13 @@ class Plan:
             self._wg_pending.append(list(descs))
             return
         if len(descs) == 1:
+            if ws_name != 'wg_ws':
+                # the descriptor was built with the shared 'wg_ws' scratch: a launch that runs on ANOTHER stream beside the
+                # weight-gradient stream's needs its own split-K scratch as the multi-member groups get below (a one-member group on
+                # the caller's stream raced the side stream's partial tiles: round 4, test_training_step_is_bit_reproducible)
+                need = L.lib.dsl_wgrad_workspace_bytes(C.byref(descs[0]))
+                ws = self._wg_buf(need, ws_name)
+                descs[0].workspace, descs[0].workspace_bytes = L.ptr(ws), ws.numel()
             ol.wgrad(descs[0], side=side)
             return
         arr0 = (L.WgradDesc * len(descs))()
@@ -658,11 +677,15 @@ class Plan:
                                  dbias=st.t32_ptr(lay['spec'].name + '.bias', st.grad))
                 ol.gn_bwd(gd, side=sd)
                 tower_group.append(self._wgrad(ol, lay['spec'], g_pre[tower], lay['xin'], N, ls, ls, side=SIDE, emit=False, no_db=True,
-                                               slots=int(os.environ.get('DSL_TOWER_SLOTS', '72'))))     # measured: tools/experiments_r2.txt (exp_r2z) (48-128: 5.84 ms, 160-192: 5.89); round 3: 72 / 96 / 128: 5.435 / 5.461 / 5.456
+                                               slots=int(os.environ.get('DSL_DEFER_SLOTS', '144')) if self.defer else
+                                               int(os.environ.get('DSL_TOWER_SLOTS', '72'))))     # measured: tools/experiments_r2.txt (exp_r2z) (48-128: 5.84 ms, 160-192: 5.89); round 3: 72 / 96 / 128: 5.435 / 5.461 / 5.456
             if (HALVES and i in (2, 0)) or i == 0:
                 if BT and SIDE:
                     ol.fork(1, other=BT)       # the weight-gradient stream also waits for the regression tower's stream
-                self._wgrad_group(ol, tower_group, side=SIDE)
+                if self.defer:
+                    self._deferred_towers = list(tower_group)      # emitted behind the last segment, see below
+                else:
+                    self._wgrad_group(ol, tower_group, side=SIDE)
                 self._flush_wgrads(ol, side=SIDE)
                 tower_group = []
             if i > 0:
@@ -761,8 +784,13 @@ class Plan:
         # bucket s is complete - the data-parallel wrapper's communication stream waits for exactly that
         # (dsl_stream_wait_slot) and starts the bucket's all-reduce, independent of the caller's stream.
         self._flush_wgrads(ol, side=SIDE)
-        ol.record(0)
-        self.bwd_segments.append((ol, dict(bucket=buckets[0], slot=0, main=False)))
+        if self.defer:
+            # bucket 0 is complete only behind the deferred tower group: its entry follows the last segment (bucket None = no bucket
+            # completes with this list)
+            self.bwd_segments.append((ol, dict(bucket=None, slot=None, main=False)))
+        else:
+            ol.record(0)
+            self.bwd_segments.append((ol, dict(bucket=buckets[0], slot=0, main=False)))
         # ================= backbone: layer4, layer3, layer2 =================
         if rla:
             from . import engine_rla
@@ -790,6 +818,12 @@ class Plan:
                 ol.join(BB)          # whatever stream 3 still runs (laterals, an earlier scatter) is visible to the caller's stream ...
                 ol.fork(BB)          # ... and stream 3 starts behind everything the caller's stream has queued
                 self._br_pending = False
+            # Last segment (layer2), round 4: its weight gradients used to go out behind the whole data-gradient chain - 250 us of
+            # memory-bound launches with nothing else left to run (profiles/r03b_sequence.txt: 2 284 -> 2 533 us).  With the towers'
+            # group deferred the weight-gradient stream is idle by then, so the groups of the blocks that are already through
+            # (all but block 0) go out as soon as block 1's data gradients are queued and run under block 0's chain; the tail is
+            # block 0's four launches.  DSL_L2_EARLY=0: the round-3 order.
+            early = bsplit and li == 1 and len(blks) > 2 and os.environ.get('DSL_L2_EARLY', '0') != '0'
             for blk in reversed(blks):
                 p = blk['prefix']
                 c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
@@ -798,6 +832,8 @@ class Plan:
                 grp = GROUP and (li > 1 or GROUP_LAST)
                 tsl = TAIL_SLOTS if li == 1 else 0      # last segment: nothing else is left to run beside these launches
                 if bsplit:
+                    if early and blk['b'] > 0:
+                        tsl = 0          # these run beside the chain: the weight-gradient stream's usual workgroup budget
                     g3.append(self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw], side=SIDE, emit=False, slots=tsl))
                     g2.append(self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw], side=SIDE, emit=False, slots=tsl))
                     g_prev = self.buf(p + '.g_in', N, hw[0], hw[1], planes * 4) if blk['b'] > 0 else None
@@ -820,6 +856,13 @@ class Plan:
                     if blk['b'] > 0:
                         g1.append(self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, emit=False, slots=tsl))
                         g_pre = g_prev
+                        if early and blk['b'] == 1:
+                            # blocks nb-1 .. 1 are through on both chains: their three groups leave now (the weight-gradient stream
+                            # waits for both chains' streams; the chains themselves go on without a join)
+                            ol.fork(1, other=BB)
+                            for grp_descs in (g3, g2, g1):
+                                self._wgrad_group(ol, grp_descs, side=SIDE, ws_name='wg_ws')
+                            g3, g2, g1 = [], [], []
                     else:
                         ol.join(BB)       # both chains are done: the weight gradients below (and the groups) read whole-batch tensors
                         d1 = self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, emit=True, slots=tsl)
@@ -880,6 +923,15 @@ class Plan:
                 ol.join()
             # main=True: part of this bucket's gradients was computed on the caller's stream (the last group above)
             self.bwd_segments.append((ol, dict(bucket=buckets[seg], slot=seg, main=(li == 1))))
+            if li == 1 and self.defer:
+                # the towers' weight gradients, last on the weight-gradient stream and NOT joined: they run under whatever the caller
+                # queues next (the next step's backbone forward); event slot 0 = "bucket 0 (head + FPN) complete"
+                dl = OpList()
+                on, self._multi_on = self._multi_on, False
+                self._wgrad_group(dl, self._deferred_towers, side=True)
+                self._multi_on = on
+                dl.record(0)
+                self.bwd_segments.append((dl, dict(bucket=buckets[0], slot=0, main=False, deferred=True)))
 
     # ---------------------------------------------------------------------------------------------
     def _split_prefix(self):
@@ -959,7 +1011,7 @@ class Engine:
     def plan(self, store, N, H, W, training=True, single_stream=False):
         if store.dirty:
             store.refresh()           # in place where the packs exist; a re-allocation bumps store.generation
-        key = (id(store), getattr(store, 'generation', 0), single_stream, N, H, W, training)
+        key = (id(store), getattr(store, 'generation', 0), bool(getattr(store, 'defer_head', False)), single_stream, N, H, W, training)
         p = self.plans.pop(key, None)
         if p is None:
             stale = [k for k in self.plans if k[0] == id(store) and k[1] != key[1]]

@@ -212,7 +212,8 @@ def build_backward(plan, buckets, SIDE):
                 g_t = plan.buf(p + '.g_t', pout, RLA_C)
                 g_u = plan.buf(p + '.g_u', pout, 64, zero=True)
                 g_pre = plan.buf(p + '.g_pre', pout, c4)
-                nrec = [-(-((e_ - b_) * ohw) // 256) for b_, e_, _ in groups]
+                # block records per group: the kernel's own rows-per-block constant decides (rla.hip BT_ROWS), through the ABI
+                nrec = [int(L.lib.dsl_bn_tanh_bwd_workspace_bytes((e_ - b_) * ohw, RLA_C)) // (2 * RLA_C * 4) for b_, e_, _ in groups]
                 ws = plan.buf(p + '.bnws', sum(nrec) * 2 * RLA_C + 8, dtype=torch.float32)
                 sc, _ = st.bn_ptrs(blk['bn'])
                 rec0 = 0

@@ -35,72 +35,146 @@ class FlatSGD:
         self.momentum_buf = None
         self.gnorm_sq = None
         self.steps = 0
+        self._sync_defer()
+
+    def _sync_defer(self):
+        """Deferred head update (engine.Plan.defer): possible when the update is element-wise per bucket - no gradient
+        clipping (a global norm needs every gradient first), per-bucket steps on, packs on the side stream.  The flag lives on
+        the parameter store because it shapes the op lists; DSL_DEFER_HEAD=0 turns it off."""
+        want = (self.max_norm is None and _BUCKET_SGD and _PACK_SIDE and os.environ.get('DSL_DEFER_HEAD', '0') != '0'
+                and self.store.backbone != 'rla')
+        if bool(getattr(self.store, 'defer_head', False)) != want:
+            self.store.wait_pending() if self.store.train.is_cuda else None
+            self.store.defer_head = want        # plans are keyed by it (Engine.plan): lists built the other way are not reused
 
     def zero_grad(self, set_to_none=False):
         # every gradient element is overwritten by the backward kernels; nothing to clear
         return
+
+    def _adopt_loaded_state(self):
+        """A momentum tensor restored by load_state_dict (CPU tensor, possibly laid out by another build) -> a buffer laid out like this
+        model's parameter buffer.  Called by step(); separate so that it can be checked without a device."""
+        st = self.store
+        # state restored from a checkpoint (CPU tensor, possibly laid out by another build): move it into a buffer laid out like
+        # the parameter buffer, REGION BY REGION (name -> offset, size, saved with the state), and keep the step count (resume
+        # must not re-zero momentum).  A prefix copy is only right when the two layouts differ by trailing padding; a state
+        # without a region table whose size is off by more than that is refused instead of being attached to the wrong parameters.
+        src = self.momentum_buf.reshape(-1)
+        buf = torch.zeros_like(st.train)
+        regs = getattr(self, '_loaded_regions', None)
+        cur = {k: (int(v[0]), int(v[1])) for k, v in st.train_regions.items()}
+        if regs:
+            regs = {k: (int(v[0]), int(v[1])) for k, v in regs.items()}
+            missing = [k for k in cur if k not in regs]
+            if missing:
+                raise RuntimeError(f'optimizer state: no momentum for {len(missing)} parameter regions of this model (first: {missing[:3]})')
+            for k, (o, n) in cur.items():
+                so, sn = regs[k]
+                m = min(n, sn)          # (a region's tail is tile padding: zeros in both)
+                buf.view(-1)[o:o + m].copy_(src[so:so + m].to(device=st.device, dtype=buf.dtype))
+        else:
+            if abs(buf.numel() - src.numel()) > 4096:
+                raise RuntimeError(f'optimizer state: momentum has {src.numel()} elements, the parameter buffer {buf.numel()}, and the '
+                                   'state carries no region table to remap it by (saved by an older build with another layout?)')
+            n = min(buf.numel(), src.numel())
+            buf.view(-1)[:n].copy_(src[:n].to(device=st.device, dtype=buf.dtype))
+        self.momentum_buf = buf
+        self._loaded_regions = None
 
     def step(self):
         st = self.store
         if self.momentum_buf is None:
             self.momentum_buf = torch.zeros_like(st.train)
             self.steps = 0
-        elif self.momentum_buf.device != st.device or self.momentum_buf.shape != st.train.shape:
-            # state restored from a checkpoint (CPU tensor, possibly without the tile padding of this build): move it
-            # into a buffer laid out like the parameter buffer and keep the step count (resume must not re-zero momentum)
-            buf = torch.zeros_like(st.train)
-            n = min(buf.numel(), self.momentum_buf.numel())
-            buf.view(-1)[:n].copy_(self.momentum_buf.reshape(-1)[:n].to(device=st.device, dtype=buf.dtype))
-            self.momentum_buf = buf
+        elif (self.momentum_buf.device != st.device or self.momentum_buf.shape != st.train.shape
+              or getattr(self, '_loaded_regions', None) is not None):
+            self._adopt_loaded_state()
         if self.gnorm_sq is None or self.gnorm_sq.device != st.device:
             self.gnorm_sq = torch.zeros(1, device=st.device)
         sp = L.stream_ptr()
         lr = float(self.param_groups[0]['lr'])
         blr = float(self.param_groups[1]['lr']) / lr if lr != 0 else self.bias_lr_mult
+        self._sync_defer()          # (OptimizerHook may set max_norm after construction)
         infos = getattr(self.model, '_last_bwd_infos', None)
+        infos = [i for i in infos if i['bucket'] is not None] if infos else infos      # completion order; a deferred bucket comes last
         if self.max_norm is None and _BUCKET_SGD and infos and st.grad.is_cuda and all(i['bucket'][0] % 4 == 0 for i in infos):
             # No gradient clipping (the supervised config): the update is element-wise, so each gradient bucket - head + FPN,
             # layer4, layer3, layer2, in the order the backward pass completes them - is updated on the optimizer's own stream
             # as soon as its weight gradients (data parallel: its all-reduce) are done, beside the rest of the backward pass,
             # instead of one pass over all 32 M parameters behind the last weight gradient.  Same arithmetic, same bits.
             cur = torch.cuda.current_stream()
-            if getattr(self, '_opt_stream', None) is None:
-                self._opt_stream = torch.cuda.Stream()
-            os_ = self._opt_stream
-            osp = C.c_void_p(os_.cuda_stream)
+            deferred = any(i.get('deferred') for i in infos)
+            if deferred:
+                # Deferred head update: the buckets the next forward pass needs first are updated on the CALLER's stream (idle once
+                # the data-gradient chain is through), the deferred bucket on the weight-gradient stream itself, in order behind the
+                # towers' group.  A stream of the optimizer's own would do logically, but streams share four hardware queues: it
+                # landed on the weight-gradient stream's queue, and the three early updates - hence the whole next forward pass -
+                # then sat behind the deferred 0.5 ms group (measured: 401 instead of 430 img/s, profiles/r04_defer_first.txt).
+                if getattr(self, '_side1', None) is None:
+                    h = C.c_void_p()
+                    L.check(L.lib.dsl_side_stream(1, C.byref(h)), 'dsl_side_stream')
+                    self._side1 = torch.cuda.ExternalStream(h.value)
+                os_ = None
+            else:
+                if getattr(self, '_opt_stream', None) is None:
+                    self._opt_stream = torch.cuda.Stream()
+                os_ = self._opt_stream
             pend = list(getattr(self.model, '_pending', []) or [])
             for k, info in enumerate(infos):
                 lo, hi = info['bucket']
+                tgt = (self._side1 if info.get('deferred') else cur) if deferred else os_
+                tp = C.c_void_p(tgt.cuda_stream)
                 if pend:
-                    with torch.cuda.stream(os_):
+                    with torch.cuda.stream(tgt):
                         pend[k].wait()
                         tr = getattr(self.model, 'comm_trace', None)
                         if tr and k < len(tr[-1]['buckets']):
                             ed = torch.cuda.Event(enable_timing=True)
                             ed.record()
                             tr[-1]['buckets'][k]['done'] = ed
-                else:
-                    never = L.lib.dsl_stream_wait_slot(int(info['slot']), osp)
-                    if info['main'] or never != 0:
-                        os_.wait_stream(cur)
+                elif not (deferred and info.get('deferred')):          # (the deferred bucket's stream IS the one its gradients ran on)
+                    never = L.lib.dsl_stream_wait_slot(int(info['slot']), tp)
+                    if (info['main'] or never != 0) and tgt is not cur:
+                        tgt.wait_stream(cur)
                 o4, o2, o1 = lo * 4, lo * 2, lo
                 L.check(L.lib.dsl_sgd_step(C.c_void_p(st.train.data_ptr() + o4), C.c_void_p(st.grad.data_ptr() + o4),
                                            C.c_void_p(self.momentum_buf.data_ptr() + o4), C.c_void_p(st.train16.data_ptr() + o2),
                                            C.c_void_p(st.group.data_ptr() + o1), hi - lo, lr, self.momentum, self.weight_decay, blr,
-                                           self.bias_decay_mult, None, 0.0, int(self.steps == 0), osp), 'dsl_sgd_step')
+                                           self.bias_decay_mult, None, 0.0, int(self.steps == 0), tp), 'dsl_sgd_step')
             if hasattr(self.model, '_pending'):
                 self.model._pending = []
-            cur.wait_stream(os_)
-            st.repack_dgrad(sp, side=_PACK_SIDE)
+            if deferred:
+                s1p = C.c_void_p(self._side1.cuda_stream)
+                L.check(L.lib.dsl_stream_record_slot(L.SLOT_HEADW, s1p), 'dsl_stream_record_slot')
+                st._pending_ev = torch.cuda.Event()
+                st._pending_ev.record(self._side1)
+                # the data-gradient packs read every bucket: behind the caller's stream (its three updates) AND the deferred one,
+                # i.e. forked from the caller's stream onto the weight-gradient stream, in order behind the deferred update
+                st.repack_dgrad(sp, side=True)
+            else:
+                cur.wait_stream(os_)
+                st.repack_dgrad(sp, side=_PACK_SIDE)
             self.steps += 1
             return
         if hasattr(self.model, 'wait_grads'):
             self.model.wait_grads()
+        for i in infos or []:
+            if i.get('deferred'):        # a list built for the deferred head update left its last weight gradients unjoined
+                L.lib.dsl_stream_wait_slot(int(i['slot']), sp)
         gptr = None
         if self.max_norm is not None:
-            if getattr(self, '_sumsq_ws', None) is None or self._sumsq_ws.device != st.device:
-                self._sumsq_ws = torch.zeros(1024, device=st.device)
-            L.check(L.lib.dsl_sumsq_det(L.ptr(st.grad), st.n_train, L.ptr(self.gnorm_sq), L.ptr(self._sumsq_ws), sp), 'dsl_sumsq_det')
+            m = self.model
+            if getattr(m, 'world_size', 1) > 1 and st.grad.is_cuda and getattr(m, 'clip_partials', None) is None and hasattr(m, 'clip_partials'):
+                # data parallel + clipping: from the next backward pass on, the norm arrives in pieces - one partial sum per bucket,
+                # computed on the communication stream behind that bucket's all-reduce - and only their fold precedes the update
+                m.clip_partials = torch.zeros(8 * L.SUMSQ_PARTS, device=st.device)
+            if getattr(m, '_partials_valid', False):
+                L.check(L.lib.dsl_sumsq_fold(L.ptr(m.clip_partials), int(m._n_partials), L.ptr(self.gnorm_sq), sp), 'dsl_sumsq_fold')
+                m._partials_valid = False
+            else:
+                if getattr(self, '_sumsq_ws', None) is None or self._sumsq_ws.device != st.device:
+                    self._sumsq_ws = torch.zeros(1024, device=st.device)
+                L.check(L.lib.dsl_sumsq_det(L.ptr(st.grad), st.n_train, L.ptr(self.gnorm_sq), L.ptr(self._sumsq_ws), sp), 'dsl_sumsq_det')
             gptr = self.gnorm_sq
         L.check(L.lib.dsl_sgd_step(L.ptr(st.train), L.ptr(st.grad), L.ptr(self.momentum_buf), L.ptr(st.train16),
                                    L.ptr(st.group), st.n_train, lr, self.momentum, self.weight_decay, blr,
@@ -110,7 +184,9 @@ class FlatSGD:
         self.steps += 1
 
     def state_dict(self):
-        return dict(momentum=self.momentum_buf, steps=self.steps, param_groups=self.param_groups)
+        # regions: where every named parameter lives in the flat momentum buffer - what load_state_dict / step remap by
+        return dict(momentum=self.momentum_buf, steps=self.steps, param_groups=self.param_groups,
+                    regions={k: (int(v[0]), int(v[1])) for k, v in self.store.train_regions.items()})
 
     def load_state_dict(self, sd):
         """Restores momentum, the step count (first-step rule of torch.optim.SGD: buf = grad) and the groups' learning
@@ -119,6 +195,9 @@ class FlatSGD:
         self.momentum_buf = m.detach().clone() if isinstance(m, torch.Tensor) else None
         self.steps = int(sd['steps']) if self.momentum_buf is not None else 0
         self.param_groups = [dict(g) for g in sd['param_groups']]
+        self._loaded_regions = dict(sd['regions']) if sd.get('regions') else None
+        if self._loaded_regions is None and self.momentum_buf is not None:
+            self._loaded_regions = {}          # (falsy, but makes step() run the size check once)
         self.gnorm_sq = None
         self._sumsq_ws = None
 

@@ -119,6 +119,8 @@ class ParamStore:
     def __init__(self, num_classes=80, device='cpu', backbone='resnet'):
         assert num_classes == 80 and backbone in ('resnet', 'rla')
         self.num_classes, self.backbone = num_classes, backbone
+        self.defer_head = False       # deferred head update (FlatSGD._sync_defer decides; engine.Plan.defer reads it)
+        self._pending_ev = None
         bspecs = backbone_specs() if backbone == 'resnet' else rla_backbone_specs()
         self.convs = {s.name: s for s in bspecs + neck_specs() + head_specs()}
         self.extra_bns = rla_stage_bns() if backbone == 'rla' else []        # BatchNorms that follow no convolution
@@ -272,7 +274,17 @@ class ParamStore:
             out[f'bbox_head.scales.{i}.scale'] = sc[i]
         return out
 
+    def wait_pending(self):
+        """Deferred head update (FlatSGD, Plan.defer): the last optimizer step may still be updating the head + FPN bucket on the
+        optimizer's stream.  Training forwards wait for it inside their op lists; every other reader or writer of the parameters
+        on the current stream (state_dict, EMA, evaluation, loading) calls this first."""
+        ev = getattr(self, '_pending_ev', None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._pending_ev = None
+
     def load_named(self, sd, strict=True):
+        self.wait_pending()
         views = self.named_views()
         missing = [k for k in views if k not in sd]
         unexpected = [k for k in sd if k not in views]
@@ -426,6 +438,7 @@ class ParamStore:
 
     def refresh(self):
         assert self.device.type == 'cuda', 'the HIP packs live on the GPU'
+        self.wait_pending()
         self.refresh_frozen()
         self.refresh_train_packs()
         self.dirty = False

@@ -209,6 +209,7 @@ class SemiEpochBasedRunner:
         s, t = self._det(self.model).store, self._det(self.ema_model).store
         if t.device != s.device:
             t.to(s.device)
+        s.wait_pending()          # (a deferred head update of the optimizer step just taken)
         ev = getattr(self, '_sweep_event', None)          # an asynchronous teacher sweep (UnlabelPredHook.async_sweep) still reads the
         if ev is not None:                                # teacher's weights: the update waits for it
             torch.cuda.current_stream().wait_event(ev)
@@ -608,8 +609,24 @@ class UnlabelPredHook(Hook):
         n, maxk, dev = dets.shape[0], dets.shape[1], dets.device
         olds = [self.bank[nm] if nm in self.bank else None for nm in names]
         max_old = max([len(o['scores']) for o in olds if o is not None] + [0])
-        if max_old + maxk > 1024:
-            raise RuntimeError(f'fuse_history: {max_old} stored labels + {maxk} detections exceed the fuse step\'s 1024 candidates')
+        cap = 1024 - maxk          # the fuse kernel holds 1024 candidates per image (detect.hip FUSE_MAX)
+        if max_old > cap:
+            # the reference has no such limit and the lists grow from round to round: keep an image's `cap` best-scoring stored labels
+            # (the per-class NMS favours high scores anyway) and say so once, instead of aborting a training run
+            trimmed = []
+            for o in olds:
+                if o is not None and len(o['scores']) > cap:
+                    keep = np.sort(np.argsort(-np.asarray(o['scores'], np.float32), kind='stable')[:cap])
+                    o = dict(o, rects=[np.asarray(o['rects'], np.float32).reshape(-1, 4)[j].tolist() for j in keep],
+                             scores=[o['scores'][j] for j in keep], tags=[o['tags'][j] for j in keep])
+                trimmed.append(o)
+            olds = trimmed
+            if not getattr(self, '_warned_fuse_cap', False):
+                self._warned_fuse_cap = True
+                import logging
+                logging.getLogger('dsl_amd').warning('fuse_history: %d stored labels + %d detections exceed the fuse step\'s 1024 candidates; '
+                                                      'keeping the %d best-scoring stored labels per image', max_old, maxk, cap)
+            max_old = cap
         mo = max(max_old, 1)
         hb, hs = torch.zeros(n, mo, 4), torch.zeros(n, mo)
         hl, hc = torch.zeros(n, mo, dtype=torch.int64), torch.zeros(n, dtype=torch.int32)

@@ -413,6 +413,14 @@ int dsl_sgd_step(float* p, const float* g, float* m, void* p16, const uint8_t* g
                  const float* gnorm_sq, float max_norm, int first_step, void* stream);
 int dsl_ema_lerp(float* teacher, const float* student, long n, float keep, void* stream);
 int dsl_cast_bf16(const float* x, void* y, long n, void* stream);
+/* bf16 -> fp32 (n % 4 == 0): the way back of a gradient bucket that crossed xGMI as bf16 (dsl_allreduce_bucket_bf16). */
+int dsl_cast_f32(const void* x_bf16, float* y, long n, void* stream);
+/* The clipping norm in pieces, for data parallel with grad_clip (every DSL config: mmcv OptimizerHook's clip_grad_norm_,
+ * mmdet/apis/train.py:157-166): one dsl_sumsq_partial per gradient bucket as its all-reduce completes (DSL_SUMSQ_PARTS block
+ * sums of x[0..n) -> partials), one dsl_sumsq_fold over all of them (index order) behind the last bucket.  No atomics. */
+#define DSL_SUMSQ_PARTS 256
+int dsl_sumsq_partial(const float* x, long n, float* partials /* [DSL_SUMSQ_PARTS] */, void* stream);
+int dsl_sumsq_fold(const float* partials, int n_partials, float* out /* [1] */, void* stream);
 /* KRSC fp32 -> CRSK bf16 ("dgrad pack"), optional per-cout scale fold. */
 int dsl_pack_dgrad(const float* w, const float* scale, void* out, int cout, int cout_pad, int taps,
                    int cin, void* stream);
@@ -483,6 +491,10 @@ int dsl_comm_size(void* comm);
 int dsl_comm_destroy(void* comm);
 int dsl_allreduce_bucket(void* comm, float* buf, size_t count, void* stream);
 int dsl_allreduce_buckets(void* comm, float* const* bufs, const size_t* counts, int n, void* stream);
+/* The same exchange on a bf16 copy of the bucket (half the bytes over xGMI; north_star allows bf16 gradients on the wire): in-place
+ * bf16 sum of buf[0..count).  The caller casts fp32 -> bf16 before (dsl_cast_bf16) and back after (dsl_cast_f32); the master gradient,
+ * the clipping norm and the optimizer stay fp32. */
+int dsl_allreduce_bucket_bf16(void* comm, void* buf_bf16, size_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Op-list executor: run a prebuilt sequence of the ops above with one call (keeps the per-step
@@ -522,6 +534,13 @@ int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream);
  * start a gradient bucket's all-reduce when the side stream has finished that bucket's weight gradients, whatever the
  * caller's compute stream is doing.  Returns 1 (and does nothing) if the slot was never recorded. */
 int dsl_stream_wait_slot(int slot, void* stream);
+/* Record named event slot `slot` (0..15) on `stream`: the counterpart of dsl_stream_wait_slot / DSL_OP_WAIT for a stream
+ * the caller owns (the optimizer's stream marks "bucket updated"; the next forward list waits for it where it first reads
+ * that bucket's weights). */
+int dsl_stream_record_slot(int slot, void* stream);
+/* The library's side stream `id` (1..3: 1 carries the weight gradients) of the current device as a hipStream_t, for work the
+ * caller must queue in order with it (the optimizer step of a bucket whose last weight gradients run there). */
+int dsl_side_stream(int id, void** stream_out);
 
 /* ------------------------------------------------------------------------------------------
  * Live kernel timing with HIP events (bench.py roofline): when enabled, each launch of the MFMA

@@ -170,3 +170,52 @@ def test_weight_tiles_never_read_past_the_buffers(backbone):
         assert off + s.cout_pad * s.k * s.k * s.cin_store <= total, s.name
     for name, rows in (('head.cls_w', 128), ('head.regctr_w', 64)):
         assert st.train_regions[name][0] + rows * 9 * 256 <= st.n_train
+
+
+def test_optimizer_state_is_remapped_by_region_not_by_prefix():
+    """Round-3 advisor: a restored momentum tensor whose flat layout differs from this build's (other tile padding between regions)
+    used to be prefix-copied - silently attached to the wrong parameters.  The state now carries the region table and is remapped
+    region by region; a state without a table whose size is off by more than trailing padding is refused."""
+    import pytest
+    import torch
+    from dsl_amd import detectors  # noqa: F401
+    from dsl_amd.optim import FlatSGD
+    from dsl_amd.registry import build_detector
+    from util import fcos_model_cfg
+    m = build_detector(fcos_model_cfg())
+    opt = FlatSGD(m, lr=0.01, momentum=0.9)
+    st = m.store
+    mom = torch.arange(st.train.numel(), dtype=torch.float32) % 1013
+    # what another build could have saved: every region shifted by a growing amount of padding
+    regs, chunks, off = {}, [], 0
+    for i, (k, (o, n, _)) in enumerate(sorted(st.train_regions.items(), key=lambda kv: kv[1][0])):
+        pad = 8 * (i % 3)
+        chunks += [mom[o:o + n], torch.full((pad,), -7.0)]
+        regs[k] = (off, n)
+        off += n + pad
+    other = torch.cat(chunks)
+    assert other.numel() != mom.numel()
+    opt.load_state_dict(dict(momentum=other, steps=5, param_groups=opt.param_groups, regions=regs))
+    opt._adopt_loaded_state()
+    covered = torch.zeros(st.train.numel(), dtype=torch.bool)
+    for k, (o, n, _) in st.train_regions.items():
+        assert torch.equal(opt.momentum_buf[o:o + n], mom[o:o + n]), k
+        covered[o:o + n] = True
+    assert float(opt.momentum_buf[~covered].abs().sum()) == 0 and opt.steps == 5 and -7.0 not in opt.momentum_buf
+    # round trip of this build's own state: identical
+    sd = opt.state_dict()
+    assert set(sd) == {'momentum', 'steps', 'param_groups', 'regions'}
+    opt2 = FlatSGD(m, lr=0.01, momentum=0.9)
+    opt2.load_state_dict(sd)
+    opt2._adopt_loaded_state()
+    assert torch.equal(opt2.momentum_buf, opt.momentum_buf)
+    # no table and a size that is not "this layout + trailing padding": refused
+    opt3 = FlatSGD(m, lr=0.01, momentum=0.9)
+    opt3.load_state_dict(dict(momentum=other[:-100000], steps=5, param_groups=opt.param_groups))
+    with pytest.raises(RuntimeError, match='region table'):
+        opt3._adopt_loaded_state()
+    # no table, trailing padding only: accepted (checkpoints of the previous rounds)
+    opt4 = FlatSGD(m, lr=0.01, momentum=0.9)
+    opt4.load_state_dict(dict(momentum=mom[:-8], steps=2, param_groups=opt.param_groups))
+    opt4._adopt_loaded_state()
+    assert torch.equal(opt4.momentum_buf[:-8], mom[:-8])

@@ -784,3 +784,84 @@ def test_conv_in_register_epilogue_equals_staged_epilogue(K, force, flavour):
     assert bool(same.all()), int((~same).sum())
     got = from_nhwc(outs[0].cuda())
     assert (got - bf(ref)).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+# ------------------------------------------------------------------------------------------------
+# Kernel-level checks at the benchmark's OWN sizes (round-3 review item 10: the weight- and data-gradient kernel tests above
+# stop at 25 x 42 pixels, the whole-net gradient tests are relative to a bf16 noise model).  Inputs are bf16-representable, the
+# reference is fp32 torch on the CPU, the bar is the one test_conv_forward uses: |err| <= 2^-7 * max|ref| (bf16 outputs carry
+# 2^-9 of their own magnitude, the fp32 sums of up to 44 800 x 256 exact products the rest).
+FULL_LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]        # the five FPN levels of an 800 x 1344 image
+
+
+def test_full_size_tower_layer_wgrad_and_dgrad(K):
+    """One FCOS tower layer (3x3 256 -> 256 over the five levels of two 800 x 1344 images = 44 800 locations): the weight gradient
+    (direct 256 x 256 tiles on 72 workgroups, as the step launches the towers' group, and the library's own choice) and the
+    data gradient against fp32 autograd."""
+    L, ops = K
+    g = torch.Generator().manual_seed(31)
+    N = 2
+    xs = [rnd(N, 256, h, w, g=g) for h, w in FULL_LEVELS]
+    dys = [rnd(N, 256, h, w, g=g, scale=0.25) for h, w in FULL_LEVELS]
+    w = rnd(256, 256, 3, 3, g=g, scale=1 / 48.0)
+    # fp32 reference: torch's own convolution autograd in fp32 ON THE DEVICE (an independent implementation - MIOpen / rocBLAS, true
+    # fp32 - of 317 GFLOP; the same sums on the host's cores take minutes)
+    wd = w.cuda().requires_grad_()
+    xg = [x.cuda().requires_grad_() for x in xs]
+    sum((F.conv2d(x, wd, None, 1, 1) * dy.cuda()).sum() for x, dy in zip(xg, dys)).backward()
+    ref_w = wd.grad.permute(0, 2, 3, 1).cpu()
+    ref_x = torch.cat([x.grad.permute(0, 2, 3, 1).reshape(-1, 256) for x in xg]).cpu()
+    X, DY = _multiseg(xs), _multiseg(dys)
+    M = X.shape[0]
+    assert M == 44800
+    for slots in (72, 0):
+        dw = torch.full((256, 3, 3, 256), float('nan'), dtype=torch.float32, device='cuda')
+        d = ops.wgrad_desc(DY, X, dw, n=N, grid=FULL_LEVELS, src_hw=FULL_LEVELS, cs=256, cy=256, cd=256, kh=3, kw=3, stride=1, pad=1,
+                           slots=slots)
+        L.check(L.lib.dsl_conv2d_wgrad(C.byref(d), L.stream_ptr()), 'dsl_conv2d_wgrad')
+        sync()
+        err = float((dw.cpu() - ref_w).abs().max())
+        assert err <= 2.0 ** -7 * float(ref_w.abs().max()), (slots, err, float(ref_w.abs().max()))
+    dx = torch.empty(M, 256, dtype=torch.bfloat16, device='cuda')
+    ops.conv2d(DY, pack_w_dgrad(w, 256), dx, n=N, grid=FULL_LEVELS, src_hw=FULL_LEVELS, dst_hw=FULL_LEVELS, cs=256, cd=256,
+               cd_pad=256, ldd=256, kh=3, kw=3, stride=1, pad=1, mode=1)
+    sync()
+    err = float((dx.float().cpu() - ref_x).abs().max())
+    assert err <= 2.0 ** -7 * float(ref_x.abs().max()), (err, float(ref_x.abs().max()))
+
+
+def test_full_size_layer3_block_wgrad_and_dgrad(K):
+    """The three convolutions of a layer3 bottleneck at the benchmark's size (2 x 50 x 84 = 8 400 pixels; 1x1 1024 -> 256, 3x3 256 ->
+    256, 1x1 256 -> 1024): weight gradients through the multi launch the step uses (one grid, the planner's split factors and
+    schedule table) and the three data gradients, against fp32 autograd."""
+    L, ops = K
+    g = torch.Generator().manual_seed(32)
+    N, H, W = 2, 50, 84
+    shapes = [(1024, 256, 1, 0), (256, 256, 3, 1), (256, 1024, 1, 0)]            # (cin, cout, k, pad)
+    subs, refs, outs, dgr = [], [], [], []
+    for ci, co, k, p in shapes:
+        x = rnd(N, ci, H, W, g=g)
+        w = rnd(co, ci, k, k, g=g, scale=1 / math.sqrt(ci * k * k))
+        dy = rnd(N, co, H, W, g=g, scale=0.25)
+        xd, wd = x.cuda().requires_grad_(), w.cuda().requires_grad_()          # fp32 reference on the device (see above)
+        (F.conv2d(xd, wd, None, 1, p) * dy.cuda()).sum().backward()
+        dw = torch.full((co, k, k, ci), float('nan'), dtype=torch.float32, device='cuda')
+        subs.append([ops.wgrad_desc(nhwc(dy), nhwc(x), dw, n=N, grid=[(H, W)], src_hw=[(H, W)], cs=ci, cy=co, cd=co, kh=k,
+                                    kw=k, stride=1, pad=p)])
+        refs.append(wd.grad.permute(0, 2, 3, 1).cpu())
+        outs.append(dw)
+        dgr.append((dy, w, xd.grad.cpu(), ci, co, k, p))
+    assert {L.lib.dsl_wgrad_multi_config(C.byref(s[0])) for s in subs} == {1}
+    plan = ops.WgradMulti(subs)
+    plan.run()
+    sync()
+    for ref, dw in zip(refs, outs):
+        err = float((dw.cpu() - ref).abs().max())
+        assert err <= 2.0 ** -7 * float(ref.abs().max()), (tuple(ref.shape), err, float(ref.abs().max()))
+    for dy, w, ref, ci, co, k, p in dgr:
+        dx = torch.empty(N, H, W, ci, dtype=torch.bfloat16, device='cuda')
+        ops.conv2d(nhwc(dy), pack_w_dgrad(w, co), dx, n=N, grid=[(H, W)], src_hw=[(H, W)], dst_hw=[(H, W)], cs=co, cd=ci, cd_pad=ci,
+                   ldd=ci, kh=k, kw=k, stride=1, pad=p, mode=1)
+        sync()
+        err = float((from_nhwc(dx) - ref).abs().max())
+        assert err <= 2.0 ** -7 * float(ref.abs().max()), ((ci, co, k), err, float(ref.abs().max()))

@@ -329,3 +329,63 @@ def test_async_sweep_gives_the_same_labels():
         for x, y in zip(la[n], lb[n]):
             assert np.array_equal(x, y), n
     assert torch.equal(wa, wb)
+
+
+def test_bench_loop_and_train_detector_enqueue_the_same_step(tmp_path):
+    """The headline is the product (round-3 review, item 5): bench.py's loop (train_step -> loss.backward() -> opt.step(), no
+    attribute set on the detector) and dsl_amd.apis.train_detector on the supervised config's training sections run the same
+    detector flags, build the same op lists (kinds and streams, forward / prefix / every backward segment) and reach the same
+    weights bit for bit."""
+    from dsl_amd.apis import train_detector
+    from dsl_amd.optim import FlatSGD
+    from dsl_amd.registry import Config
+    batch = {k: v for k, v in make_batches(1)[0].items() if k != 'gt_bboxes_ignore'}
+    n_it = 4
+
+    def lists(det):
+        plan = [p for p in det._engine.plans.values() if p.training][0]
+        sig = lambda ol: [(o.kind, o.i[6]) for o in ol.items]
+        out = dict(fwd=sig(plan.fwd), prefix=sig(plan.prefix) if plan.prefix is not None else None, defer=plan.defer)
+        for k, (ol, info) in enumerate(plan.bwd_segments):
+            out[f'bwd{k}'] = (sig(ol), info.get('bucket'), info.get('deferred', False))
+        return out
+
+    a = build()
+    opt = FlatSGD(a, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+    opt.param_groups[0]['lr'] = opt.param_groups[1]['lr'] = 0.0          # set per iteration below: the config's warm-up schedule
+    for it in range(n_it):
+        f = 1 - (1 - it / 500) * (1 - 1.0 / 3)
+        opt.param_groups[0]['lr'], opt.param_groups[1]['lr'] = 0.01 * f, 0.02 * f
+        out = a.train_step(batch, opt)
+        out['loss'].backward()
+        opt.step()
+    torch.cuda.synchronize()
+
+    class Loader:
+        def __len__(self):
+            return n_it
+
+        def __iter__(self):
+            return iter([batch] * n_it)
+
+    b = build()
+    cfg = Config(dict(
+        model=fcos_model_cfg(), data=dict(samples_per_gpu=2, workers_per_gpu=2),
+        optimizer=dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=0.0001, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.)),
+        optimizer_config=dict(grad_clip=None),
+        lr_config=dict(policy='step', warmup='linear', warmup_iters=500, warmup_ratio=1.0 / 3, step=[50, 80]),
+        runner=dict(type='EpochBasedRunner', max_epochs=1), checkpoint_config=dict(interval=1000),
+        log_config=dict(interval=2, hooks=[dict(type='TextLoggerHook')]), custom_hooks=[dict(type='NumClassCheckHook')],
+        log_level='ERROR', load_from=None, resume_from=None, workflow=[('train', 1)], work_dir=str(tmp_path)))
+    runner = train_detector(b, [Loader()], cfg, distributed=False, validate=False)
+    torch.cuda.synchronize()
+    det = runner._det(runner.model)
+    assert runner.iter == n_it
+    for flag in ('lazy_log', 'eager_backward', 'pipeline_prefix'):
+        assert getattr(a, flag) == getattr(det, flag) is True, flag
+    assert a.store.defer_head == det.store.defer_head                # (the deferred head update is opt-in: DSL_DEFER_HEAD=1)
+    la, lb = lists(a), lists(det)
+    assert la.keys() == lb.keys()
+    for k in la:
+        assert la[k] == lb[k], k
+    assert torch.equal(a.store.train, det.store.train) and torch.equal(a.store.train16, det.store.train16)

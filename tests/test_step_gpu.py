@@ -291,3 +291,70 @@ def test_pipelined_prefix_equals_inline_forward(golden):
         assert (plan.prefix is not None) and (plan._parity == (0 if not pipe else len(imgs) % 2))
         finals.append((torch.stack(losses).cpu(), model.store.train.clone().cpu()))
     assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+
+
+def test_deferred_head_update_trains_to_the_same_bits(golden, monkeypatch):
+    """Deferred head update (engine.Plan.defer, FlatSGD without clipping): the towers' weight gradients and the head + FPN bucket's
+    optimizer step run under the NEXT step's backbone forward, which waits for them in front of the FPN (SLOT_HEADW).  Same kernels
+    and summation order (DSL_DEFER_SLOTS = the inline budget) => bit-identical losses and weights over steps with changing images;
+    a state_dict() read right behind opt.step() already sees the finished update (ParamStore.wait_pending)."""
+    from dsl_amd.optim import FlatSGD
+    d = golden('net_tiny.npz')
+    B = int(d['B'])
+    gtb, gtl = [T(d[f'gt{i}']) for i in range(B)], [T(d[f'gl{i}']) for i in range(B)]
+    g = torch.Generator().manual_seed(5)
+    imgs = [(T(d['img']) + 0.5 * k * torch.randn(T(d['img']).shape, generator=g)).cuda() for k in range(5)]
+    metas = [dict(img_shape=tuple(imgs[0].shape[2:]) + (3,), pad_shape=tuple(imgs[0].shape[2:]) + (3,), scale_factor=1.0)] * B
+    monkeypatch.setenv('DSL_DEFER_SLOTS', '72')
+    monkeypatch.setenv('DSL_TOWER_SLOTS', '72')
+    finals = []
+    for defer in ('0', '1'):
+        monkeypatch.setenv('DSL_DEFER_HEAD', defer)
+        model = build()
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+        assert bool(getattr(model.store, 'defer_head', False)) == (defer == '1')
+        losses = []
+        for img in imgs:
+            out = model.train_step(dict(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl), opt)
+            out['loss'].backward()
+            opt.step()
+            losses.append(out['loss'].detach().clone())
+        early = {k: v.clone() for k, v in model.state_dict().items()}          # no device-wide sync in front of this read
+        torch.cuda.synchronize()
+        late = model.state_dict()
+        assert all(torch.equal(early[k], late[k]) for k in late)
+        plan = [p for p in model._engine.plans.values() if p.training][0]
+        assert plan.defer == (defer == '1')
+        finals.append((torch.stack(losses).cpu(), model.store.train.clone().cpu(), model.store.train16.clone().cpu()))
+    assert torch.equal(finals[0][0], finals[1][0])
+    assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+
+
+def test_deferred_plan_with_a_clipping_optimizer_still_sees_every_gradient(golden, monkeypatch):
+    """mmcv's OptimizerHook hands grad_clip to the optimizer AFTER the first backward pass: a list built for the deferred update
+    (its last weight gradients are not joined into the caller's stream) then meets the whole-buffer clipped step, which must wait
+    for them; from the next step on the lists are built without the deferral."""
+    from dsl_amd.optim import FlatSGD
+    d = golden('net_tiny.npz')
+    B = int(d['B'])
+    gtb, gtl = [T(d[f'gt{i}']) for i in range(B)], [T(d[f'gl{i}']) for i in range(B)]
+    img = T(d['img']).cuda()
+    metas = [dict(img_shape=tuple(img.shape[2:]) + (3,), pad_shape=tuple(img.shape[2:]) + (3,), scale_factor=1.0)] * B
+    monkeypatch.setenv('DSL_DEFER_SLOTS', '72')
+    monkeypatch.setenv('DSL_DEFER_HEAD', '1')
+    res = []
+    for late_clip in (False, True):
+        model = build()
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
+                      grad_clip=None if late_clip else dict(max_norm=1.0, norm_type=2))
+        for it in range(2):
+            out = model.train_step(dict(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl), opt)
+            if late_clip and it == 0:
+                assert model.store.defer_head
+                opt.max_norm = 1.0                 # what OptimizerHook.after_train_iter does in front of its first step
+            out['loss'].backward()
+            opt.step()
+        assert not model.store.defer_head
+        torch.cuda.synchronize()
+        res.append(model.store.train.clone().cpu())
+    assert torch.equal(res[0], res[1])

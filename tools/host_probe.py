@@ -9,7 +9,7 @@ model.lazy_log = True; model.eager_backward = True
 opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
 batch = bench.synth_batch(0, 2)
 from dsl_amd.data import mark_ready
-mark_ready(batch['img'])
+_ev = torch.cuda.Event(); _ev.record()
 acc = collections.Counter()
 def wrap(obj, name, key):
     f = getattr(obj, name)
@@ -22,7 +22,7 @@ wrap(model, '_run_backward', '_run_backward')
 wrap(model, '_parse_losses', '_parse_losses')
 wrap(opt, 'step', 'opt.step')
 def step():
-    out = model.train_step(batch, opt); out['loss'].backward(); opt.step()
+    mark_ready(batch['img'], event=_ev); out = model.train_step(batch, opt); out['loss'].backward(); opt.step()
 for _ in range(6): step()
 torch.cuda.synchronize(); acc.clear()
 K = 20; t0 = time.perf_counter()

@@ -10,9 +10,10 @@ from dsl_amd.registry import build_detector
 model = build_detector(bench.model_cfg()).cuda()
 model.lazy_log = True; model.eager_backward = True
 opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
-batch = bench.synth_batch(0, 2); mark_ready(batch['img'])
+batch = bench.synth_batch(0, 2)
+_ev = torch.cuda.Event(); _ev.record()
 def step():
-    out = model.train_step(batch, opt); out['loss'].backward(); opt.step()
+    mark_ready(batch['img'], event=_ev); out = model.train_step(batch, opt); out['loss'].backward(); opt.step()
 for _ in range(6): step()
 torch.cuda.synchronize()
 plan = model._prefix_plan
