@@ -106,7 +106,7 @@ class DetDesc(C.Structure):
 class PackItem(C.Structure):
     _fields_ = [('w', C.c_void_p), ('scale', C.c_void_p), ('out', C.c_void_p),
                 ('cout', C.c_int32), ('cout_pad', C.c_int32), ('taps', C.c_int32), ('cin', C.c_int32),
-                ('block_start', C.c_int32), ('tiles_ci', C.c_int32), ('tiles_co', C.c_int32), ('pad_', C.c_int32)]
+                ('block_start', C.c_int32), ('tiles_ci', C.c_int32), ('tiles_co', C.c_int32), ('tapmap', C.c_int32)]
 
 
 class RlaDesc(C.Structure):

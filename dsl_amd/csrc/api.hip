@@ -97,6 +97,13 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
       dsl_prof_phase(o.i[0], o.i[1], o.l[0], o.l[1], pick(o.i[6]));
       continue;
     }
+    // Step-level ablation (tools/step_ablation.sh; results are WRONG, only the clock is read): DSL_SKIP_KINDS = bit mask of op kinds
+    // that are not launched (ordering ops are never skipped) - "what would the step gain if this component cost nothing?", measured
+    // under the step's real contention instead of estimated from standalone kernel times.  Bit 30: only the ops of side stream 1.
+    static const unsigned skip_kinds = [] { const char* e = getenv("DSL_SKIP_KINDS"); return e ? (unsigned)strtoul(e, nullptr, 0) : 0u; }();
+    if (skip_kinds && o.kind < 30 && (skip_kinds >> o.kind & 1u) && o.kind != DSL_OP_FORK && o.kind != DSL_OP_JOIN &&
+        o.kind != DSL_OP_RECORD && o.kind != DSL_OP_WAIT && (!(skip_kinds >> 30 & 1u) || o.i[6] == 1))
+      continue;
     if (o.kind == DSL_OP_RECORD || o.kind == DSL_OP_WAIT) {
       side_init(dev);
       DSL_CHECK(o.i[1] >= 0 && o.i[1] < 16, "dsl_run_ops: event slot %d out of range", o.i[1]);

@@ -4027,6 +4027,16 @@ bool wgrad_multi_v3(const dsl_wgrad_desc* descs, const int* counts, int nsub, in
   for (int s = 0; s < nsub; ++s) { v3 = v3 && wgrad_v3_ok(&descs[off], cfg); off += counts[s]; }
   return v3;
 }
+// workgroup budget of a multi launch: the library's (DSL_WGRAD_SLOTS, default 128) unless a descriptor asks for its own
+// (dsl_wgrad_desc.slots > 0: the launches at the very end of a backward pass, with nothing left to run beside them, take more)
+int wgrad_multi_cap(const dsl_wgrad_desc* descs, const int* counts, int nsub) {
+  int n = 0, cap = 0;
+  for (int s = 0; s < nsub; ++s) n += counts[s];
+  for (int i = 0; i < n; ++i) cap = std::max(cap, descs[i].slots);
+  if (cap <= 0) cap = wgrad_slots();
+  return (std::min(cap, 256) + 7) / 8 * 8;
+}
+
 // the planner's view of a launch's sub-launches (in the caller's order)
 void wgrad_plan_subs(const dsl_wgrad_desc* descs, const int* counts, int nsub, int ks, PlanSub* subs) {
   int off = 0;
@@ -4050,7 +4060,7 @@ int wgrad_multi_splits(const dsl_wgrad_desc* descs, const int* counts, int nsub,
       PlanSub subs[kMaxMulti];
       wgrad_plan_subs(descs, counts, nsub, kWgV3KS, subs);
       PlanOut po;
-      wgrad_plan(subs, nsub, cfg0, (wgrad_slots() + 7) / 8 * 8, &po);
+      wgrad_plan(subs, nsub, cfg0, wgrad_multi_cap(descs, counts, nsub), &po);
       for (int s = 0; s < nsub; ++s) splits[s] = po.splits[s];
       return 0;
     }
@@ -4064,7 +4074,7 @@ int wgrad_multi_splits(const dsl_wgrad_desc* descs, const int* counts, int nsub,
     off += counts[s];
   }
   const int cfg = wgrad_pick(descs);
-  const int slots = wgrad_slots() * (cfg == 4 ? 2 : 1);
+  const int slots = wgrad_multi_cap(descs, counts, nsub) * (cfg == 4 ? 2 : 1);
   long long lmax = (total + slots - 1) / slots;
   if (lmax < 4) lmax = 4;
   off = 0;
@@ -4204,7 +4214,7 @@ extern "C" int dsl_wgrad_multi_build(const dsl_wgrad_desc* descs, const int* cou
     wgrad_plan_subs(descs, counts, nsub, kWgV3KS, subs);
     long long items = 0;
     for (int i = 0; i < nsub; ++i) { tsubs[i] = subs[order[i]]; tsplits[i] = splits[order[i]]; items += (long long)tsplits[i] * tsubs[i].tiles; }
-    const int cap_ = (wgrad_slots() + 7) / 8 * 8;
+    const int cap_ = wgrad_multi_cap(descs, counts, nsub);
     int G = (int)std::min<long long>(cap_, (items + 7) / 8 * 8);
     if (G < 8) G = 8;
     {

@@ -128,12 +128,15 @@ __global__ __launch_bounds__(256) void pack_dgrad_batched_kernel(const dsl_pack_
   const int t = b / I.tiles_co;
   const int ci0 = tci * 64, co0 = tco * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // tap selection (dsl_pack_item.tapmap): out tap t reads source tap st of a weight with staps taps; st >= staps = a zero tap
+  const int staps = I.tapmap ? ((I.tapmap >> 16) & 0xff) : I.taps;
+  const int st = I.tapmap ? ((I.tapmap >> (4 * t)) & 0xf) : t;
 #pragma unroll 4
   for (int r = ty; r < 64; r += 4) {
     const int co = co0 + r, ci = ci0 + tx;
     float v = 0.f;
-    if (co < I.cout && ci < I.cin) {
-      v = I.w[((long long)co * I.taps + t) * I.cin + ci];
+    if (co < I.cout && ci < I.cin && st < staps) {
+      v = I.w[((long long)co * staps + st) * I.cin + ci];
       if (I.scale) v *= I.scale[co];
     }
     tile[r][tx] = v;

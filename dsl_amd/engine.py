@@ -943,6 +943,8 @@ class Plan:
         f, end = self.fwd, self._prefix_end
         pre, rest = OpList(), OpList()
         pre.items, rest.items = f.items[:end], f.items[end:]
+        if os.environ.get('DSL_SKIP_PREFIX_CONVS'):      # step-level ablation (tools/step_ablation.sh): layer1 costs nothing - timing only
+            pre.items = [o for o in pre.items if o.kind != L.OP_CONV]
         pre.keep = rest.keep = f.keep
         ws = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)      # the prefix runs beside the caller's convs: own split-K scratch
         for o in pre.items:

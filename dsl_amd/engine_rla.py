@@ -165,6 +165,7 @@ def build_backward(plan, buckets, SIDE):
     # ResNet engine's backward, the caller's stream is full of kernel time here (10.7 of 12.1 ms busy, profiles/r03_rla_timeline.txt),
     # not of launch gaps, and the weight-gradient grids already hold the CUs a second chain would use.
     BSPLIT = os.environ.get('DSL_RLA_SPLIT_BWD', '') if (SIDE and plan._multi_on and plan.BR and N >= 2) else ''
+    S2_CLASSES = os.environ.get('DSL_S2_CLASSES', '1') != '0'          # stride-2 3x3 data gradients as four parity-class launches
     BB = plan.BR
 
     def br_ws(d_):
@@ -181,6 +182,9 @@ def build_backward(plan, buckets, SIDE):
         bsplit = str(s_) in BSPLIT
         groups = [(0, (N + 1) // 2, 0), ((N + 1) // 2, N, BB)] if bsplit else [(0, N, 0)]
         rec_items = []
+        # the last stage's weight gradients go out behind the whole data-gradient chain, with nothing left to run beside them (0.8 ms
+        # of the iteration, profiles/r03_rla_sequence.txt): they take the chip instead of the weight-gradient stream's usual budget
+        tsl = int(os.environ.get('DSL_RLA_TAIL_SLOTS', '192')) if s_ == 1 else 0
         if bsplit:
             ol.fork(BB)
 
@@ -236,9 +240,9 @@ def build_backward(plan, buckets, SIDE):
                     it = L.RecSumItem()
                     it.rec, it.out_a, it.out_b, it.nrec = ws.data_ptr(), bn_g(blk['bn'], 'weight'), bn_g(blk['bn'], 'bias'), sum(nrec)
                     rec_items.append(it)
-                g_rc.append(plan._wgrad(ol, rc, gh, blk['t'], N, [(oh, ow)], [(oh, ow)], cy=64, cd=RLA_C, emit=False, shared=1))
+                g_rc.append(plan._wgrad(ol, rc, gh, blk['t'], N, [(oh, ow)], [(oh, ow)], cy=64, cd=RLA_C, emit=False, shared=1, slots=tsl))
                 g_co.append(plan._wgrad(ol, co, g_u, blk['out'], N, [(oh, ow)], [(oh, ow)], cy=64, cd=RLA_C, emit=False,
-                                        ldx=blk['ld_out'], shared=1))
+                                        ldx=blk['ld_out'], shared=1, slots=tsl))
             # ---- bottleneck: out = relu(bn3(conv3(a2)) + identity)
             gA2 = plan.buf(p + '.g_a2', pout, planes)
             gA1 = plan.buf(p + '.g_a1', pin, planes)
@@ -251,8 +255,17 @@ def build_backward(plan, buckets, SIDE):
                 n_ = ge - g0
                 dg(sd, plan._dgrad(c3.name, O(g_pre, g0, ge), O(gA2, g0, ge), n_, [(oh, ow)], [(oh, ow)], cs=c4, cd=planes, k=1,
                                    stride=1, pad=0, mask=O(blk['a2'], g0, ge), mask_last=True))
-                dg(sd, plan._dgrad(c2.name, O(gA2, g0, ge), I(gA1, g0, ge), n_, [(oh, ow)], [(h, w)], cs=planes, cd=planes, k=3,
-                                   stride=stride, pad=1, mask=I(blk['a1'], g0, ge), mask_last=True))
+                if stride == 2 and S2_CLASSES:
+                    # the stride-2 3x3 data gradient as four stride-1 launches of the pipelined kernel (one per output-pixel parity
+                    # class, ops.dgrad_s2_descs) instead of the general strided gather: 13 instead of 36 tap products per 2 x 2 block
+                    packs = {(py, px): st.wT_ptr(f'{c2.name}#s2{py}{px}') for py in (0, 1) for px in (0, 1)}
+                    for d_ in ops.dgrad_s2_descs(O(gA2, g0, ge), packs, I(gA1, g0, ge), n=n_, dy_hw=(oh, ow), dst_hw=(h, w), cs=planes,
+                                                 cd=planes, mask=I(blk['a1'], g0, ge), ldm=planes, flags=L.CONV_MASK_LAST,
+                                                 workspace=plan.conv_ws):
+                        dg(sd, d_)
+                else:
+                    dg(sd, plan._dgrad(c2.name, O(gA2, g0, ge), I(gA1, g0, ge), n_, [(oh, ow)], [(h, w)], cs=planes, cd=planes, k=3,
+                                       stride=stride, pad=1, mask=I(blk['a1'], g0, ge), mask_last=True))
                 if first:
                     continue
                 # ---- gradient w.r.t. the block input (x part) and w.r.t. the incoming h
@@ -277,20 +290,20 @@ def build_backward(plan, buckets, SIDE):
                 dg(sd, plan._dgrad(c1.name, I(gA1, g0, ge), I(gh_prev, g0, ge), n_, [(h, w)], [(h, w)], cs=planes, cd=RLA_C, cd_pad=64,
                                    k=1, stride=1, pad=0, ldd=64, addend=add, lda=lda, wptr=wT + cx * c1.cout_pad * 2))
             g3.append(plan._wgrad(ol, c3, g_pre, blk['a2'], N, [(oh, ow)], [(oh, ow)], emit=False, raw=True,
-                                  db_ptr=bn_g(c3.bn, 'bias')))
-            d2 = plan._wgrad(ol, c2, gA2, blk['a1'], N, [(oh, ow)], [(h, w)], emit=False, raw=True, db_ptr=bn_g(c2.bn, 'bias'))
+                                  db_ptr=bn_g(c3.bn, 'bias'), slots=tsl))
+            d2 = plan._wgrad(ol, c2, gA2, blk['a1'], N, [(oh, ow)], [(h, w)], emit=False, raw=True, db_ptr=bn_g(c2.bn, 'bias'), slots=tsl)
             if stride == 1:
                 g2.append(d2)                # the stage's stride-1 3x3 convolutions share a geometry
             else:
                 emit(d2)
-            d1 = plan._wgrad(ol, c1, gA1, blk['xh'], N, [(h, w)], [(h, w)], emit=False, raw=True, db_ptr=bn_g(c1.bn, 'bias'))
+            d1 = plan._wgrad(ol, c1, gA1, blk['xh'], N, [(h, w)], [(h, w)], emit=False, raw=True, db_ptr=bn_g(c1.bn, 'bias'), slots=tsl)
             if b > 0:
                 g1.append(d1)
             else:
                 emit(d1)
                 ds = cv[p + '.downsample.0']
                 emit(plan._wgrad(ol, ds, g_pre, blk['xh'], N, [(oh, ow)], [(h, w)], emit=False, raw=True,
-                                 db_ptr=bn_g(ds.bn, 'bias'), ldx=ldx))
+                                 db_ptr=bn_g(ds.bn, 'bias'), ldx=ldx, slots=tsl))
             if not first:
                 gh_next = gh_prev
                 gx = gx_prev

@@ -36,6 +36,53 @@ def conv_desc(src, wgt, dst, *, n, grid, src_hw, dst_hw, cs, cd, cd_pad, ldd, kh
     return d
 
 
+# ---- data gradient of a 3x3 / stride-2 / pad-1 convolution as four stride-1 convolutions ------------------------------------------
+# dX[y][x] = sum over taps (r, s) with (y + 1 - r), (x + 1 - s) even of dY[(y + 1 - r) / 2][(x + 1 - s) / 2] . W[r][s]: an output
+# pixel of parity class (py, px) = (y % 2, x % 2) only ever meets the taps r = py +- 1, s = px +- 1 - one tap for (0, 0), two for
+# (0, 1) / (1, 0), four for (1, 1).  Each class is a stride-1 transposed convolution over the dY grid with a 1x1 (class (0, 0)) or
+# 2x2 kernel (weight tap t -> source row i + pad - t, the library's mode-1 rule), written with output stride 2 at offset (py, px).
+# 13 of the 36 tap-pixel products of the strided gather per 2x2 output block remain (the 2x2 classes (0, 1), (1, 0) carry two zero
+# taps: the descriptor has one `pad` for both axes), and the launches go to the pipelined kernel instead of the general-gather one
+# (conv_glds: 292 / 167 / 75 us for RLA_ResNet's three stride-2 convolutions at N = 3, profiles/r03_rla_sequence.txt).
+def s2_class(py, px):
+    """(k, pad, source taps of the class's k*k weight taps in (t_r, t_s) order; -1 = a zero tap)."""
+    if py == 0 and px == 0:
+        return 1, 0, [4]
+    taps = []
+    for tr in (0, 1):
+        r = (py - 1) if tr == 0 else (py + 1)
+        for ts in (0, 1):
+            s_ = (px - 1) if ts == 0 else (px + 1)
+            taps.append(r * 3 + s_ if (0 <= r <= 2 and 0 <= s_ <= 2) else -1)
+    return 2, 1, taps
+
+
+def dgrad_s2_descs(dy, packs, dst, *, n, dy_hw, dst_hw, cs, cd, cd_pad=None, ldd=None, mask=None, ldm=0, addend=None, lda=0, flags=0,
+                   workspace=None, cs_real=0):
+    """Four conv descriptors (one per parity class) for the data gradient of a 3x3 / 2 / pad 1 convolution.  dy: [n][oh][ow][cs] bf16
+    (tensor or pointer), packs: {(py, px): pointer of the class's [cd_in = Cin][k][k][cs] bf16 pack}, dst / mask / addend: tensors or
+    raw pointers of [n][h][w][.] rows.  One segment."""
+    (oh, ow), (h, w) = dy_hw, dst_hw
+    ldd = ldd or cd
+    raw = lambda t: 0 if t is None else (t if isinstance(t, int) else t.data_ptr())
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            gh, gw = (h - py + 1) // 2, (w - px + 1) // 2
+            if gh <= 0 or gw <= 0:
+                continue
+            k, pad, _ = s2_class(py, px)
+            off = py * w + px
+            d = conv_desc(dy, packs[(py, px)], raw(dst) + off * ldd * 2, n=n, grid=[(gh, gw)], src_hw=[(oh, ow)], dst_hw=[(h, w)], cs=cs, cd=cd,
+                          cd_pad=cd_pad or cd, ldd=ldd, kh=k, kw=k, stride=1, pad=pad, mode=1, os=2, flags=flags,
+                          addend=(raw(addend) + off * (lda or cd) * 2) if addend is not None else None, lda=lda or cd,
+                          mask=(raw(mask) + off * (ldm or cd) * 2) if mask is not None else None, ldm=ldm or cd, workspace=workspace,
+                          cs_real=cs_real)
+            d._keep = d._keep + (dy, dst, mask, addend)
+            out.append(d)
+    return out
+
+
 def pair_desc(a, wa, mid, wb, out, *, m, p, lda=None, ldmid=None, ldo=None, scale1=None, bias1=None, addend=None, ldadd=0, mask1=None,
               ldm1=0, relu1=False, scale2=None, bias2=None, mask2=None, ldm2=0, relu2=False):
     """dsl_conv1x1_pair descriptor: mid = epi1(a . wa^T), out = epi2(mid . wb^T); wa [4p][p], wb [p][4p] bf16."""

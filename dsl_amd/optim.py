@@ -137,6 +137,8 @@ class FlatSGD:
                     if (info['main'] or never != 0) and tgt is not cur:
                         tgt.wait_stream(cur)
                 o4, o2, o1 = lo * 4, lo * 2, lo
+                if os.environ.get('DSL_SKIP_SGD'):          # step-level ablation (tools/step_ablation.sh): timing only
+                    continue
                 L.check(L.lib.dsl_sgd_step(C.c_void_p(st.train.data_ptr() + o4), C.c_void_p(st.grad.data_ptr() + o4),
                                            C.c_void_p(self.momentum_buf.data_ptr() + o4), C.c_void_p(st.train16.data_ptr() + o2),
                                            C.c_void_p(st.group.data_ptr() + o1), hi - lo, lr, self.momentum, self.weight_decay, blr,

@@ -319,6 +319,15 @@ class ParamStore:
                     continue      # fed by frozen layer1: no data gradient needed
                 lay[s.name] = (off, s.cin_store * s.k * s.k * s.cout_pad)
                 off += _round_up(lay[s.name][1], 8)
+                if s.k == 3 and s.stride == 2:
+                    # + the four parity-class packs of its data gradient (ops.dgrad_s2_descs): [Cin][k_c * k_c][CoutPad], k_c = 1 for
+                    # the even-even pixels, 2 for the rest
+                    from .ops import s2_class
+                    for py in (0, 1):
+                        for px in (0, 1):
+                            k_c = s2_class(py, px)[0]
+                            lay[f'{s.name}#s2{py}{px}'] = (off, s.cin_store * k_c * k_c * s.cout_pad)
+                            off += _round_up(lay[f'{s.name}#s2{py}{px}'][1], 8)
             lay['head.cls'] = (off, 256 * 9 * 128)
             off += 256 * 9 * 128
             lay['head.regctr'] = (off, 256 * 9 * 64)
@@ -411,12 +420,21 @@ class ParamStore:
                 elif name == 'head.regctr':
                     w, co, cop, taps, cin, sc = self.tview('head.regctr_w'), 5, 64, 9, 256, None
                 else:
-                    s = self.convs[name]
-                    w, co, cop, taps, cin = self.tview(name + '.weight'), s.cout, s.cout_pad, s.k * s.k, s.cin_store
+                    s = self.convs[name.split('#')[0]]
+                    w, co, cop, taps, cin = self.tview(s.name + '.weight'), s.cout, s.cout_pad, s.k * s.k, s.cin_store
                     sc = self.bn_scale[self.bn_off[s.bn]:] if s.bn else None
+                tapmap = 0
+                if '#s2' in name:         # a parity-class pack: k_c * k_c out taps selected from the 9 source taps
+                    from .ops import s2_class
+                    k_c, _, srcs = s2_class(int(name[-2]), int(name[-1]))
+                    tapmap = 9 << 16
+                    for t, src in enumerate(srcs):
+                        tapmap |= (src if src >= 0 else 0xF) << (4 * t)
+                    taps = k_c * k_c
                 it = L.PackItem()
                 it.w, it.scale, it.out = w.data_ptr(), (sc.data_ptr() if sc is not None else 0), self.wT16.data_ptr() + off * 2
                 it.cout, it.cout_pad, it.taps, it.cin = co, cop, taps, cin
+                it.tapmap = tapmap
                 it.tiles_ci, it.tiles_co, it.block_start = (cin + 63) // 64, (cop + 63) // 64, start     # 64x64 tiles (optim.hip)
                 start += it.tiles_ci * it.tiles_co * taps
                 items.append(it)

@@ -428,7 +428,10 @@ int dsl_pack_dgrad(const float* w, const float* scale, void* out, int cout, int 
 typedef struct dsl_pack_item {
   const float* w; const float* scale; void* out;
   int32_t cout, cout_pad, taps, cin;
-  int32_t block_start, tiles_ci, tiles_co, pad_;       /* 64x64 (cout x cin) tiles; block_start: prefix sum of tiles_ci*tiles_co*taps */
+  int32_t block_start, tiles_ci, tiles_co;             /* 64x64 (cout x cin) tiles; block_start: prefix sum of tiles_ci*tiles_co*taps */
+  int32_t tapmap;   /* 0: out tap t = source tap t of `taps`.  Else a tap SELECTION (the parity-class packs of a stride-2 3x3 data
+                     * gradient): bits 16-23 = taps of the source weight (9), nibble t (bits 4t..4t+3) = source tap of out tap t,
+                     * 0xF = a zero tap; `taps` (<= 4) counts the OUT taps */
 } dsl_pack_item;
 int dsl_pack_dgrad_batched(const dsl_pack_item* items_dev, int n, int total_blocks, void* stream);
 

@@ -865,3 +865,51 @@ def test_full_size_layer3_block_wgrad_and_dgrad(K):
         sync()
         err = float((from_nhwc(dx) - ref).abs().max())
         assert err <= 2.0 ** -7 * float(ref.abs().max()), ((ci, co, k), err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 128, 20, 28), (1, 64, 128, 13, 21), (3, 256, 256, 10, 14), (2, 128, 64, 7, 9)])
+def test_dgrad_3x3_stride2_as_four_parity_class_convolutions(K, shape):
+    """ops.dgrad_s2_descs: the data gradient of a 3x3 / 2 / pad 1 convolution as four stride-1 transposed convolutions over the dY
+    grid (1x1 for the even-even pixels, 2x2 for the rest) scattered with output stride 2 == autograd's input gradient, with the ReLU
+    mask of the consumer applied last; even and odd image sizes; and == the general strided gather it replaces."""
+    L, ops = K
+    N, Ci, Co, H, W = shape
+    g = torch.Generator().manual_seed(H * W + Ci)
+    x = rnd(N, Ci, H, W, g=g).requires_grad_()
+    w = rnd(Co, Ci, 3, 3, g=g, scale=1 / math.sqrt(Co * 9))
+    y = F.conv2d(x, w, None, 2, 1)
+    Ho, Wo = y.shape[2:]
+    dy = rnd(N, Co, Ho, Wo, g=g)
+    y.backward(dy)
+    msk = rnd(N, Ci, H, W, g=g)
+    ref = x.grad * (msk > 0)
+    cy = (Co + 63) // 64 * 64
+    dyp = torch.zeros(N, Ho, Wo, cy)
+    dyp[..., :Co] = dy.permute(0, 2, 3, 1)
+    dyp = dyp.bfloat16().cuda()
+    packs = {}
+    for py in (0, 1):
+        for px in (0, 1):
+            k, pad, taps = ops.s2_class(py, px)
+            pk = torch.zeros(Ci, k * k, cy)
+            for t, src in enumerate(taps):
+                if src >= 0:
+                    pk[:, t, :Co] = w[:, :, src // 3, src % 3].t()
+            packs[(py, px)] = pk.bfloat16().cuda()
+    dx = torch.full((N, H, W, Ci), float('nan'), dtype=torch.bfloat16, device='cuda')
+    m = nhwc(msk)
+    descs = ops.dgrad_s2_descs(dyp, {k_: v.data_ptr() for k_, v in packs.items()}, dx, n=N, dy_hw=(Ho, Wo), dst_hw=(H, W), cs=cy, cd=Ci,
+                               mask=m, ldm=Ci, flags=L.CONV_MASK_LAST)
+    assert len(descs) == 4
+    for d in descs:
+        L.check(L.lib.dsl_conv2d(C.byref(d), L.stream_ptr()), 'dsl_conv2d')
+    sync()
+    got = from_nhwc(dx)
+    assert torch.isfinite(got).all()                       # every pixel belongs to exactly one class
+    assert torch.allclose(got, ref, rtol=1e-2, atol=2e-2), (got - ref).abs().max()
+    # the strided gather it replaces (conv_glds): same result up to the bf16 rounding of differently ordered fp32 sums
+    dx2 = torch.empty(N, H, W, Ci, dtype=torch.bfloat16, device='cuda')
+    ops.conv2d(dyp, pack_w_dgrad(w, cy), dx2, n=N, grid=[(H, W)], src_hw=[(Ho, Wo)], dst_hw=[(H, W)], cs=cy, cd=Ci, cd_pad=Ci, ldd=Ci,
+               kh=3, kw=3, stride=2, pad=1, mode=1, mask=m, ldm=Ci, flags=L.CONV_MASK_LAST)
+    sync()
+    assert torch.allclose(from_nhwc(dx2), got, rtol=1e-2, atol=2e-2)
