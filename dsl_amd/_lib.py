@@ -32,6 +32,7 @@ OP_PAIR = 20
 OP_PROF = 21
 OP_QUANT_FP8, OP_QUANT_FP8_W, OP_FP8_COMB = 22, 23, 24
 OP_STEM_POOL = 25
+OP_BNECK64 = 26
 PROF_CLASSES = 8
 MAX_MULTI = 16
 SLOT_TAIL, SLOT_PREFIX = 13, 14     # pipelined frozen prefix: 'previous backward's data-gradient chain done', 'prefix of this step done'
@@ -109,6 +110,13 @@ class PackItem(C.Structure):
                 ('block_start', C.c_int32), ('tiles_ci', C.c_int32), ('tiles_co', C.c_int32), ('tapmap', C.c_int32)]
 
 
+class Bneck64Desc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('w1', C.c_void_p), ('w2', C.c_void_p), ('w3', C.c_void_p), ('wds', C.c_void_p),
+                ('s1', C.c_void_p), ('b1', C.c_void_p), ('s2', C.c_void_p), ('b2', C.c_void_p), ('s3', C.c_void_p), ('b3', C.c_void_p),
+                ('sds', C.c_void_p), ('bds', C.c_void_p),
+                ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('ld_x', C.c_int32), ('ld_out', C.c_int32)]
+
+
 class RlaDesc(C.Structure):
     _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 8), ('f', C.c_float * 2), ('rows', C.c_int64), ('p', C.c_void_p * 10)]
 
@@ -173,7 +181,7 @@ _SIGS = {
     'dsl_wgrad_multi_config': [_vp], 'dsl_wgrad_multi_table_bytes': [], 'dsl_wgrad_multi_workspace_bytes': [_vp, _vp, _i],
     'dsl_wgrad_multi_build': [_vp, _vp, _i, _vp, C.c_size_t, _vp, C.c_size_t], 'dsl_conv2d_wgrad_multi': [_vp, _vp, _vp], 'dsl_wgrad_multi_info': [_vp, _vp, _vp, _vp, _vp, _vp],
     'dsl_wgrad_plan_probe': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    'dsl_image_prep': [_vp, _i, _vp, _i, _i, _vp], 'dsl_conv1x1_pair': [_vp, _vp],
+    'dsl_image_prep': [_vp, _i, _vp, _i, _i, _vp], 'dsl_conv1x1_pair': [_vp, _vp], 'dsl_bottleneck64': [_vp, _vp],
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_stem_pool': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
     'dsl_conv3x3_c64_patch': [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_maxpool3x3s2_ld': [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -135,6 +135,7 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
       case DSL_OP_WGRAD_GROUP: rc = dsl_conv2d_wgrad_group((const dsl_wgrad_desc*)o.desc, o.i[0], stream); break;
       case DSL_OP_WGRAD_MULTI: rc = dsl_conv2d_wgrad_multi(o.p[0], o.p[1], stream); break;
       case DSL_OP_PAIR: rc = dsl_conv1x1_pair((const dsl_pair_desc*)o.desc, stream); break;
+      case DSL_OP_BNECK64: rc = dsl_bottleneck64((const dsl_bneck64_desc*)o.desc, stream); break;
       case DSL_OP_GN_FWD: rc = dsl_groupnorm_relu_fwd((const dsl_gn_desc*)o.desc, stream); break;
       case DSL_OP_GN_BWD: rc = dsl_groupnorm_relu_bwd((const dsl_gn_desc*)o.desc, stream); break;
       case DSL_OP_MAXPOOL: rc = dsl_maxpool3x3s2_ld(o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] > 0 ? o.i[4] : o.i[3], stream); break;

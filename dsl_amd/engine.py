@@ -416,11 +416,32 @@ class Plan:
                 f.join(self.BR)
                 split_open = False
             groups = [(0, (N + 1) // 2, 0), ((N + 1) // 2, N, self.BR)] if split else [(0, N, 0)]
+            # The frozen layer1: every bottleneck as ONE launch (dsl_bottleneck64, csrc/bneck.hip): no backward pass needs its
+            # intermediates, so a1 / a2 / the downsample identity never leave the CU.  OPT-IN (DSL_BNECK64=1): bit-identical, 246 vs 336 us
+            # alone (N = 2), but the step is 0.8 % SLOWER with it (421.2 vs 424.7 img/s, three alternations): one 129 KB / 494-register
+            # workgroup per CU shares its CU with nothing, and layer1 runs beside the previous backward pass (the lesson of 3.9 again).
+            fused1 = (li == 0 and planes == 64 and not split and not PAIR_FWD and os.environ.get('DSL_BNECK64', '0') != '0'
+                      and all(not cv[f'backbone.layer1.{b_}.conv1'].trainable for b_ in range(nb)))
             for b in range(nb):
                 p = f'backbone.layer{li + 1}.{b}'
                 c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
                 s = c1.stride
                 oh, ow = conv_out(h, 1, s, 0), conv_out(w, 1, s, 0)
+                if fused1 and s == 1:
+                    out = self.buf(p + '.out', N, oh, ow, planes * 4)
+                    dsp = cv[p + '.downsample.0'] if b == 0 else None
+                    (s1_, b1_), (s2_, b2_), (s3_, b3_) = st.bn_ptrs(c1.bn), st.bn_ptrs(c2.bn), st.bn_ptrs(c3.bn)
+                    sd_, bd_ = st.bn_ptrs(dsp.bn) if dsp is not None else (None, None)
+                    bd = ops.bneck64_desc(x, out, st.w16_ptr(c1), st.w16_ptr(c2), st.w16_ptr(c3), s1_, b1_, s2_, b2_, s3_, b3_, n=N, h=h, w=w,
+                                          cin=int(x.shape[-1]), ld_x=int(x.shape[-1]), ld_out=planes * 4,
+                                          wds=st.w16_ptr(dsp) if dsp is not None else None, sds=sd_, bds=bd_)
+                    f._add(L.OP_BNECK64, bd)
+                    if b == nb - 1:
+                        self._pp['c3'], self._pp['out'] = bd, out
+                    self.blocks.append(dict(prefix=p, xin=x, a1=None, a2=None, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
+                                            stage=li, b=b, planes=planes))
+                    x, h, w = out, oh, ow
+                    continue
                 a1 = self.bufs[p + '.a1'] if pair_done else self.buf(p + '.a1', N, oh, ow, planes)
                 a2 = self.buf(p + '.a2', N, oh, ow, planes)
                 out = self.buf(p + '.out', N, oh, ow, planes * 4)
@@ -944,7 +965,7 @@ class Plan:
         pre, rest = OpList(), OpList()
         pre.items, rest.items = f.items[:end], f.items[end:]
         if os.environ.get('DSL_SKIP_PREFIX_CONVS'):      # step-level ablation (tools/step_ablation.sh): layer1 costs nothing - timing only
-            pre.items = [o for o in pre.items if o.kind != L.OP_CONV]
+            pre.items = [o for o in pre.items if o.kind not in (L.OP_CONV, L.OP_BNECK64)]
         pre.keep = rest.keep = f.keep
         ws = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)      # the prefix runs beside the caller's convs: own split-K scratch
         for o in pre.items:
@@ -972,7 +993,10 @@ class Plan:
     def set_parity(self, p):
         """Points the five descriptors that touch layer1's output at buffer p."""
         ptr = self._l1out[p].data_ptr()
-        self._pp['c3'].dst = ptr
+        if isinstance(self._pp['c3'], L.Bneck64Desc):
+            self._pp['c3'].out = ptr
+        else:
+            self._pp['c3'].dst = ptr
         for d_, off in self._pp['c1'] + self._pp['ds']:
             d_.src = ptr + off
         self._pp['wg_c1'].x = ptr

@@ -189,6 +189,22 @@ typedef struct dsl_pair_desc {
 } dsl_pair_desc;
 int dsl_conv1x1_pair(const dsl_pair_desc* d, void* stream);
 
+/* A whole 64-plane bottleneck of the frozen layer1 (mmdet/models/backbones/resnet.py:262-301, caffe style, stride 1, eval-mode
+ * BatchNorms folded to (scale, bias); frozen by frozen_stages=1, :616-632) as ONE launch (csrc/bneck.hip):
+ *   out = relu( bn3(conv3( relu(bn2(conv2_3x3( relu(bn1(conv1(x))) ))) )) + identity ),
+ *   identity = x (cin == 256: blocks 1, 2) or bn_ds(conv_ds(x)) (cin == 64 with wds: block 0).
+ * x [n][h][w][ld_x] bf16 (cin real channels), out [n][h][w][ld_out] bf16 (256 channels); weights bf16 in the forward layout
+ * ([cout][kh][kw][cin]): w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wds [256][64] or NULL.  No intermediate is written: the
+ * launch is for frozen blocks (nothing is needed by a backward pass).  Bit-identical to the dsl_conv2d launches it replaces. */
+typedef struct dsl_bneck64_desc {
+  const void* x; void* out;
+  const void* w1; const void* w2; const void* w3; const void* wds;
+  const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3;
+  const float* sds; const float* bds;
+  int32_t n, h, w, cin, ld_x, ld_out;
+} dsl_bneck64_desc;
+int dsl_bottleneck64(const dsl_bneck64_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GPU data path
  * ---------------------------------------------------------------------------------------- */
@@ -522,6 +538,7 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
                                 * inv_act_scale = the float whose bits are l[1]) */
        DSL_OP_STEM_POOL = 25,  /* dsl_stem_pool(p[0] = img, p[1] = w_groups, l[0] / l[1] = scale / bias pointers, p[2] = out, i[0] = ld_out,
                                 * i[1..3] = n, h, w) */
+       DSL_OP_BNECK64 = 26,    /* desc = dsl_bneck64_desc -> dsl_bottleneck64 */
        DSL_OP_PROF = 21 };     /* phase mark (dsl_prof_enable(3) only, else a no-op): i[0] = class >= 4, i[1] = 0 begin | 1 end, l[0] / l[1] =
                                 * algorithmic FLOPs / bytes of the phase as IEEE doubles' bit patterns (begin only) */
 typedef struct dsl_op {

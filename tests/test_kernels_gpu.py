@@ -913,3 +913,51 @@ def test_dgrad_3x3_stride2_as_four_parity_class_convolutions(K, shape):
                kh=3, kw=3, stride=2, pad=1, mode=1, mask=m, ldm=Ci, flags=L.CONV_MASK_LAST)
     sync()
     assert torch.allclose(from_nhwc(dx2), got, rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('ds', [False, True])
+@pytest.mark.parametrize('shape', [(2, 32, 48), (1, 13, 21), (3, 37, 50), (1, 8, 16), (2, 200, 336)])
+def test_bottleneck64_fused(K, shape, ds):
+    """dsl_bottleneck64 (csrc/bneck.hip): a frozen layer1 bottleneck - conv1 1x1 -> BN -> ReLU -> conv2 3x3 -> BN -> ReLU -> conv3 1x1 ->
+    BN -> + identity (x, or the downsample convolution of block 0) -> ReLU - as ONE launch == the three / four dsl_conv2d launches it
+    replaces, bit for bit, and == fp32 torch within the bf16 storage error of the intermediates; ragged tiles and 2 x 200 x 336."""
+    L, ops = K
+    N, H, W = shape
+    cin = 64 if ds else 256
+    g = torch.Generator().manual_seed(H * W + cin)
+    x = rnd(N, cin, H, W, g=g)
+    w1, w2, w3 = rnd(64, cin, 1, 1, g=g, scale=1 / math.sqrt(cin)), rnd(64, 64, 3, 3, g=g, scale=1 / 24.0), rnd(256, 64, 1, 1, g=g, scale=1 / 8.0)
+    wd = rnd(256, 64, 1, 1, g=g, scale=1 / 8.0) if ds else None
+    aff = lambda c: ((torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.2).cuda())
+    (s1, b1), (s2, b2), (s3, b3) = aff(64), aff(64), aff(256)
+    sd, bd = aff(256) if ds else (None, None)
+    xd = nhwc(x)
+    p1, p2, p3 = pack_w(w1, 64), pack_w(w2, 64), pack_w(w3, 256)
+    pd = pack_w(wd, 256) if ds else None
+    # the separate launches
+    a1 = torch.empty(N, H, W, 64, dtype=torch.bfloat16, device='cuda')
+    a2 = torch.empty_like(a1)
+    ref = torch.empty(N, H, W, 256, dtype=torch.bfloat16, device='cuda')
+    hw = [(H, W)]
+    ops.conv2d(xd, p1, a1, n=N, grid=hw, src_hw=hw, dst_hw=hw, cs=cin, cd=64, cd_pad=64, ldd=64, kh=1, kw=1, scale=s1, bias=b1, flags=L.CONV_RELU_OUT)
+    ops.conv2d(a1, p2, a2, n=N, grid=hw, src_hw=hw, dst_hw=hw, cs=64, cd=64, cd_pad=64, ldd=64, kh=3, kw=3, pad=1, scale=s2, bias=b2, flags=L.CONV_RELU_OUT)
+    idt = xd
+    if ds:
+        idt = torch.empty_like(ref)
+        ops.conv2d(xd, pd, idt, n=N, grid=hw, src_hw=hw, dst_hw=hw, cs=64, cd=256, cd_pad=256, ldd=256, kh=1, kw=1, scale=sd, bias=bd)
+    ops.conv2d(a2, p3, ref, n=N, grid=hw, src_hw=hw, dst_hw=hw, cs=64, cd=256, cd_pad=256, ldd=256, kh=1, kw=1, scale=s3, bias=b3, addend=idt,
+               lda=256, flags=L.CONV_RELU_OUT)
+    out = torch.full((N, H, W, 256), float('nan'), dtype=torch.bfloat16, device='cuda')
+    ops.bottleneck64(xd, out, p1, p2, p3, s1, b1, s2, b2, s3, b3, n=N, h=H, w=W, cin=cin, wds=pd, sds=sd, bds=bd)
+    sync()
+    assert torch.isfinite(out.float()).all()
+    diff = (out.float() - ref.float()).abs()
+    assert torch.equal(out, ref), (float(diff.max()), int((diff > 0).sum()), out.numel())
+    # fp32 torch, with the intermediates rounded where they are stored
+    bn = lambda t, s_, b_: t * s_.cpu()[None, :, None, None] + b_.cpu()[None, :, None, None]
+    t1 = bf(F.relu(bn(F.conv2d(x, w1), s1, b1)))
+    t2 = bf(F.relu(bn(F.conv2d(t1, w2, None, 1, 1), s2, b2)))
+    ident = bf(bn(F.conv2d(x, wd), sd, bd)) if ds else x
+    want = F.relu(bn(F.conv2d(t2, w3), s3, b3) + ident)
+    got = from_nhwc(out)
+    assert torch.allclose(got, want, rtol=2e-2, atol=2e-2 * float(want.abs().max())), float((got - want).abs().max())
