@@ -524,6 +524,11 @@ class FCOS(nn.Module):
                     L.check(L.lib.dsl_cast_bf16(L.ptr(g), L.ptr(g16), hi - lo, csp), 'dsl_cast_bf16')
                     if self.rccl is not None:
                         L.check(L.lib.dsl_allreduce_bucket_bf16(self.rccl.comm, L.ptr(g16), hi - lo, csp), 'dsl_allreduce_bucket_bf16')
+                    elif dist.get_backend(self.dist_group) == 'gloo':
+                        # (the CPU-side test carrier has no bf16 sum: the bf16-rounded values are added in fp32 and rounded back)
+                        t32 = g16.float()
+                        dist.all_reduce(t32, group=self.dist_group, async_op=True).wait()
+                        g16.copy_(t32)
                     else:
                         dist.all_reduce(g16, group=self.dist_group, async_op=True).wait()      # (orders cs behind the collective)
                     L.check(L.lib.dsl_cast_f32(L.ptr(g16), L.ptr(g), hi - lo, csp), 'dsl_cast_f32')

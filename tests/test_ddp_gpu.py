@@ -227,3 +227,70 @@ def test_bench_two_rank_dry_run():
     assert j['cpu_baseline'] is None and np.isfinite(j['final_losses']['loss'])
     comm = j['extra']['comm']          # per gradient bucket: [MB, all-reduce start, done] in ms from the start of the step
     assert len(comm['buckets']) == 4 and all(b['done_ms'] >= b['start_ms'] >= 0 for b in comm['buckets'])
+
+
+def _worker_opts(rank, world, port, q):
+    """Two ranks, bf16 gradient buckets + a clipping optimizer: the second step takes the norm from the per-bucket partial sums."""
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from dsl_amd import _lib as L
+        from dsl_amd.optim import FlatSGD
+        from dsl_amd.parallel import HipDistributedDataParallel
+        model = build()
+        ddp = HipDistributedDataParallel(model, grad_dtype='bf16')
+        assert model.grad_bf16 and os.environ.get('DSL_WGRAD_SLOTS') == '112'
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
+                      grad_clip=dict(max_norm=1.0, norm_type=2))
+        norms = []
+        for it in range(2):
+            out = ddp.train_step(make_batch(rank), opt)
+            out['loss'].backward()
+            used_partials = bool(model._partials_valid)
+            opt.step()
+            torch.cuda.synchronize()
+            ref = torch.zeros(1, device='cuda')
+            ws = torch.zeros(1024, device='cuda')
+            L.check(L.lib.dsl_sumsq_det(L.ptr(model.store.grad), model.store.n_train, L.ptr(ref), L.ptr(ws), L.stream_ptr()))
+            torch.cuda.synchronize()
+            norms.append((used_partials, float(opt.gnorm_sq), float(ref)))
+        w = model.store.train.detach().cpu()
+        g = model.store.grad.detach().cpu()
+        lst = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(lst, w)
+        same = all(torch.equal(t, lst[0]) for t in lst)
+        bf16_valued = bool(torch.equal(g, g.bfloat16().float()))       # the reduced gradient came back through bf16
+        dist.destroy_process_group()
+        q.put((rank, 'ok', same, norms, bf16_valued))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc(), False, None, None))
+
+
+def test_ddp_bf16_buckets_and_clip_norm_in_pieces():
+    """HipDistributedDataParallel(grad_dtype='bf16') + FlatSGD(grad_clip=...) on two ranks (gloo, one GPU): the gradient buckets cross
+    the wire as bf16 copies (what comes back is bf16-valued, identical on both ranks), the first step's clipping norm is the
+    whole-buffer sum, the second step's is folded from the per-bucket partial sums taken on the communication stream - both equal
+    the fixed-order sum over the reduced gradient buffer to fp32 summation-order noise - and the ranks end with identical weights."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_opts, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=200) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.kill()
+    assert all(r[1] == 'ok' for r in res), [r[1] for r in res]
+    assert all(r[2] for r in res), 'ranks hold different weights'
+    assert all(r[4] for r in res), 'the reduced gradient is not bf16-valued: the bucket did not go through the bf16 copy'
+    for r in res:
+        (p0, n0, ref0), (p1, n1, ref1) = r[3]
+        assert not p0 and p1, (p0, p1)                  # step 1: whole-buffer norm; step 2: per-bucket partial sums
+        assert n0 == pytest.approx(ref0, rel=1e-5) and n1 == pytest.approx(ref1, rel=1e-5), r[3]
+    assert res[0][3] == res[1][3]
