@@ -88,7 +88,7 @@ def test_detect_with_more_valid_pairs_than_the_candidate_buffer(golden):
     spec.loader.exec_module(M)
     d = golden('detect_many.npz')
     cls, reg, ctr = M.inputs()
-    assert M.digest(cls + reg + ctr) == pytest.approx(float(d['digest']), rel=1e-12), 'the seeded inputs differ from the fixture\'s'
+    assert M.digest(cls + reg + ctr) == pytest.approx(float(d['digest']), rel=1e-7), 'the seeded inputs differ from the fixture\'s'      # (exp() differs in the last bits between hosts)
     sizes, strides, B, shp = M.SIZES, M.STRIDES, M.B, M.SHAPE
     n_valid = [int((torch.cat([c[i].permute(1, 2, 0).reshape(-1, 80) for c in cls]).sigmoid() > 0.05).sum()) for i in range(B)]
     assert min(n_valid) > 4 * 16384, n_valid
