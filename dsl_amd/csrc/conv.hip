@@ -3601,6 +3601,19 @@ static int wgrad_splits_for(const dsl_wgrad_desc* d, int count) {
   if (splits > max_by_k) splits = max_by_k;
   if (splits < 1) splits = 1;
   if (splits > 256) splits = 256;
+  {
+    // No EMPTY split (round 4): split i covers stages [i * tps, (i + 1) * tps), tps = ceil(stages / splits); with 9 or more splits
+    // and few stages the last ones start past the end - (splits - 1) * tps >= stages, e.g. 129 stages in 16 splits of 9 - their
+    // workgroups return without writing their partial tile and the reduce pass adds whatever the scratch buffer held.  The comment
+    // "cannot happen with the host's split factors" in the kernels was wrong for this corner; the planner of the multi launches
+    // normalises the same way (plan_norm_splits).
+    long long px = 0;
+    for (int s = 0; s < d->nseg; ++s) px += (long long)d->n * d->gh[s] * d->gw[s];
+    const int ks = wgrad_v3_ok(d, cfg) ? kWgV3KS : 64;
+    const int stages = (int)((px + ks - 1) / ks);
+    const int tps = (stages + splits - 1) / splits;
+    splits = (stages + tps - 1) / tps;
+  }
   return splits;
 }
 

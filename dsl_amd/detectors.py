@@ -208,6 +208,27 @@ class FCOSHead(nn.Module):
         return w
 
 
+# One stream per ROLE and device for the whole process, not per model instance (round 4).  Streams are dealt onto four hardware
+# queues in creation order; which streams share a queue moves the step by up to 20 % (350 vs 427 img/s for one stream
+# created too early).  The first detector of a process creates the streams in the order the measured layout came about; every later
+# instance (a second model in a notebook, bench.py's extra timings, student + teacher) must find the SAME streams instead of drawing
+# new ones from torch's pool - measured: the same loop on a second model in one process ran at 433 or 362 img/s depending on which
+# pool stream it happened to get (profiles/r04_td_first.txt).
+_ROLE_STREAMS = {}
+
+
+def role_stream(role, device=None, priority=0):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (role, dev)
+    if os.environ.get('DSL_ROLE_STREAMS', '1') == '0':          # (experiment: a stream per instance, as before round 4)
+        return torch.cuda.Stream(device=dev, priority=priority) if priority else torch.cuda.Stream(device=dev)
+    st = _ROLE_STREAMS.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=dev, priority=priority) if priority else torch.cuda.Stream(device=dev)
+        _ROLE_STREAMS[key] = st
+    return st
+
+
 class _LossDict(OrderedDict):
     """The loss dict of forward_train; `.vec` (optional) holds the same scalars as one graph-connected tensor."""
     vec = None
@@ -393,7 +414,7 @@ class FCOS(nn.Module):
                 # streams share four hardware queues in creation order: DSL_PREFIX_SKIP = n takes n streams from torch's pool first,
                 # which moves the prefix stream to another hardware queue (experiment)
                 self._skipped_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get('DSL_PREFIX_SKIP', '0')))]
-                self._prefix_stream = torch.cuda.Stream(priority=prio) if prio else torch.cuda.Stream()
+                self._prefix_stream = role_stream('prefix', self.store.device, prio)
             if img.is_cuda:
                 img.record_stream(self._prefix_stream)
             ready = getattr(img, '_dsl_ready', None)          # event of the image's producer (dsl_amd.data.mark_ready)
@@ -471,7 +492,7 @@ class FCOS(nn.Module):
             return dist.all_reduce(t, group=self.dist_group, async_op=True)
         from .parallel import StreamWork
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream()
+            self._comm_stream = role_stream('comm', self.store.device)
         cs = self._comm_stream
         if after_current:
             cs.wait_stream(torch.cuda.current_stream())
@@ -490,7 +511,7 @@ class FCOS(nn.Module):
         ddp = self.world_size > 1 and not self.comm_off
         on_gpu = self.store.grad.is_cuda
         if ddp and on_gpu and self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream()
+            self._comm_stream = role_stream('comm', self.store.device)
         self._partials_valid = False
         nb = 0
         for ol, info in plan.bwd_segments:

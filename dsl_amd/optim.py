@@ -83,9 +83,16 @@ class FlatSGD:
 
     def step(self):
         st = self.store
+        fresh = False
         if self.momentum_buf is None:
+            # (zeros, queued on the CALLER's stream: the per-bucket path below runs on other streams that are not ordered behind the
+            # caller's - `fresh` makes them wait for this fill.  Round 4: without that wait the fill could land AFTER the first
+            # bucket's update had written its momentum - that bucket then started its second step from zero momentum; which buckets,
+            # if any, depended on how far the GPU lagged behind the host: found as a flaky bit-exactness test once the optimizer's
+            # stream was shared between model instances)
             self.momentum_buf = torch.zeros_like(st.train)
             self.steps = 0
+            fresh = True
         elif (self.momentum_buf.device != st.device or self.momentum_buf.shape != st.train.shape
               or getattr(self, '_loaded_regions', None) is not None):
             self._adopt_loaded_state()
@@ -117,9 +124,13 @@ class FlatSGD:
                 os_ = None
             else:
                 if getattr(self, '_opt_stream', None) is None:
-                    self._opt_stream = torch.cuda.Stream()
+                    from .detectors import role_stream          # one optimizer stream per device and process (hardware queues)
+                    self._opt_stream = role_stream('optimizer', st.device)
                 os_ = self._opt_stream
             pend = list(getattr(self.model, '_pending', []) or [])
+            if fresh:
+                for s_ in ([self._side1] if deferred else [os_]):
+                    s_.wait_stream(cur)          # the momentum buffer's zero fill (see above)
             for k, info in enumerate(infos):
                 lo, hi = info['bucket']
                 tgt = (self._side1 if info.get('deferred') else cur) if deferred else os_

@@ -567,7 +567,8 @@ class UnlabelPredHook(Hook):
             # student's next step (the reference refreshes `preload` iterations ahead of the loader for the same reason); it
             # starts behind everything queued so far (the teacher's EMA update included), the next EMA update waits for it
             if self._sweep_stream is None:
-                self._sweep_stream = torch.cuda.Stream()
+                from .detectors import role_stream
+                self._sweep_stream = role_stream('sweep')
             ss = self._sweep_stream
             ss.wait_stream(torch.cuda.current_stream())
             imgs.record_stream(ss)

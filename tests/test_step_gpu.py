@@ -358,3 +358,37 @@ def test_deferred_plan_with_a_clipping_optimizer_still_sees_every_gradient(golde
         torch.cuda.synchronize()
         res.append(model.store.train.clone().cpu())
     assert torch.equal(res[0], res[1])
+
+
+def test_first_optimizer_step_keeps_every_buckets_momentum():
+    """Round 4: the momentum buffer is created (zero-filled on the caller's stream) inside the first `step()`, while the per-bucket
+    updates run on other streams as soon as their bucket's weight gradients are done - a bucket updated BEFORE the fill landed had its
+    momentum wiped and started its second step from zero.  After one step without clipping, every bucket's momentum must be the
+    first-step rule's `grad + wd * param` (torch.optim.SGD: buf = d_p), in particular non-zero wherever the gradient is."""
+    from dsl_amd.optim import FlatSGD
+    from oracle import fcos_oracle as O
+    rng = np.random.RandomState(11)
+    g = torch.Generator().manual_seed(11)
+    H, W, B = 256, 320, 2
+    img = (torch.randn(B, 3, H, W, generator=g) * 40).cuda()
+    gtb = [T(O.synth_boxes(rng, 4, H=H, W=W, lo=8, hi=200)) for _ in range(B)]
+    gtl = [T(rng.randint(0, 80, len(b)).astype('int64')) for b in gtb]
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), scale_factor=1.0)] * B
+    for rep in range(3):                      # (a race: a few fresh optimizers, the GPU kept busy in front of each first step)
+        model = build()
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+        p0 = model.store.train.clone()
+        for _ in range(3):                    # queue work ahead of the step under test so that the GPU lags behind the host
+            model.forward_train(img, metas, gtb, gtl)
+        out = model.train_step(dict(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl), opt)
+        out['loss'].backward()
+        opt.step()
+        torch.cuda.synchronize()
+        st = model.store
+        grad, mom = st.grad, opt.momentum_buf
+        wd = torch.where(st.group.bool(), torch.zeros_like(p0), torch.full_like(p0, 1e-4))
+        want = grad + wd * p0
+        err = (mom - want).abs().max()
+        assert float(err) <= 1e-6 * float(want.abs().max()) + 1e-12, (rep, float(err))
+        for lo, hi in st.grad_buckets():
+            assert float(mom[lo:hi].abs().sum()) > 0, (rep, lo, hi)
