@@ -96,6 +96,7 @@ class FlatSGD:
         elif (self.momentum_buf.device != st.device or self.momentum_buf.shape != st.train.shape
               or getattr(self, '_loaded_regions', None) is not None):
             self._adopt_loaded_state()
+            fresh = True          # (copied into place on the caller's stream just now: the same ordering as for the zero fill)
         if self.gnorm_sq is None or self.gnorm_sq.device != st.device:
             self.gnorm_sq = torch.zeros(1, device=st.device)
         sp = L.stream_ptr()
