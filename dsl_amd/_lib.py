@@ -52,7 +52,8 @@ class ConvDesc(C.Structure):
                 ('mode', C.c_int32), ('os', C.c_int32), ('flags', C.c_int32),
                 ('src', C.c_void_p), ('wgt', C.c_void_p), ('dst', C.c_void_p),
                 ('scale', C.c_void_p), ('bias', C.c_void_p), ('addend', C.c_void_p), ('mask', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('cs_real', C.c_int32), ('lds', C.c_int32)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('cs_real', C.c_int32), ('lds', C.c_int32),
+                ('gn_ws', C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -71,7 +72,8 @@ class GnDesc(C.Structure):
                 ('h', I5), ('w', I5), ('eps', C.c_float),
                 ('x', C.c_void_p), ('y', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
                 ('stats', C.c_void_p), ('dy', C.c_void_p), ('dx', C.c_void_p), ('dgamma', C.c_void_p),
-                ('dbeta', C.c_void_p), ('dbias', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('dbeta', C.c_void_p), ('dbias', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+                ('conv_stats', C.c_int32), ('pad_', C.c_int32)]
 
 
 class FcosDesc(C.Structure):
@@ -176,7 +178,7 @@ if hasattr(lib, 'dsl_detect_workspace_bytes'):
     lib.dsl_detect_workspace_bytes.restype = C.c_size_t
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
-    'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_workspace_bytes': [_vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
+    'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_workspace_bytes': [_vp], 'dsl_conv2d_gn_fusable': [_vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
     'dsl_wgrad_workspace_bytes': [_vp], 'dsl_wgrad_group_workspace_bytes': [_vp, _i], 'dsl_conv2d_wgrad_group': [_vp, _i, _vp],
     'dsl_wgrad_multi_config': [_vp], 'dsl_wgrad_multi_table_bytes': [], 'dsl_wgrad_multi_workspace_bytes': [_vp, _vp, _i],
     'dsl_wgrad_multi_build': [_vp, _vp, _i, _vp, C.c_size_t, _vp, C.c_size_t], 'dsl_conv2d_wgrad_multi': [_vp, _vp, _vp], 'dsl_wgrad_multi_info': [_vp, _vp, _vp, _vp, _vp, _vp],

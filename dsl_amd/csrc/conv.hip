@@ -46,6 +46,7 @@ struct ConvK {
   const float* bias;
   const uint16_t* addend;
   const uint16_t* mask;
+  float* gnws;                        // GroupNorm statistics records of the output (dsl_conv_desc.gn_ws), or null
 };
 
 __device__ __forceinline__ u32x4 relu_bf16x8(u32x4 v) {
@@ -838,6 +839,70 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvK& p, f32x16 (&acc)
             }
             *reinterpret_cast<u32x4*>(out + (long long)gp * p.ldd) = r;
           }
+        }
+      }
+      // ---- GroupNorm statistics of the tile (dsl_conv_desc.gn_ws; 8 channels per group, so a 16-byte chunk of the staged tile is
+      // one pixel of one group): per (segment, image) row of the level-major pixel axis that crosses this tile, sum and sum of
+      // squares of the ROUNDED values - what gn_stats_kernel would read back - reduced over the tile's pixels in a fixed order and
+      // written as one record per (row, pixel tile); gn_apply_kernel adds a row's records up in tile order.  Record layout:
+      // [64 floats of header: word 0 = BPX][segment * n + image][maxhw / 64 + 2 tiles][cd / 8 groups][2].
+      if (p.gnws) {
+        constexpr int RPT = T / GPR;
+        static_assert((long long)BPX * ROWH + T * 8 <= (long long)RING, "reduction scratch behind the staged tile");
+        static_assert(BPX >= 64, "the record count per row is sized for pixel tiles of at least 64");
+        float* red = reinterpret_cast<float*>(smem + BPX * ROWH);
+        const unsigned char* rd = smem + row0 * ROWH + cgp * 16;
+        const bool live = co0 + cgp * 8 < p.cd;
+        const int ngr = p.cd >> 3;
+        int maxhw = 0;
+#pragma unroll
+        for (int sg = 0; sg < DSL_MAX_SEG; ++sg)
+          if (sg < p.nseg) maxhw = max(maxhw, p.gh[sg] * p.gw[sg]);
+        const int nbk = maxhw / 64 + 2;
+        if (px0 == 0 && co0 == 0 && tid == 0) *reinterpret_cast<int*>(p.gnws) = BPX;
+        const int pend = min(px0 + BPX, totpx);
+        int cur = px0;
+#pragma nounroll
+        while (cur < pend) {
+          int seg, img, y_, x_;
+          decode_pixel(p, cur, seg, img, y_, x_);
+          const int hw = p.gh[seg] * p.gw[seg];
+          const int rs = p.pxstart[seg] + img * hw;
+          const int lo = cur - px0, hi = min(rs + hw, pend) - px0;
+          float s = 0.f, ss = 0.f;
+          if (live) {
+#pragma unroll 4
+            for (int n_ = 0; n_ < NITP; ++n_) {
+              const int r_ = row0 + n_ * RPT;
+              if (r_ >= lo && r_ < hi) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(rd + n_ * RPT * ROWH);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float a = bflo(v[e]), b = bfhi(v[e]);
+                  s += a + b;
+                  ss += a * a + b * b;
+                }
+              }
+            }
+          }
+          red[tid * 2] = s;
+          red[tid * 2 + 1] = ss;
+          lds_barrier();
+          if (tid < GPR && co0 + tid * 8 < p.cd) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k_ = 0; k_ < RPT; ++k_) {
+              a += red[(k_ * GPR + tid) * 2];
+              b += red[(k_ * GPR + tid) * 2 + 1];
+            }
+            const int si = seg * p.n + img;
+            const int j = px0 / BPX - rs / BPX;
+            float* dst = p.gnws + 64 + (((long long)si * nbk + j) * ngr + (co0 >> 3) + tid) * 2;
+            dst[0] = a;
+            dst[1] = b;
+          }
+          lds_barrier();
+          cur = rs + hw;
         }
       }
     }
@@ -3120,7 +3185,7 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
       if (smallc && c != 4) continue;                // the 8-channel-source variant is instantiated for the 64x256 tile
       if ((d->flags & DSL_CONV_FP8) && c != 0 && c != 1 && c != 3) continue;     // fp8: instantiated for 256x192, 256x128, 128x128
       for (int sp = 1; sp <= 16; ++sp) {
-        if (sp > 1 && (smallc || (d->flags & DSL_CONV_FP8))) break;
+        if (sp > 1 && (smallc || (d->flags & DSL_CONV_FP8) || d->gn_ws)) break;
         if (sp > 1 && (!d->workspace || sp > ktiles / 2 || (size_t)sp * px * d->cd_pad * 4 > d->workspace_bytes)) break;
         if (force_split > 1 && sp != force_split) continue;
         const double t = conv_cost_us(c, px, d->cd_pad, ktiles, sp, out_f32);
@@ -3167,7 +3232,26 @@ long long conv_pixels(const dsl_conv_desc* d) {
   for (int s = 0; s < d->nseg; ++s) px += (long long)d->n * d->gh[s] * d->gw[s];
   return px;
 }
+
+// Would a launch of `d` with gn_ws set leave the GroupNorm records?  Only the pipelined kernel's in-register ("pure") epilogue
+// writes them: bf16 output on the compute grid's own pixels, nothing added, one launch (no split-K).
+bool conv_gn_ok(const dsl_conv_desc* d) {
+  if (d->nseg < 1 || d->nseg > DSL_MAX_SEG) return false;
+  if (d->flags & (DSL_CONV_SMALL_C | DSL_CONV_FP8 | DSL_CONV_OUT_F32 | DSL_CONV_ADD_UPSAMPLE | DSL_CONV_RELU_IN)) return false;
+  if (d->cs % 64 || d->cd % 8 || d->cd_pad % 64 || d->os != 1 || d->addend) return false;
+  if (d->mask && ((d->flags & DSL_CONV_MASK_FIRST) || ((d->flags & DSL_CONV_MASK_LAST) && (d->flags & DSL_CONV_RELU_OUT)))) return false;
+  for (int s = 0; s < d->nseg; ++s)
+    if (d->gh[s] != d->dh[s] || d->gw[s] != d->dw[s]) return false;
+  if (conv_v2_only(d) || getenv("DSL_CONV_V2") || getenv("DSL_CONV_KT") || getenv("DSL_CONV_LOADER")) return false;
+  dsl_conv_desc t = *d;
+  t.gn_ws = (void*)1;
+  int pick, splits;
+  conv_choose(&t, conv_pixels(d), d->kh * d->kw * (d->cs / 64), &pick, &splits);
+  return pick >= 0 && splits == 1;
+}
 }  // namespace
+
+extern "C" int dsl_conv2d_gn_fusable(const dsl_conv_desc* d) { return d && conv_gn_ok(d) ? 1 : 0; }
 
 extern "C" size_t dsl_conv2d_workspace_bytes(const dsl_conv_desc* d) {
   if (!d || d->nseg < 1 || d->nseg > DSL_MAX_SEG || (d->flags & DSL_CONV_SMALL_C) || d->cs % 64) return 0;
@@ -3245,6 +3329,9 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   k.src = (const uint16_t*)d->src; k.wgt = (const uint16_t*)d->wgt; k.dst = d->dst;
   k.scale = d->scale; k.bias = d->bias;
   k.addend = (const uint16_t*)d->addend; k.mask = (const uint16_t*)d->mask;
+  DSL_CHECK(!d->gn_ws || conv_gn_ok(d), "dsl_conv2d: gn_ws is set but this launch cannot write GroupNorm records "
+            "(ask dsl_conv2d_gn_fusable first)");
+  k.gnws = (float*)d->gn_ws;
 
   hipStream_t st = (hipStream_t)stream;
   // ---- 3x3 / 1, 64 -> 64, BatchNorm + ReLU epilogue (layer1's middle convolutions): the activation-stationary kernel of patch3.hip

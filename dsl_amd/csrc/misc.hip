@@ -75,6 +75,9 @@ struct GnK {
   float* dbeta;
   float* dbias;                  // optional: gradient of the bias of the convolution that produced x = sum_p dx
   float* ws;                     // partial records [nseg*n][nblk][rec]; rec = 2*groups (fwd) or 3*c + 2*groups (bwd)
+  int conv_nbk;                  // > 0: the forward records were left by the producing convolution's epilogue (conv.hip
+                                 // conv_tile_epilogue): [64 floats of header, word 0 = its pixel tile][nseg*n][conv_nbk][2*groups],
+                                 // a row's records indexed by pixel tile relative to the tile that holds the row's first pixel
 };
 
 constexpr int GN_PPB = 128;   // pixels per block
@@ -180,8 +183,15 @@ __global__ __launch_bounds__(GN_TA) void gn_apply_kernel(const GnK p) {
   const int hw = p.h[seg] * p.w[seg];
   const int px0 = blockIdx.x * GN_PPB;
   if (px0 >= hw) return;
-  const int nb = (hw + GN_PPB - 1) / GN_PPB;
-  gn_sum_records<GN_TA>(p.ws + (long long)si * p.nblk * (2 * p.groups), nb, 2 * p.groups, 2 * p.groups, sh, tot);
+  if (p.conv_nbk > 0) {
+    const int bpx = *reinterpret_cast<const int*>(p.ws);
+    const long long rs = p.off[seg] + (long long)img * hw;
+    const int nb = (int)((rs + hw - 1) / bpx - rs / bpx) + 1;
+    gn_sum_records<GN_TA>(p.ws + 64 + (long long)si * p.conv_nbk * (2 * p.groups), nb, 2 * p.groups, 2 * p.groups, sh, tot);
+  } else {
+    const int nb = (hw + GN_PPB - 1) / GN_PPB;
+    gn_sum_records<GN_TA>(p.ws + (long long)si * p.nblk * (2 * p.groups), nb, 2 * p.groups, 2 * p.groups, sh, tot);
+  }
   const int cpr = p.c / 8, ppi = GN_TA / cpr;
   const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
   const int grp = chunk / p.cpg8;
@@ -502,6 +512,7 @@ int fill_gn(const dsl_gn_desc* d, GnK& k, long long* total_px) {
   int maxhw = 0;
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   k.nblk = (maxhw + GN_PPB - 1) / GN_PPB;
+  k.conv_nbk = 0;
   return 0;
 }
 
@@ -511,7 +522,9 @@ extern "C" size_t dsl_groupnorm_workspace_bytes(const dsl_gn_desc* d) {
   int maxhw = 0;
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   const size_t nblk = (maxhw + GN_PPB - 1) / GN_PPB;
-  return (size_t)d->nseg * d->n * nblk * (3 * (size_t)d->c + 2 * (size_t)d->groups) * sizeof(float);
+  const size_t own = (size_t)d->nseg * d->n * nblk * (3 * (size_t)d->c + 2 * (size_t)d->groups) * sizeof(float);
+  const size_t conv = 64 * sizeof(float) + (size_t)d->nseg * d->n * (maxhw / 64 + 2) * 2 * (size_t)d->groups * sizeof(float);
+  return own > conv ? own : conv;       // (the records of a producing convolution, dsl_conv_desc.gn_ws, fit as well)
 }
 namespace {
 int gn_check(const dsl_gn_desc* d, const char* who) {
@@ -564,7 +577,12 @@ extern "C" int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream) {
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   dim3 grid((maxhw + GN_PPB - 1) / GN_PPB, d->nseg * d->n);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_T), 0, st, k);
+  if (d->conv_stats) {
+    DSL_CHECK(d->c / d->groups == 8, "dsl_groupnorm_relu_fwd: conv_stats needs 8 channels per group (C=%d groups=%d)", d->c, d->groups);
+    k.conv_nbk = maxhw / 64 + 2;
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_T), 0, st, k);
+  }
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_TA), 0, st, k);
   DSL_LAUNCH_CHECK("gn forward");
   return 0;

@@ -315,6 +315,7 @@ class Plan:
         self.tower = {}
         # the two towers are independent chains: the regression tower (+ its predictor) runs on the side stream
         self.conv_ws_side = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
+        GN_FUSE = os.environ.get('DSL_GN_FUSE', '1') != '0'
         FSIDE = 2 if (os.environ.get('DSL_SIDE', '1') != '0' and not self.single_stream) else 0      # side stream 1 carries the weight gradients (and may be CU-masked)
         # phase marks for bench.py: 8 tower convs + 2 predictors over all M locations, 8 GroupNorm+ReLU passes
         self._head_flops = 2.0 * self.M * (8 * 256 * 2304 + (80 + 5) * 2304)
@@ -359,10 +360,15 @@ class Plan:
                     cd_ = self._conv(spec, xin, pre, N, ls, ls)
                 if side:
                     cd_.workspace, cd_.workspace_bytes = L.ptr(self.conv_ws_side), self.conv_ws_side.numel()
-                f.conv(cd_, side=side)
                 base = f'bbox_head.{tower}.{i}.gn'
                 gd = ops.gn_desc(pre, act, st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'), stats,
                                  self._gn_workspace('side' if side else 'main'), n=N, hw=ls)
+                # conv -> GN -> ReLU (ConvModule, anchor_free_head.py:104-133): the convolution's epilogue leaves the statistics
+                # records, GroupNorm is then ONE pass over the tensor (DSL_GN_FUSE=0: its own statistics pass)
+                if GN_FUSE and not f8 and L.lib.dsl_conv2d_gn_fusable(C.byref(cd_)):
+                    cd_.gn_ws = gd.workspace
+                    gd.conv_stats = 1
+                f.conv(cd_, side=side)
                 f.gn_fwd(gd, side=side)
                 lays.append(dict(spec=spec, xin=xin, pre=pre, act=act, stats=stats, gn=base))
                 xin = act

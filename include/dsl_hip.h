@@ -79,7 +79,15 @@ typedef struct dsl_conv_desc {
                                                       * algorithmic FLOP / byte counts of dsl_prof_* use it */
   int32_t lds;                                       /* 0 = cs; else the source's pixel stride in elements (>= cs, multiple of
                                                       * 8): the source is a channel slice [0, cs) of wider rows */
+  void* gn_ws;                                       /* NULL, or the `workspace` of the dsl_gn_desc that normalises this output
+                                                      * (8 channels per group, conv_stats = 1): the epilogue leaves the per-tile
+                                                      * statistics records there and dsl_groupnorm_relu_fwd skips its own
+                                                      * statistics pass (ConvModule conv -> GN -> ReLU, anchor_free_head.py:104-133);
+                                                      * legal only where dsl_conv2d_gn_fusable() says 1 */
 } dsl_conv_desc;
+
+/* 1 if a launch of `d` can write GroupNorm records (pipelined kernel, bf16 output on its own pixel grid, no split-K) */
+int dsl_conv2d_gn_fusable(const dsl_conv_desc* d);
 
 /* bytes of split-K scratch this conv would like (0 if it will not split); any smaller buffer is legal */
 size_t dsl_conv2d_workspace_bytes(const dsl_conv_desc* d);
@@ -306,6 +314,9 @@ typedef struct dsl_gn_desc {
   float* dbias;           /* fp32 [c] or NULL: sum over pixels of dx = gradient of the bias of the conv that made x */
   void* workspace;        /* >= dsl_groupnorm_workspace_bytes(d); private to this call until it completes */
   size_t workspace_bytes;
+  int32_t conv_stats;     /* forward: 1 = the convolution that produced x already left its statistics records in `workspace`
+                           * (dsl_conv_desc.gn_ws == workspace): one pass instead of two; needs c / groups == 8 */
+  int32_t pad_;
 } dsl_gn_desc;
 size_t dsl_groupnorm_workspace_bytes(const dsl_gn_desc* d);
 int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream);

@@ -654,6 +654,60 @@ def test_groupnorm_relu_fwd_bwd(K):
     assert torch.allclose(dbias.cpu(), ref_db, rtol=1e-2, atol=1e-2 * float(ref_db.abs().max()) + 1e-3), (dbias.cpu() - ref_db).abs().max()
 
 
+@pytest.mark.parametrize('N,sizes,force', [
+    (2, [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)], 0),          # every (level, image) row inside one or two pixel tiles
+    (3, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 0),       # rows that span many tiles, ragged ends
+    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 4),       # 128 x 128 tile (two cout tiles write one record)
+    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 7),       # 64 x 64 tile
+    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 3),       # 128 x 256 tile
+])
+def test_groupnorm_statistics_from_the_conv_epilogue(K, N, sizes, force):
+    """conv -> GN -> ReLU (ConvModule, anchor_free_head.py:104-133) with the statistics left by the convolution's epilogue
+    (dsl_conv_desc.gn_ws) against the two-pass GroupNorm on the same convolution output."""
+    L, ops = K
+    g = torch.Generator().manual_seed(41)
+    Cc = 256
+    P = sum(h * w for h, w in sizes) * N
+    x = _multiseg([rnd(N, Cc, h, w, g=g) for h, w in sizes])
+    w = (torch.randn(Cc, 9 * Cc, generator=g) * 0.03).bfloat16().cuda()
+    bias = (0.2 * torch.randn(Cc, generator=g)).cuda()
+    ga, be = (1 + 0.2 * torch.randn(Cc, generator=g)).cuda(), (0.3 * torch.randn(Cc, generator=g)).cuda()
+    outs = []
+    for fused in (0, 1):
+        pre = torch.zeros(P, Cc, dtype=torch.bfloat16, device='cuda')
+        y = torch.empty_like(pre)
+        stats = torch.empty(5 * N * 32, 2, device='cuda')
+        gd = ops.gn_desc(pre, y, ga, be, stats, n=N, hw=sizes)
+        cd = ops.conv_desc(x, w, pre, n=N, grid=sizes, src_hw=sizes, dst_hw=sizes, cs=Cc, cd=Cc, cd_pad=Cc, ldd=Cc, kh=3, kw=3,
+                           stride=1, pad=1, flags=force << 8, bias=bias)
+        if fused:
+            assert L.lib.dsl_conv2d_gn_fusable(C.byref(cd)) == 1
+            cd.gn_ws = gd.workspace
+            gd.conv_stats = 1
+            gd._keep[5].fill_(0xff)                   # (nothing relies on a zeroed workspace: an unwritten record would read NaN)
+        L.check(L.lib.dsl_conv2d(C.byref(cd), L.stream_ptr()), 'dsl_conv2d')
+        L.check(L.lib.dsl_groupnorm_relu_fwd(C.byref(gd), L.stream_ptr()), 'gn')
+        sync()
+        outs.append((pre.clone(), y.clone(), stats.clone()))
+        if fused:                                    # fixed-order reductions: a second run gives the same bits
+            L.check(L.lib.dsl_conv2d(C.byref(cd), L.stream_ptr()), 'dsl_conv2d')
+            L.check(L.lib.dsl_groupnorm_relu_fwd(C.byref(gd), L.stream_ptr()), 'gn')
+            sync()
+            assert torch.equal(y, outs[-1][1]) and torch.equal(stats, outs[-1][2])
+    (p0, y0, s0), (p1, y1, s1) = outs
+    assert torch.equal(p0, p1)                       # the convolution's own output does not change
+    assert torch.allclose(s0, s1, rtol=2e-5, atol=2e-6), (s0 - s1).abs().max()
+    d = (y0.float() - y1.float()).abs()
+    assert float(d.max()) <= 2 ** -7 * float(y0.float().abs().max()), float(d.max())
+    assert float((d > 0).float().mean()) < 0.01      # the same statistics up to fp32 summation order: rare 1-ulp flips only
+    # a split-K launch, an fp32 output or an addend cannot leave records: the query says so and the launch refuses
+    cd2 = ops.conv_desc(x, w, torch.empty(P, Cc, device='cuda'), n=N, grid=sizes, src_hw=sizes, dst_hw=sizes, cs=Cc, cd=Cc, cd_pad=Cc,
+                        ldd=Cc, kh=3, kw=3, stride=1, pad=1, flags=L.CONV_OUT_F32)
+    assert L.lib.dsl_conv2d_gn_fusable(C.byref(cd2)) == 0
+    cd2.gn_ws = gd.workspace
+    assert L.lib.dsl_conv2d(C.byref(cd2), L.stream_ptr()) != 0
+
+
 def test_maxpool_sum2x2_colsum(K):
     L, _ = K
     g = torch.Generator().manual_seed(5)
