@@ -53,7 +53,8 @@ class ConvDesc(C.Structure):
                 ('src', C.c_void_p), ('wgt', C.c_void_p), ('dst', C.c_void_p),
                 ('scale', C.c_void_p), ('bias', C.c_void_p), ('addend', C.c_void_p), ('mask', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('cs_real', C.c_int32), ('lds', C.c_int32),
-                ('gn_ws', C.c_void_p)]
+                ('gn_ws', C.c_void_p), ('gn_x', C.c_void_p), ('gn_gamma', C.c_void_p), ('gn_beta', C.c_void_p),
+                ('gn_stats', C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

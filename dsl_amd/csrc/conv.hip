@@ -47,6 +47,10 @@ struct ConvK {
   const uint16_t* addend;
   const uint16_t* mask;
   float* gnws;                        // GroupNorm statistics records of the output (dsl_conv_desc.gn_ws), or null
+  const uint16_t* gnx;                // not null: the output is dY of a GroupNorm + ReLU whose input was gnx; gnws takes the BACKWARD
+  const float* gngamma;               // records (what gn_bwd_reduce_kernel computes from dY and x)
+  const float* gnbeta;
+  const float* gnstats;               // [(segment, image)][cd / 8][mean, rstd] of the forward pass
 };
 
 __device__ __forceinline__ u32x4 relu_bf16x8(u32x4 v) {
@@ -766,7 +770,7 @@ __device__ unsigned long long g_conv_trace[8 * kTraceIters * 8 + 8 * 16 + 8];
 // Output tile of the DMA-pipelined kernels (bf16 and fp8): accumulators -> destination.  `stamp(i)` is the trace build's
 // s_memtime hook (a no-op otherwise).  RING = bytes of LDS the K loop used (free once every wave is here).
 // ================================================================================================
-template <int BCO, int BPX, int WCO, int WPX, int CT, int PT, int RING, class Stamp>
+template <int BCO, int BPX, int WCO, int WPX, int CT, int PT, int RING, bool GNB = false, class Stamp>
 __device__ __forceinline__ void conv_tile_epilogue(const ConvK& p, f32x16 (&acc)[CT][PT], unsigned char* smem, const int co0, const int px0,
                                                    const int totpx, Stamp&& stamp) {
   constexpr int T = 64 * WCO * WPX;
@@ -846,7 +850,139 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvK& p, f32x16 (&acc)
       // squares of the ROUNDED values - what gn_stats_kernel would read back - reduced over the tile's pixels in a fixed order and
       // written as one record per (row, pixel tile); gn_apply_kernel adds a row's records up in tile order.  Record layout:
       // [64 floats of header: word 0 = BPX][segment * n + image][maxhw / 64 + 2 tiles][cd / 8 groups][2].
-      if (p.gnws) {
+      bool gn_bwd = false;
+      if constexpr (GNB) gn_bwd = p.gnws != nullptr && p.gnx != nullptr;
+      if (gn_bwd) {
+        // ---- backward records (gn_bwd_reduce_kernel's, per pixel tile instead of per 128-pixel block): per channel dg = sum dz*xhat,
+        // db = sum dz, sx = sum xhat; per group s1 = sum dz*gamma, s2 = sum dz*gamma*xhat, dz = dy * [gamma*xhat + beta > 0]; dy is the
+        // staged tile, x comes from HBM.  Reduction: lanes of a wave that share a channel group by shuffles, then the waves through
+        // the LDS left behind the staged tile, WPR waves per round (the 256 x 192 tile has room for four of its eight), slot k adding
+        // waves k, k + WPR, ... in order; every sum in a fixed order.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr int RPT = T / GPR, NW = T / 64, NV = 26;
+        static_assert(GPR <= 64 && 64 % GPR == 0, "lanes of one channel group inside a wave");
+        constexpr int FREE = RING - BPX * ROWH;
+        constexpr int WPR = (FREE / (GPR * NV * 4)) >= NW ? NW : ((FREE / (GPR * NV * 4)) >= NW / 2 ? NW / 2 : NW / 4);
+        static_assert(WPR >= 1 && WPR * GPR * NV * 4 <= FREE && NW % WPR == 0, "reduction scratch behind the staged tile");
+        float* red = reinterpret_cast<float*>(smem + BPX * ROWH);
+        const unsigned char* rd = smem + row0 * ROWH + cgp * 16;
+        const bool live = co0 + cgp * 8 < p.cd;
+        const int ngr = p.cd >> 3;
+        const int R = 3 * p.cd + 2 * ngr;
+        int maxhw = 0;
+#pragma unroll
+        for (int sg = 0; sg < DSL_MAX_SEG; ++sg)
+          if (sg < p.nseg) maxhw = max(maxhw, p.gh[sg] * p.gw[sg]);
+        const int nbk = maxhw / 64 + 2;
+        if (px0 == 0 && co0 == 0 && tid == 0) *reinterpret_cast<int*>(p.gnws) = BPX;
+        f32x2 ga[4], be[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ch = co0 + cgp * 8 + 2 * e;
+          ga[e] = live ? f32x2{p.gngamma[ch], p.gngamma[ch + 1]} : f32x2{0.f, 0.f};
+          be[e] = live ? f32x2{p.gnbeta[ch], p.gnbeta[ch + 1]} : f32x2{0.f, 0.f};
+        }
+        const uint16_t* xsrc = p.gnx + (long long)(px0 + row0) * p.cd + (co0 + cgp * 8);
+        const int pend = min(px0 + BPX, totpx);
+        int cur = px0;
+#pragma nounroll
+        while (cur < pend) {
+          int seg, img, y_, x_;
+          decode_pixel(p, cur, seg, img, y_, x_);
+          const int hw = p.gh[seg] * p.gw[seg];
+          const int rs = p.pxstart[seg] + img * hw;
+          const int lo = cur - px0, hi = min(rs + hw, pend) - px0;
+          const int si = seg * p.n + img;
+          f32x2 dg[4], db[4], sx[4], s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dg[e] = db[e] = sx[e] = f32x2{0.f, 0.f};
+          if (live) {
+            const float* stp = p.gnstats + ((long long)si * ngr + (co0 >> 3) + cgp) * 2;
+            const float rstd = stp[1], nmr = -stp[0] * rstd;
+            // x in batches of XB chunks, one batch ahead of the arithmetic (the loads are the epilogue's only HBM latency)
+            constexpr int XB = NITP % 4 == 0 ? 4 : 1;
+            u32x4 xn[XB];
+            auto fetch = [&](int b_) {
+#pragma unroll
+              for (int i_ = 0; i_ < XB; ++i_) {
+                const int r_ = row0 + (b_ * XB + i_) * RPT;
+                xn[i_] = (r_ >= lo && r_ < hi) ? *reinterpret_cast<const u32x4*>(xsrc + (long long)(b_ * XB + i_) * RPT * p.cd) : u32x4{0, 0, 0, 0};
+              }
+            };
+            fetch(0);
+#pragma nounroll
+            for (int b_ = 0; b_ < NITP / XB; ++b_) {
+              u32x4 xc[XB];
+#pragma unroll
+              for (int i_ = 0; i_ < XB; ++i_) xc[i_] = xn[i_];
+              if (b_ + 1 < NITP / XB) fetch(b_ + 1);
+#pragma unroll
+              for (int i_ = 0; i_ < XB; ++i_) {
+                const int n_ = b_ * XB + i_;
+                const int r_ = row0 + n_ * RPT;
+                if (r_ >= lo && r_ < hi) {
+                  const u32x4 gv = *reinterpret_cast<const u32x4*>(rd + n_ * RPT * ROWH);
+                  const u32x4 xv = xc[i_];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const f32x2 xx = {bflo(xv[e]), bfhi(xv[e])};
+                    const f32x2 gg = {bflo(gv[e]), bfhi(gv[e])};
+                    const f32x2 xh = xx * rstd + nmr;
+                    const f32x2 t = xh * ga[e] + be[e];
+                    const f32x2 dz = {t[0] > 0.f ? gg[0] : 0.f, t[1] > 0.f ? gg[1] : 0.f};
+                    dg[e] += dz * xh;
+                    db[e] += dz;
+                    sx[e] += xh;
+                    const f32x2 u = dz * ga[e];
+                    s1 += u;
+                    s2 += u * xh;
+                  }
+                }
+              }
+            }
+          }
+          float v[NV];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] = dg[e][0]; v[2 * e + 1] = dg[e][1];
+            v[8 + 2 * e] = db[e][0]; v[8 + 2 * e + 1] = db[e][1];
+            v[16 + 2 * e] = sx[e][0]; v[16 + 2 * e + 1] = sx[e][1];
+          }
+          v[24] = s1[0] + s1[1];
+          v[25] = s2[0] + s2[1];
+#pragma unroll
+          for (int off = GPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int k_ = 0; k_ < NV; ++k_) v[k_] += __shfl_xor(v[k_], off);
+          // lanes [0, GPR) of every wave now hold the wave's sums for channel group `lane`
+#pragma unroll
+          for (int rnd = 0; rnd < NW / WPR; ++rnd) {
+            if (wave / WPR == rnd && lane < GPR) {
+              float* slot = red + ((wave % WPR) * GPR + lane) * NV;
+#pragma unroll
+              for (int k_ = 0; k_ < NV; ++k_) slot[k_] = rnd == 0 ? v[k_] : slot[k_] + v[k_];
+            }
+            lds_barrier();
+          }
+          {
+            const int j = px0 / BPX - rs / BPX;
+            float* rec = p.gnws + 64 + ((long long)si * nbk + j) * R;
+#pragma nounroll
+            for (int id = tid; id < GPR * NV; id += T) {
+              const int cg = id / NV, k_ = id - cg * NV;
+              float a = 0.f;
+#pragma unroll
+              for (int w_ = 0; w_ < WPR; ++w_) a += red[(w_ * GPR + cg) * NV + k_];
+              if (co0 + cg * 8 < p.cd) {
+                if (k_ < 24) rec[(k_ >> 3) * p.cd + co0 + cg * 8 + (k_ & 7)] = a;
+                else rec[3 * p.cd + 2 * ((co0 >> 3) + cg) + (k_ - 24)] = a;
+              }
+            }
+          }
+          lds_barrier();
+          cur = rs + hw;
+        }
+      } else if (p.gnws) {
         constexpr int RPT = T / GPR;
         static_assert((long long)BPX * ROWH + T * 8 <= (long long)RING, "reduction scratch behind the staged tile");
         static_assert(BPX >= 64, "the record count per row is sized for pixel tiles of at least 64");
@@ -970,7 +1106,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvK& p, f32x16 (&acc)
   }
 }
 
-template <int BCO, int BPX, int WCO, int WPX, int NST, bool SMC = false, int HB = 1, int LW = 0>
+template <int BCO, int BPX, int WCO, int WPX, int NST, bool SMC = false, int HB = 1, int LW = 0, bool GNB = false>
 __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int T = 64 * WCO * WPX;          // MFMA ("consumer") threads
@@ -1383,9 +1519,9 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
 
   // ---- epilogue (conv_tile_epilogue)
 #ifdef DSL_TRACE_BUILD
-  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, NST * STAGE>(p, acc, smem, co0, px0, totpx, [&](int i_) { TRE(i_); });
+  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, NST * STAGE, GNB>(p, acc, smem, co0, px0, totpx, [&](int i_) { TRE(i_); });
 #else
-  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, NST * STAGE>(p, acc, smem, co0, px0, totpx, [](int) {});
+  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, NST * STAGE, GNB>(p, acc, smem, co0, px0, totpx, [](int) {});
 #endif
 #ifdef DSL_TRACE_BUILD
   trace_dump();
@@ -3247,7 +3383,12 @@ bool conv_gn_ok(const dsl_conv_desc* d) {
   t.gn_ws = (void*)1;
   int pick, splits;
   conv_choose(&t, conv_pixels(d), d->kh * d->kw * (d->cs / 64), &pick, &splits);
-  return pick >= 0 && splits == 1;
+  if (pick < 0 || splits != 1) return false;
+  if (d->gn_x) {      // the backward records: instantiated for the head's tiles only (256 x 192, 256 x 128, 128 x 128)
+    if (pick != 0 && pick != 1 && pick != 3) return false;
+    if (getenv("DSL_CONV_TALL") || getenv("DSL_CONV_HOLD") || d->ldd != d->cd) return false;
+  }
+  return true;
 }
 }  // namespace
 
@@ -3332,6 +3473,11 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   DSL_CHECK(!d->gn_ws || conv_gn_ok(d), "dsl_conv2d: gn_ws is set but this launch cannot write GroupNorm records "
             "(ask dsl_conv2d_gn_fusable first)");
   k.gnws = (float*)d->gn_ws;
+  if (d->gn_ws && d->gn_x) {
+    DSL_CHECK(d->gn_gamma && d->gn_beta && d->gn_stats && d->ldd == d->cd, "dsl_conv2d: backward GroupNorm records need gn_gamma, "
+              "gn_beta, gn_stats and a dense destination (ldd=%d cd=%d)", d->ldd, d->cd);
+    k.gnx = (const uint16_t*)d->gn_x; k.gngamma = d->gn_gamma; k.gnbeta = d->gn_beta; k.gnstats = d->gn_stats;
+  }
 
   hipStream_t st = (hipStream_t)stream;
   // ---- 3x3 / 1, 64 -> 64, BatchNorm + ReLU epilogue (layer1's middle convolutions): the activation-stationary kernel of patch3.hip
@@ -3433,6 +3579,16 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     }                                                                                                         \
     hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_, false, H_>), dim3(8 * k.xcd_chunk), dim3(64 * C_ * D), lds, st, k); \
   } while (0)
+#define LAUNCH3G(A, B, C_, D, S_)                                                                              \
+  do {                                                                                                        \
+    static bool attr_set3g = false;                                                                           \
+    if (!attr_set3g) {                                                                                        \
+      hipFuncSetAttribute((const void*)conv_pipe_kernel<A, B, C_, D, S_, false, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)lds);                                                                          \
+      attr_set3g = true;                                                                                      \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_pipe_kernel<A, B, C_, D, S_, false, 1, 0, true>), dim3(8 * k.xcd_chunk), dim3(64 * C_ * D), lds, st, k); \
+  } while (0)
     const long long n_wg = (long long)grid.x * grid.y * grid.z;
     const bool use_kt = !force_v2_kernel && !smallc && (pick == 3 || pick == 5 || pick == 6 || pick == 7) &&
                         (kt_mode == 2 || (kt_mode == 1 && n_wg <= 256LL * c.occ));
@@ -3485,6 +3641,13 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
         default: LAUNCH2(64, 256, 1, 4, 2); break;
       }
     } else {
+      if (k.gnx) {            // (conv_gn_ok: one of the three tiles below, none of the variant knobs)
+        switch (pick) {
+          case 0: LAUNCH3G(256, 192, 4, 2, 2); break;
+          case 1: LAUNCH3G(256, 128, 4, 2, 3); break;
+          default: LAUNCH3G(128, 128, 2, 4, 2); break;
+        }
+      } else
       switch (pick) {
         case 0:
           if (tall & 1) LAUNCH3(256, 192, 2, 2, 2); else if (hold) LAUNCH3H(256, 192, 4, 2, 2, 2); else if (ldw) LAUNCH3L(256, 192, 4, 2, 2, 4); else LAUNCH3(256, 192, 4, 2, 2);
@@ -3510,6 +3673,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     }
 #undef LAUNCH2
 #undef LAUNCH3
+#undef LAUNCH3G
     dsl_prof_end(prof, st);
     if (splits > 1) {
       const long long total = (long long)px * (d->cd_pad / 4);

@@ -81,6 +81,28 @@ struct GnK {
 };
 
 constexpr int GN_PPB = 128;   // pixels per block
+
+// Where the block records of one (segment, image) row are and how many there are: the pass's own (one per GN_PPB pixels) or the
+// ones a convolution's epilogue left (conv_nbk > 0: one per pixel tile of that launch that meets the row).
+struct GnRows {
+  const float* base;
+  int nb;
+};
+__device__ __forceinline__ GnRows gn_rows(const GnK& p, int si, int R) {
+  const int seg = si / p.n, img = si - seg * p.n;
+  const int hw = p.h[seg] * p.w[seg];
+  GnRows r;
+  if (p.conv_nbk > 0) {
+    const int bpx = *reinterpret_cast<const int*>(p.ws);
+    const long long rs = p.off[seg] + (long long)img * hw;
+    r.nb = (int)((rs + hw - 1) / bpx - rs / bpx) + 1;
+    r.base = p.ws + 64 + (long long)si * p.conv_nbk * R;
+  } else {
+    r.nb = (hw + GN_PPB - 1) / GN_PPB;
+    r.base = p.ws + (long long)si * p.nblk * R;
+  }
+  return r;
+}
 // Block sizes: 256 threads.  Standalone the passes like big blocks (1024 / 512 threads: 17 + 32 us forward + backward against 25 + 39),
 // but in the step every pass runs BESIDE a convolution of the other tower or image chain whose workgroups already hold 2 waves x
 // ~190 VGPRs per SIMD and 112 KB of LDS on every CU: a 16-wave block (or gn_bwd_reduce's 53 KB of LDS at 512 threads) cannot
@@ -183,14 +205,9 @@ __global__ __launch_bounds__(GN_TA) void gn_apply_kernel(const GnK p) {
   const int hw = p.h[seg] * p.w[seg];
   const int px0 = blockIdx.x * GN_PPB;
   if (px0 >= hw) return;
-  if (p.conv_nbk > 0) {
-    const int bpx = *reinterpret_cast<const int*>(p.ws);
-    const long long rs = p.off[seg] + (long long)img * hw;
-    const int nb = (int)((rs + hw - 1) / bpx - rs / bpx) + 1;
-    gn_sum_records<GN_TA>(p.ws + 64 + (long long)si * p.conv_nbk * (2 * p.groups), nb, 2 * p.groups, 2 * p.groups, sh, tot);
-  } else {
-    const int nb = (hw + GN_PPB - 1) / GN_PPB;
-    gn_sum_records<GN_TA>(p.ws + (long long)si * p.nblk * (2 * p.groups), nb, 2 * p.groups, 2 * p.groups, sh, tot);
+  {
+    const GnRows rr = gn_rows(p, si, 2 * p.groups);
+    gn_sum_records<GN_TA>(rr.base, rr.nb, 2 * p.groups, 2 * p.groups, sh, tot);
   }
   const int cpr = p.c / 8, ppi = GN_TA / cpr;
   const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
@@ -337,11 +354,10 @@ __global__ __launch_bounds__(GN_TA) void gn_bwd_apply_kernel(const GnK p) {
         float a = 0.f;
         if (j < Q1) {
           const int si = v / (2 * NG), k = v - si * (2 * NG);
-          const int seg = si / p.n;
-          const int nb = (p.h[seg] * p.w[seg] + GN_PPB - 1) / GN_PPB;
-          const float* col = p.ws + (long long)si * p.nblk * R + 3 * p.c + 2 * g_lo + k;
+          const GnRows rr = gn_rows(p, si, R);
+          const float* col = rr.base + 3 * p.c + 2 * g_lo + k;
 #pragma unroll 8
-          for (int b = j; b < nb; b += Q1) a += col[(long long)b * R];
+          for (int b = j; b < rr.nb; b += Q1) a += col[(long long)b * R];
         }
         sh[threadIdx.x] = a;
         __syncthreads();
@@ -361,13 +377,13 @@ __global__ __launch_bounds__(GN_TA) void gn_bwd_apply_kernel(const GnK p) {
       for (int si = 0; si < S; ++si) {
         const int seg = si / p.n;
         const int hw = p.h[seg] * p.w[seg];
-        const int nb = (hw + GN_PPB - 1) / GN_PPB;
+        const GnRows rr = gn_rows(p, si, R);
         const float rstd = p.stats[((long long)si * p.groups + g_lo + gi) * 2 + 1];
         const float m2 = tot[(si * NG + gi) * 2 + 1] / ((float)hw * (float)cpg);
         if (ok) {
 #pragma unroll 4
-          for (int b = q; b < nb; b += Q) {
-            const float* rec = p.ws + ((long long)si * p.nblk + b) * R;
+          for (int b = q; b < rr.nb; b += Q) {
+            const float* rec = rr.base + (long long)b * R;
             const float rdb = rec[p.c + ch];
             dg += rec[ch];
             db += rdb;
@@ -398,8 +414,8 @@ __global__ __launch_bounds__(GN_TA) void gn_bwd_apply_kernel(const GnK p) {
   const int hw = p.h[seg] * p.w[seg];
   const int px0 = blockIdx.x * GN_PPB;
   if (px0 >= hw) return;
-  const int nb = (hw + GN_PPB - 1) / GN_PPB;
-  gn_sum_records<GN_TA>(p.ws + (long long)si * p.nblk * R + 3 * p.c, nb, R, 2 * p.groups, sh, tot);
+  const GnRows rr = gn_rows(p, si, R);
+  gn_sum_records<GN_TA>(rr.base + 3 * p.c, rr.nb, R, 2 * p.groups, sh, tot);
   const int cpr = p.c / 8, ppi = GN_TA / cpr;
   const int chunk = threadIdx.x % cpr, prow = threadIdx.x / cpr;
   const int grp = chunk / p.cpg8;
@@ -523,7 +539,8 @@ extern "C" size_t dsl_groupnorm_workspace_bytes(const dsl_gn_desc* d) {
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   const size_t nblk = (maxhw + GN_PPB - 1) / GN_PPB;
   const size_t own = (size_t)d->nseg * d->n * nblk * (3 * (size_t)d->c + 2 * (size_t)d->groups) * sizeof(float);
-  const size_t conv = 64 * sizeof(float) + (size_t)d->nseg * d->n * (maxhw / 64 + 2) * 2 * (size_t)d->groups * sizeof(float);
+  const size_t conv = 64 * sizeof(float) +
+                      (size_t)d->nseg * d->n * (maxhw / 64 + 2) * (3 * (size_t)d->c + 2 * (size_t)d->groups) * sizeof(float);
   return own > conv ? own : conv;       // (the records of a producing convolution, dsl_conv_desc.gn_ws, fit as well)
 }
 namespace {
@@ -599,7 +616,12 @@ extern "C" int dsl_groupnorm_relu_bwd(const dsl_gn_desc* d, void* stream) {
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   dim3 grid((maxhw + GN_PPB - 1) / GN_PPB, d->nseg * d->n);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(GN_T), 0, st, k);
+  if (d->conv_stats) {
+    DSL_CHECK(d->c / d->groups == 8, "dsl_groupnorm_relu_bwd: conv_stats needs 8 channels per group (C=%d groups=%d)", d->c, d->groups);
+    k.conv_nbk = maxhw / 64 + 2;
+  } else {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(GN_T), 0, st, k);
+  }
   dim3 grid2(grid.x, grid.y + 1);        // + the parameter-gradient row
   hipLaunchKernelGGL(gn_bwd_apply_kernel, grid2, dim3(GN_TA), 0, st, k);
   DSL_LAUNCH_CHECK("gn backward");

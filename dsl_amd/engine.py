@@ -525,8 +525,10 @@ class Plan:
         """Launches on one stream run one after the other and may share the block-record scratch."""
         ws = self._gn_ws.get(key)
         if ws is None:
-            nblk = (max(h * w for h, w in self.level_sizes) + 127) // 128
-            ws = torch.empty(5 * self.N * nblk * (3 * 256 + 64), dtype=torch.float32, device=self.dev)
+            d = L.GnDesc()
+            d.nseg, d.n, d.c, d.groups = len(self.level_sizes), self.N, 256, 32
+            d.h, d.w = ops._segs(self.level_sizes)
+            ws = torch.empty((L.lib.dsl_groupnorm_workspace_bytes(C.byref(d)) + 3) // 4, dtype=torch.float32, device=self.dev)
             self._gn_ws[key] = ws
         return ws
 
@@ -679,13 +681,34 @@ class Plan:
         if os.environ.get('DSL_PRED_EARLY', '0') != '0':
             self._flush_wgrads(ol, side=SIDE)
         g_act = {}
+        # The data gradient that produces dY of a tower layer's GroupNorm + ReLU also leaves that norm's backward block records
+        # (dsl_conv_desc.gn_x: x is read once more in the epilogue, dY never again): GroupNorm backward is then ONE pass
+        # (DSL_GN_FUSE_BWD=0: its own reduction pass first)
+        GN_FUSE_BWD = os.environ.get('DSL_GN_FUSE_BWD', '1') != '0'
+        gn_from_conv = set()
+
+        def gn_records(cd_, tower, j, sd):
+            if not GN_FUSE_BWD:
+                return cd_
+            lay = self.tower[tower][j]
+            cd_.gn_x = L.ptr(lay['pre'])                 # (set first: the query answers for the backward records' tiles)
+            if L.lib.dsl_conv2d_gn_fusable(C.byref(cd_)):
+                cd_.gn_ws = L.ptr(self._gn_workspace('side' if sd else 'main'))
+                cd_.gn_gamma, cd_.gn_beta = L.ptr(st.t32_ptr(lay['gn'] + '.weight')), L.ptr(st.t32_ptr(lay['gn'] + '.bias'))
+                cd_.gn_stats = L.ptr(lay['stats'])
+                gn_from_conv.add((tower, j))
+            else:
+                cd_.gn_x = None
+            return cd_
         for tower, sd in towers:
             wsf = side_ws if sd else (lambda c: c)
             g_act[tower] = self.buf(f'g_{tower}_act3', M, 256)
             if tower == 'cls_convs':
-                ol.conv(wsf(self._dgrad('head.cls', lp.g_cls, g_act[tower], N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1, cs_real=80)), side=sd)
+                ol.conv(gn_records(wsf(self._dgrad('head.cls', lp.g_cls, g_act[tower], N, ls, ls, cs=128, cd=256, k=3, stride=1, pad=1, cs_real=80)),
+                                   tower, 3, sd), side=sd)
             else:
-                ol.conv(wsf(self._dgrad('head.regctr', lp.g_rc, g_act[tower], N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1, cs_real=5)), side=sd)
+                ol.conv(gn_records(wsf(self._dgrad('head.regctr', lp.g_rc, g_act[tower], N, ls, ls, cs=64, cd=256, k=3, stride=1, pad=1, cs_real=5)),
+                                   tower, 3, sd), side=sd)
         # layer by layer, both towers: their weight gradients go out in two groups of four (layers 3, 2 and layers 1, 0 of
         # both towers) as soon as the GroupNorm backward passes that produce their dY are queued - the side stream works from
         # the first quarter of this segment on instead of waiting for its end
@@ -702,6 +725,7 @@ class Plan:
                                  lay['stats'], self._gn_workspace('side' if sd else 'main'), n=N, hw=ls, dy=g_act[tower], dx=g_pre[tower],
                                  dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad),
                                  dbias=st.t32_ptr(lay['spec'].name + '.bias', st.grad))
+                gd.conv_stats = 1 if (tower, i) in gn_from_conv else 0
                 ol.gn_bwd(gd, side=sd)
                 tower_group.append(self._wgrad(ol, lay['spec'], g_pre[tower], lay['xin'], N, ls, ls, side=SIDE, emit=False, no_db=True,
                                                slots=int(os.environ.get('DSL_DEFER_SLOTS', '144')) if self.defer else
@@ -720,7 +744,8 @@ class Plan:
                     wsf = side_ws if sd else (lambda c: c)
                     lay = self.tower[tower][i]
                     g_act[tower] = self.buf(f'g_{tower}_act{i - 1}', M, 256)
-                    ol.conv(wsf(self._dgrad(lay['spec'].name, g_pre[tower], g_act[tower], N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1)), side=sd)
+                    ol.conv(gn_records(wsf(self._dgrad(lay['spec'].name, g_pre[tower], g_act[tower], N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1)),
+                                       tower, i - 1, sd), side=sd)
             else:
                 cl, rl = self.tower['cls_convs'][0], self.tower['reg_convs'][0]
                 ol.conv(self._dgrad(cl['spec'].name, g_pre['cls_convs'], g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1))

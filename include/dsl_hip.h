@@ -84,6 +84,13 @@ typedef struct dsl_conv_desc {
                                                       * statistics records there and dsl_groupnorm_relu_fwd skips its own
                                                       * statistics pass (ConvModule conv -> GN -> ReLU, anchor_free_head.py:104-133);
                                                       * legal only where dsl_conv2d_gn_fusable() says 1 */
+  const void* gn_x;                                  /* NULL: gn_ws takes the forward records (sum, sum of squares).  Else this launch is
+                                                      * the data gradient that produces dY of that GroupNorm + ReLU, gn_x its bf16 input
+                                                      * of the forward pass (same rows as dst, ldd == cd): gn_ws takes the BACKWARD
+                                                      * records and dsl_groupnorm_relu_bwd (conv_stats = 1) skips its reduction pass */
+  const float* gn_gamma;                             /* with gn_x: the norm's weight, bias and the forward statistics (dsl_gn_desc.stats) */
+  const float* gn_beta;
+  const float* gn_stats;
 } dsl_conv_desc;
 
 /* 1 if a launch of `d` can write GroupNorm records (pipelined kernel, bf16 output on its own pixel grid, no split-K) */
@@ -314,8 +321,9 @@ typedef struct dsl_gn_desc {
   float* dbias;           /* fp32 [c] or NULL: sum over pixels of dx = gradient of the bias of the conv that made x */
   void* workspace;        /* >= dsl_groupnorm_workspace_bytes(d); private to this call until it completes */
   size_t workspace_bytes;
-  int32_t conv_stats;     /* forward: 1 = the convolution that produced x already left its statistics records in `workspace`
-                           * (dsl_conv_desc.gn_ws == workspace): one pass instead of two; needs c / groups == 8 */
+  int32_t conv_stats;     /* 1 = a convolution already left this call's block records in `workspace` (dsl_conv_desc.gn_ws ==
+                           * workspace): forward, the one that produced x; backward, the data gradient that produced dy (its
+                           * gn_x = x).  One pass instead of two; needs c / groups == 8 */
   int32_t pad_;
 } dsl_gn_desc;
 size_t dsl_groupnorm_workspace_bytes(const dsl_gn_desc* d);

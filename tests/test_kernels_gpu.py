@@ -708,6 +708,66 @@ def test_groupnorm_statistics_from_the_conv_epilogue(K, N, sizes, force):
     assert L.lib.dsl_conv2d(C.byref(cd2), L.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize('N,sizes,force', [
+    (2, [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)], 0),
+    (3, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 1),       # 256 x 192: the reduction scratch takes two rounds
+    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 4),       # 128 x 128 (two cout tiles write one record)
+    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 7),       # 64 x 64
+    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 2),       # 256 x 128
+])
+def test_groupnorm_backward_records_from_the_data_gradient_epilogue(K, N, sizes, force):
+    """dY of a tower layer's GroupNorm + ReLU comes out of the next layer's data gradient: with dsl_conv_desc.gn_x that launch also
+    leaves the norm's backward block records, and dsl_groupnorm_relu_bwd (conv_stats = 1) is one pass - against the two-pass
+    backward on the same dY (autograd of ConvModule conv -> GN -> ReLU, anchor_free_head.py:104-133)."""
+    L, ops = K
+    g = torch.Generator().manual_seed(43)
+    Cc = 256
+    P = sum(h * w for h, w in sizes) * N
+    x = _multiseg([rnd(N, Cc, h, w, g=g, scale=2.0) for h, w in sizes])            # the norm's input of the forward pass
+    gnext = _multiseg([rnd(N, Cc, h, w, g=g) for h, w in sizes])                   # gradient at the next conv's output
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) * 0.03
+    ga, be = (1 + 0.2 * torch.randn(Cc, generator=g)).cuda(), (0.3 * torch.randn(Cc, generator=g)).cuda()
+    y = torch.empty(P, Cc, dtype=torch.bfloat16, device='cuda')
+    stats = torch.empty(5 * N * 32, 2, device='cuda')
+    L.check(L.lib.dsl_groupnorm_relu_fwd(C.byref(ops.gn_desc(x, y, ga, be, stats, n=N, hw=sizes)), L.stream_ptr()))
+    wT = pack_w_dgrad(w, Cc)
+    outs = []
+    for fused in (0, 1):
+        dy = torch.zeros(P, Cc, dtype=torch.bfloat16, device='cuda')
+        dx = torch.empty_like(dy)
+        dgam, dbet, dbias = (torch.full((Cc,), float('nan'), device='cuda') for _ in range(3))
+        gd = ops.gn_desc(x, y, ga, be, stats, n=N, hw=sizes, dy=dy, dx=dx, dgamma=dgam, dbeta=dbet, dbias=dbias)
+        cd = ops.conv_desc(gnext, wT, dy, n=N, grid=sizes, src_hw=sizes, dst_hw=sizes, cs=Cc, cd=Cc, cd_pad=Cc, ldd=Cc, kh=3, kw=3,
+                           stride=1, pad=1, mode=1, flags=force << 8)
+        if fused:
+            cd.gn_x = L.ptr(x)
+            ok = L.lib.dsl_conv2d_gn_fusable(C.byref(cd))
+            assert force == 0 or ok == (1 if force in (1, 2, 4) else 0)        # instantiated for the head's three tiles
+            if not ok:
+                cd.gn_ws = gd.workspace
+                assert L.lib.dsl_conv2d(C.byref(cd), L.stream_ptr()) != 0          # refused, not silently skipped
+                return
+            cd.gn_ws, cd.gn_gamma, cd.gn_beta, cd.gn_stats = gd.workspace, L.ptr(ga), L.ptr(be), L.ptr(stats)
+            gd.conv_stats = 1
+            gd._keep[5].fill_(0xff)
+        for rep in range(2):
+            L.check(L.lib.dsl_conv2d(C.byref(cd), L.stream_ptr()), 'dsl_conv2d')
+            L.check(L.lib.dsl_groupnorm_relu_bwd(C.byref(gd), L.stream_ptr()), 'gn bwd')
+            sync()
+            if rep == 0:
+                outs.append([t.clone() for t in (dy, dx, dgam, dbet, dbias)])
+            else:                                    # fixed-order reductions: the same bits again
+                for a, b in zip(outs[-1], (dy, dx, dgam, dbet, dbias)):
+                    assert torch.equal(a, b)
+    a, b = outs
+    assert torch.equal(a[0], b[0])                   # the data gradient itself does not change
+    tol = 2 ** -7 * float(a[1].float().abs().max())
+    assert float((a[1].float() - b[1].float()).abs().max()) <= tol
+    assert float(((a[1] != b[1]).float()).mean()) < 0.01
+    for u, v in zip(a[2:], b[2:]):                   # parameter gradients: the same sums in another (fixed) order
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-4 * float(u.abs().max())), (u - v).abs().max()
+
+
 def test_maxpool_sum2x2_colsum(K):
     L, _ = K
     g = torch.Generator().manual_seed(5)
