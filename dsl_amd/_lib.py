@@ -92,7 +92,7 @@ class FcosDesc(C.Structure):
                 ('g_cls', C.c_void_p), ('ld_gcls', C.c_int32), ('g_rc', C.c_void_p), ('ld_grc', C.c_int32),
                 ('g_scales', C.c_void_p), ('losses', C.c_void_p),
                 ('soft_weight', C.c_float), ('grad_scale', C.c_float), ('inv_world', C.c_float),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('logvec', C.c_void_p)]
 
 
 class DetDesc(C.Structure):

@@ -3384,8 +3384,10 @@ bool conv_gn_ok(const dsl_conv_desc* d) {
   int pick, splits;
   conv_choose(&t, conv_pixels(d), d->kh * d->kw * (d->cs / 64), &pick, &splits);
   if (pick < 0 || splits != 1) return false;
-  if (d->gn_x) {      // the backward records: instantiated for the head's tiles only (256 x 192, 256 x 128, 128 x 128)
-    if (pick != 0 && pick != 1 && pick != 3) return false;
+  if (d->gn_x) {      // the backward records: instantiated for the 256-cout tiles only (256 x 192, 256 x 128).  Their workgroups own a
+    // CU anyway (114 / 147 KB of LDS); the 128 x 128 tile with the ~60 extra registers (158) keeps ONE workgroup per CU instead of
+    // two and the launch takes twice as long (N = 3 head: 100 -> 212 us, profiles/r04_rla_timeline.txt) - there the separate pass stays
+    if (pick != 0 && pick != 1) return false;
     if (getenv("DSL_CONV_TALL") || getenv("DSL_CONV_HOLD") || d->ldd != d->cd) return false;
   }
   return true;
@@ -3641,12 +3643,8 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
         default: LAUNCH2(64, 256, 1, 4, 2); break;
       }
     } else {
-      if (k.gnx) {            // (conv_gn_ok: one of the three tiles below, none of the variant knobs)
-        switch (pick) {
-          case 0: LAUNCH3G(256, 192, 4, 2, 2); break;
-          case 1: LAUNCH3G(256, 128, 4, 2, 3); break;
-          default: LAUNCH3G(128, 128, 2, 4, 2); break;
-        }
+      if (k.gnx) {            // (conv_gn_ok: one of the two tiles below, none of the variant knobs)
+        if (pick == 0) LAUNCH3G(256, 192, 4, 2, 2); else LAUNCH3G(256, 128, 4, 2, 3);
       } else
       switch (pick) {
         case 0:

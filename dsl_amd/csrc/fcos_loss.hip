@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const FcK p) {
 constexpr int FIN_T = 256;
 __global__ __launch_bounds__(FIN_T) void fcos_finalize_kernel(const float* __restrict__ part, int nblocks, int V, float* out0,
                                                               int n0, float* out1, const float* norm, float inv_world,
-                                                              float soft_weight, int mode) {
+                                                              float soft_weight, int mode, float* logvec = nullptr) {
   __shared__ float sh[FIN_T];
   // thread (q, v): blocks q, q + Q, ... ; then thread v adds the Q partial sums in order
   const int Q = FIN_T / V;
@@ -158,13 +158,26 @@ __global__ __launch_bounds__(FIN_T) void fcos_finalize_kernel(const float* __res
     for (int k = 0; k < Q; ++k) t += sh[k * V + threadIdx.x];
     if (mode == 1) {           // loss records: [cls, sisoft, bbox, centerness, g_scale x 5] -> losses[4] + g_scales[5]
       const float num_pos = fmaxf(norm[0] * inv_world, 1.0f), denorm = fmaxf(norm[1] * inv_world, 1e-6f);
-      if (threadIdx.x == 0) out0[0] = t / num_pos;
-      else if (threadIdx.x == 1) out0[3] = t * soft_weight;
-      else if (threadIdx.x == 2) out0[1] = t / denorm;
-      else if (threadIdx.x == 3) out0[2] = t / num_pos;
+      float fv = t;
+      if (threadIdx.x == 0) out0[0] = fv = t / num_pos;
+      else if (threadIdx.x == 1) out0[3] = fv = t * soft_weight;
+      else if (threadIdx.x == 2) out0[1] = fv = t / denorm;
+      else if (threadIdx.x == 3) out0[2] = fv = t / num_pos;
       else if (threadIdx.x - 4 < n0) out1[threadIdx.x - 4] = t;
+      if (threadIdx.x < 4) sh[threadIdx.x] = fv;          // (slot x of sh is read by thread x only, above)
     } else if (threadIdx.x < n0) {
       out0[threadIdx.x] = t;
+    }
+  }
+  if (mode == 1 && logvec) {       // the log vector of _parse_losses (detectors/base.py:175-208): the loss terms and their sum
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float cls = sh[0], soft = sh[1], bbox = sh[2], ctr = sh[3];
+      float tot = (cls + bbox) + ctr;
+      int n = 3;
+      logvec[0] = cls; logvec[1] = bbox; logvec[2] = ctr;
+      if (soft_weight != 0.f) { logvec[n++] = soft; tot += soft; }
+      logvec[n] = tot;
     }
   }
   if (mode == 0 && (int)threadIdx.x >= V && threadIdx.x < 8) out0[threadIdx.x] = 0.f;      // stats[2..7] are reserved, kept zero
@@ -447,7 +460,7 @@ extern "C" int dsl_fcos_loss(const dsl_fcos_desc* d, void* stream) {
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(256), 0, st, k);
   hipLaunchKernelGGL(fcos_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, (const float*)k.part, blocks, 16, d->losses,
-                     DSL_MAX_SEG, d->g_scales, d->norm, d->inv_world, d->soft_weight, 1);
+                     DSL_MAX_SEG, d->g_scales, d->norm, d->inv_world, d->soft_weight, 1, d->logvec);
   DSL_LAUNCH_CHECK("loss_kernel");
   return 0;
 }

@@ -230,8 +230,36 @@ def role_stream(role, device=None, priority=0):
 
 
 class _LossDict(OrderedDict):
-    """The loss dict of forward_train; `.vec` (optional) holds the same scalars as one graph-connected tensor."""
+    """The loss dict of forward_train; `.vec` (optional) holds the same scalars as one graph-connected tensor, `.vec_total` the same
+    with their sum appended."""
     vec = None
+    vec_total = None
+
+
+class _TotalFn(torch.autograd.Function):
+    """total = the last element of the step's log vector (summed by the loss kernel), connected to the graph without a device op in
+    either direction: backward hands the cached one-hot gradient on (a gradient other than 1 is rejected where the step reads
+    values back anyway, see _TrainStepFn.backward)."""
+
+    @staticmethod
+    def forward(ctx, vec, det):
+        ctx.det, ctx.n = det, vec.numel()
+        return vec[ctx.n - 1].detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        det = ctx.det
+        if not det.lazy_log or os.environ.get('DSL_CHECK_BACKWARD_GRAD'):
+            if float(g) != 1.0:
+                raise NotImplementedError(f'dsl_amd: loss.backward() with a gradient of {float(g)} for the total loss: scale through '
+                                          'FCOS.loss_scale (folded into the loss kernel), not by scaling the loss tensor')
+        key = (ctx.n, g.device)
+        oh = det._onehot.get(key)
+        if oh is None:
+            oh = torch.zeros(ctx.n, dtype=torch.float32, device=g.device)
+            oh[ctx.n - 1] = 1.0
+            det._onehot[key] = oh
+        return oh, None
 
 
 class _TrainStepFn(torch.autograd.Function):
@@ -241,7 +269,8 @@ class _TrainStepFn(torch.autograd.Function):
     def forward(ctx, anchor, det, plan):
         ctx.det, ctx.plan, ctx.eager = det, plan, bool(getattr(det, '_eager_now', False))      # were the backward lists queued already?
         ctx.n_losses = 4 if plan.lossplan.desc.soft_weight != 0.0 else 3
-        return plan.lossplan.losses.clone()
+        # the loss terms in log order and, last, their sum - written by the loss kernel's finalize pass (dsl_fcos_desc.logvec)
+        return plan.lossplan.logvec[:ctx.n_losses + 1].clone()
 
     @staticmethod
     def backward(ctx, g):
@@ -253,10 +282,11 @@ class _TrainStepFn(torch.autograd.Function):
         det = ctx.det
         if not det.lazy_log or os.environ.get('DSL_CHECK_BACKWARD_GRAD'):
             k = ctx.n_losses
-            if not bool((g[:k] == 1).all()):
+            gh = g.tolist()       # d(total)/d(term) = 1 for every term: either through the terms or through the kernel's own sum
+            if not (all(v == 1 for v in gh[:k]) and gh[k] == 0) and not (all(v == 0 for v in gh[:k]) and gh[k] == 1):
                 raise NotImplementedError(
                     'dsl_amd: loss.backward() reached the HIP step with a gradient != 1 for its loss terms '
-                    f'({g[:k].tolist()}): scale through FCOS.loss_scale (folded into the loss kernel), not by scaling the loss tensor')
+                    f'({gh}): scale through FCOS.loss_scale (folded into the loss kernel), not by scaling the loss tensor')
         if not ctx.eager:                 # eager: the kernels were queued right behind the loss kernel
             det._run_backward(ctx.plan)
         return None, None, None
@@ -295,6 +325,7 @@ class FCOS(nn.Module):
         # `interval` iterations, float(v)) instead of once per iteration between the forward and the backward pass
         # (detectors/base.py:175-208 calls .item() per key per iteration).  False: python floats, one host sync per iteration.
         self.lazy_log = True
+        self._onehot = {}          # cached gradient of the total loss w.r.t. the step's log vector (_TotalFn)
         # eager_backward True: INSIDE train_step the backward kernel lists are queued right behind the loss kernel (and the few
         # log-variable ops) instead of when `loss.backward()` reaches the autograd bridge.  The gradient of the summed loss is 1
         # either way - the bridge ignores its incoming gradient - so only the launch order changes.  For loops that call
@@ -482,6 +513,8 @@ class FCOS(nn.Module):
         if sw != 0.0:
             losses['loss_sisoft'] = out[3]
         losses.vec = out[:len(losses)]      # the same scalars as ONE tensor: lets _parse_losses avoid per-key device ops
+        if os.environ.get('DSL_LOG_TOTAL', '1') != '0':      # (0: the stack + sum + cat device ops of the generic path; A/B only)
+            losses.vec_total = out          # ... and with their sum (the loss kernel's) as the last element: no device op at all
         return losses
 
     def _all_reduce_async(self, t, after_current=False):
@@ -602,6 +635,15 @@ class FCOS(nn.Module):
             else:
                 log_vars[name] = sum(v.mean() for v in value)
         keys = list(log_vars.keys())
+        vt = getattr(losses, 'vec_total', None)
+        if vt is not None and vt.numel() == len(keys) + 1 and all('loss' in k for k in keys):
+            # the HIP head: the loss kernel summed the terms itself, the total is the vector's last element
+            loss = _TotalFn.apply(vt, self)
+            log_vars['loss'] = loss
+            keys.append('loss')
+            # (the all-reduce below works in place: not on the storage `loss` is a view of)
+            vec = vt.detach().clone() if (self.world_size > 1 and not self.comm_off) else vt.detach()
+            return self._finish_log_vars(loss, vec, keys)
         # two device ops instead of one per key (stack + sum); the reference sums the keys containing 'loss'
         vec0 = getattr(losses, 'vec', None)
         stacked = vec0 if (vec0 is not None and vec0.numel() == len(keys)) else torch.stack([log_vars[k] for k in keys])
@@ -612,6 +654,9 @@ class FCOS(nn.Module):
         log_vars['loss'] = loss
         keys.append('loss')
         vec = torch.cat([stacked.detach(), loss.detach().reshape(1)])
+        return self._finish_log_vars(loss, vec, keys)
+
+    def _finish_log_vars(self, loss, vec, keys):
         if self.world_size > 1 and not self.comm_off:      # ONE all-reduce for all log vars instead of one per key
             if self.rccl is not None and vec.is_cuda:
                 self.rccl.all_reduce(vec)

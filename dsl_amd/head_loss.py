@@ -31,6 +31,7 @@ class FcosLossPlan:
         self.pos_weight = torch.empty(M, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(8, dtype=torch.float32, device=dev)
         self.losses = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.logvec = torch.zeros(5, dtype=torch.float32, device=dev)      # the loss terms in log order + their sum (dsl_fcos_desc.logvec)
         self.g_scales = torch.zeros(L.MAX_SEG, dtype=torch.float32, device=dev)
         # gradient buffers: padding columns stay zero forever (the kernels only write real columns)
         self.g_cls = torch.zeros(M, self.LD_GCLS, dtype=torch.bfloat16, device=dev)
@@ -55,7 +56,7 @@ class FcosLossPlan:
                      labels=self.labels, bbox_targets=self.bbox_targets, assign_idx=self.assign_idx,
                      cls_weight=self.cls_weight, pos_weight=self.pos_weight, stats=self.stats,
                      norm=self.stats, g_cls=self.g_cls, g_rc=self.g_rc, g_scales=self.g_scales,
-                     losses=self.losses)
+                     losses=self.losses, logvec=self.logvec)
         self.desc.ld_cls, self.desc.ld_rc = self.LD_CLS, self.LD_RC
         self.desc.ld_gcls, self.desc.ld_grc = self.LD_GCLS, self.LD_GRC
         need = L.lib.dsl_fcos_workspace_bytes(C.byref(self.desc))

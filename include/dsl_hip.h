@@ -426,6 +426,8 @@ typedef struct dsl_fcos_desc {
   float inv_world;                     /* 1/world_size: norm[] holds the SUM over ranks of stats[0:2] */
   void* workspace;                     /* >= dsl_fcos_workspace_bytes(d): block records of the loss / num_pos sums, which */
   size_t workspace_bytes;              /* are added up in a fixed order (bit-identical results from run to run) */
+  float* logvec;                       /* NULL, or fp32 [5]: cls, bbox, centerness, [sisoft if soft_weight != 0,] their sum - the log
+                                        * vector of BaseDetector._parse_losses (detectors/base.py:175-208) without a framework op */
 } dsl_fcos_desc;
 size_t dsl_fcos_workspace_bytes(const dsl_fcos_desc* d);
 

@@ -711,8 +711,7 @@ def test_groupnorm_statistics_from_the_conv_epilogue(K, N, sizes, force):
 @pytest.mark.parametrize('N,sizes,force', [
     (2, [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)], 0),
     (3, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 1),       # 256 x 192: the reduction scratch takes two rounds
-    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 4),       # 128 x 128 (two cout tiles write one record)
-    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 7),       # 64 x 64
+    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 4),       # 128 x 128: not instantiated, the launch refuses
     (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 2),       # 256 x 128
 ])
 def test_groupnorm_backward_records_from_the_data_gradient_epilogue(K, N, sizes, force):
@@ -742,7 +741,7 @@ def test_groupnorm_backward_records_from_the_data_gradient_epilogue(K, N, sizes,
         if fused:
             cd.gn_x = L.ptr(x)
             ok = L.lib.dsl_conv2d_gn_fusable(C.byref(cd))
-            assert force == 0 or ok == (1 if force in (1, 2, 4) else 0)        # instantiated for the head's three tiles
+            assert force == 0 or ok == (1 if force in (1, 2) else 0)        # instantiated for the two 256-cout tiles
             if not ok:
                 cd.gn_ws = gd.workspace
                 assert L.lib.dsl_conv2d(C.byref(cd), L.stream_ptr()) != 0          # refused, not silently skipped
