@@ -185,7 +185,7 @@ _SIGS = {
     'dsl_wgrad_multi_build': [_vp, _vp, _i, _vp, C.c_size_t, _vp, C.c_size_t], 'dsl_conv2d_wgrad_multi': [_vp, _vp, _vp], 'dsl_wgrad_multi_info': [_vp, _vp, _vp, _vp, _vp, _vp],
     'dsl_wgrad_plan_probe': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'dsl_image_prep': [_vp, _i, _vp, _i, _i, _vp], 'dsl_conv1x1_pair': [_vp, _vp], 'dsl_bottleneck64': [_vp, _vp],
-    'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_stem_pool': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
+    'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_stem_pool': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_stem_pool_half': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
     'dsl_conv3x3_c64_patch': [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_maxpool3x3s2_ld': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_avgpool2x2': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

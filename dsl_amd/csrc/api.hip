@@ -151,8 +151,8 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
       case DSL_OP_PACK_DGRAD: rc = dsl_pack_dgrad_batched((const dsl_pack_item*)o.p[0], o.i[0], o.i[1], stream); break;
       case DSL_OP_PACK_IMAGE: rc = dsl_pack_image((const float*)o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], stream); break;
       case DSL_OP_STEM_POOL:
-        rc = dsl_stem_pool((const float*)o.p[0], o.p[1], (const float*)(intptr_t)o.l[0], (const float*)(intptr_t)o.l[1], o.p[2], o.i[0],
-                           o.i[1], o.i[2], o.i[3], stream);
+        rc = dsl_stem_pool_half((const float*)o.p[0], o.p[1], (const float*)(intptr_t)o.l[0], (const float*)(intptr_t)o.l[1], o.p[2], o.i[0],
+                                o.i[1], o.i[2], o.i[3], o.i[4], stream);
         break;
       case DSL_OP_ASSIGN: rc = dsl_fcos_assign((const dsl_fcos_desc*)o.desc, stream); break;
       case DSL_OP_LOSS: rc = dsl_fcos_loss((const dsl_fcos_desc*)o.desc, stream); break;

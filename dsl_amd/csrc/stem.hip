@@ -33,6 +33,7 @@ constexpr int STEM_T = 256;
 struct StemK {
   const float* img; const uint16_t* w; const float* scale; const float* bias; uint16_t* out;
   int n, H, W, SH, SW, PH, PW, ld_out, tiles_x, tiles_y, tiles;
+  int half_last;     // 1: image n - 1 is not in memory - it is image n - 2 at half size (bilinear) in the top-left corner of a zero canvas
 };
 
 __device__ __forceinline__ float mul1(float a, float b) { return a * b; }      // (contract(off): one rounding each, as conv.hip's mul_nc / add_nc)
@@ -74,6 +75,26 @@ __global__ __launch_bounds__(STEM_T) void stem_pool_kernel(const StemK p) {
   {
     constexpr int NLD = (3 * IR * IC + STEM_T - 1) / STEM_T;
     float v[NLD];
+    if (p.half_last && b == p.n - 1) {
+      // SemiEpochBasedRunner's scale-invariant copy (semi_epoch_based_runner.py:186-204: F.interpolate(img[-1:], size = (H / 2, W / 2),
+      // mode = 'bilinear') pasted into a zero canvas) read straight from its source image: for an exact factor of two the bilinear
+      // sample of output (y, x) is 0.5 * (0.5 * v00 + 0.5 * v01) + 0.5 * (0.5 * v10 + 0.5 * v11) - halvings are exact in fp32, so it is
+      // ((v00 + v01) + (v10 + v11)) / 4 with those three roundings, bit for bit what the framework kernel writes
+      const int hh = p.H >> 1, hw_ = p.W >> 1;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * STEM_T;
+        const int c = idx / (IR * IC), rem = idx - c * (IR * IC);
+        const int r = rem / IC, col = rem - r * IC;
+        const int iy = iy0 + r, ix = ix0 + col;
+        v[i] = 0.f;
+        if (idx < 3 * IR * IC && (unsigned)iy < (unsigned)hh && (unsigned)ix < (unsigned)hw_) {
+          const float* s0 = p.img + ((long long)((b - 1) * 3 + c) * p.H + 2 * iy) * p.W + 2 * ix;
+          const float2 t0 = *reinterpret_cast<const float2*>(s0), t1 = *reinterpret_cast<const float2*>(s0 + p.W);
+          v[i] = mul1(add1(add1(t0.x, t0.y), add1(t1.x, t1.y)), 0.25f);
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + i * STEM_T;
@@ -83,6 +104,7 @@ __global__ __launch_bounds__(STEM_T) void stem_pool_kernel(const StemK p) {
       v[i] = 0.f;
       if (idx < 3 * IR * IC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
         v[i] = p.img[((long long)(b * 3 + c) * p.H + iy) * p.W + ix];
+    }
     }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -154,11 +176,19 @@ __global__ __launch_bounds__(STEM_T) void stem_pool_kernel(const StemK p) {
 
 }  // namespace
 
+extern "C" int dsl_stem_pool_half(const float* img, const void* w_groups, const float* scale, const float* bias, void* out, int ld_out,
+                                  int n, int h, int w, int half_last, void* stream);
 extern "C" int dsl_stem_pool(const float* img, const void* w_groups, const float* scale, const float* bias, void* out, int ld_out,
                              int n, int h, int w, void* stream) {
+  return dsl_stem_pool_half(img, w_groups, scale, bias, out, ld_out, n, h, w, 0, stream);
+}
+extern "C" int dsl_stem_pool_half(const float* img, const void* w_groups, const float* scale, const float* bias, void* out, int ld_out,
+                                  int n, int h, int w, int half_last, void* stream) {
   DSL_CHECK(img && w_groups && scale && bias && out, "dsl_stem_pool: null pointer");
   DSL_CHECK(n >= 1 && h >= 7 && w >= 7 && ld_out >= 64 && ld_out % 8 == 0, "dsl_stem_pool: bad shape");
+  DSL_CHECK(!half_last || (n >= 2 && h % 2 == 0 && w % 2 == 0), "dsl_stem_pool: half_last needs n >= 2 and even sizes (n=%d h=%d w=%d)", n, h, w);
   StemK k;
+  k.half_last = half_last ? 1 : 0;
   k.img = img; k.w = (const uint16_t*)w_groups; k.scale = scale; k.bias = bias; k.out = (uint16_t*)out;
   k.n = n; k.H = h; k.W = w;
   k.SH = (h + 6 - 7) / 2 + 1; k.SW = (w + 6 - 7) / 2 + 1;

@@ -325,6 +325,9 @@ class FCOS(nn.Module):
         # `interval` iterations, float(v)) instead of once per iteration between the forward and the backward pass
         # (detectors/base.py:175-208 calls .item() per key per iteration).  False: python floats, one host sync per iteration.
         self.lazy_log = True
+        # SemiEpochBasedRunner(scale_invariant=True) may hand the batch over WITHOUT its half-scale third image: the stem kernel reads
+        # it out of the second one (forward_train(half_scale_copy=True)); DSL_HALF_IN_STEM=0: the runner builds it with framework ops
+        self.half_scale_in_stem = os.environ.get('DSL_HALF_IN_STEM', '1') != '0' and os.environ.get('DSL_STEM_FUSED', '1') != '0'
         self._onehot = {}          # cached gradient of the total loss w.r.t. the step's log vector (_TotalFn)
         # eager_backward True: INSIDE train_step the backward kernel lists are queued right behind the loss kernel (and the few
         # log-variable ops) instead of when `loss.backward()` reaches the autograd bridge.  The gradient of the summed loss is 1
@@ -417,10 +420,14 @@ class FCOS(nn.Module):
             self._anchor = torch.zeros(1, device=self.store.device, requires_grad=True)
         return self._engine
 
-    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
-        """single_stage.py:56-84 + base_dense_head.py:22-59.  Returns dict of scalar loss tensors."""
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, half_scale_copy=False):
+        """single_stage.py:56-84 + base_dense_head.py:22-59.  Returns dict of scalar loss tensors.
+        half_scale_copy: the batch has one more image than `img` holds - SemiEpochBasedRunner's scale-invariant half-size copy of
+        img[-1] (semi_epoch_based_runner.py:186-204), whose metas / boxes are the lists' last entries; the stem kernel samples it
+        from img[-1] (dsl_stem_pool_half), it is never written to memory."""
         eng = self._get_engine()
         N, _, H, W = img.shape
+        N += 1 if half_scale_copy else 0
         assert len(img_metas) == N == len(gt_bboxes) == len(gt_labels)
         if self.comm_trace is not None and img.is_cuda:
             t0 = torch.cuda.Event(enable_timing=True)
@@ -439,7 +446,7 @@ class FCOS(nn.Module):
             # frozen prefix of THIS step on its own stream: it waits for the previous backward's data-gradient chain only (named
             # event), not for that step's weight-gradient tail / optimizer step; layer1's output alternates between two buffers
             plan.set_parity(plan._parity ^ 1)
-            plan.bind_image(img)
+            plan.bind_image(img, half_last=half_scale_copy)
             if self._prefix_stream is None:
                 prio = int(os.environ.get('DSL_PREFIX_PRIO', '0'))        # -1: high-priority queue (experiment)
                 # streams share four hardware queues in creation order: DSL_PREFIX_SKIP = n takes n streams from torch's pool first,
@@ -480,7 +487,7 @@ class FCOS(nn.Module):
                 plan.prefix.run()
             fwd = plan.fwd_rest
         else:
-            plan.bind_image(img)
+            plan.bind_image(img, half_last=half_scale_copy)
             fwd = plan.fwd
         work = None
         if ws > 1:

@@ -237,6 +237,7 @@ class Plan:
         # the three launches it replaced - an 8-channel bf16 copy of the image, the implicit-GEMM convolution with K = 448 stored
         # columns for 147 real ones, the pooling pass over its 400 x 672 x 64 output)
         fused = os.environ.get('DSL_STEM_FUSED', '1') != '0'
+        self._stem_fused = fused
         if fused:
             s1 = None
         else:
@@ -1034,12 +1035,17 @@ class Plan:
         self._pp['wg_ds'].x = ptr
         self._parity = p
 
-    def bind_image(self, img):
+    def bind_image(self, img, half_last=False):
         """The batch for the next fwd.run(): a dense fp32 tensor on this device is read in place by the layout kernel (it
-        must stay alive until that kernel has run - stream order on the caller's stream); anything else is staged in self.img."""
+        must stay alive until that kernel has run - stream order on the caller's stream); anything else is staged in self.img.
+        half_last: `img` holds N - 1 images; the plan's last image is the stem kernel's half-scale view of img[-1]
+        (dsl_stem_pool_half; SemiEpochBasedRunner's scale-invariant copy, never materialised)."""
+        assert img.shape[0] == self.N - (1 if half_last else 0), (tuple(img.shape), self.N, half_last)
+        if half_last and self._stem_fused is False:
+            raise RuntimeError('half_last needs the fused stem kernel (DSL_STEM_FUSED=0 is set)')
         direct = img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and img.device == self.img.device
         if not direct:
-            self.img.copy_(img, non_blocking=True)
+            self.img[:img.shape[0]].copy_(img, non_blocking=True)
         ptr = img.data_ptr() if direct else self.img.data_ptr()
         self._img_ref = img if direct else None
         lists = [(self.fwd, self._img_op - (1 if self.prefix is not None else 0))]
@@ -1049,6 +1055,8 @@ class Plan:
             if f.arr is None:
                 f.arr = (L.Op * len(f.items))(*f.items)
             f.arr[idx].p[0] = ptr
+            if self._stem_fused:
+                f.arr[idx].i[4] = 1 if half_last else 0
 
     def forward(self, img=None):
         if img is not None:

@@ -35,14 +35,17 @@ for _m in ('before_run', 'after_run', 'before_train_epoch', 'after_train_epoch',
     setattr(Hook, _m, lambda self, runner: None)
 
 
-def append_half_scale(img, gt_bboxes, gt_labels, gt_bboxes_ignore, img_metas):
+def append_half_scale(img, gt_bboxes, gt_labels, gt_bboxes_ignore, img_metas, materialize=True):
     """semi_epoch_based_runner.py:186-204, on device: bilinear half-size copy of the LAST image pasted at the
-    top-left of a zero canvas; boxes and ignore boxes halved; meta shapes halved (int)."""
+    top-left of a zero canvas; boxes and ignore boxes halved; meta shapes halved (int).
+    materialize=False: `img` is returned as it came (the lists still get their extra entry): the detector's stem kernel samples
+    the copy from img[-1] (FCOS.forward_train(half_scale_copy=True))."""
     B, _, H, W = img.shape
-    small = F.interpolate(img[B - 1:], size=(int(H / 2), int(W / 2)), mode='bilinear')
-    canvas = torch.zeros_like(img[B - 1:])
-    canvas[:, :, :small.shape[2], :small.shape[3]] = small
-    img = torch.cat([img, canvas], 0)
+    if materialize:
+        small = F.interpolate(img[B - 1:], size=(int(H / 2), int(W / 2)), mode='bilinear')
+        canvas = torch.zeros_like(img[B - 1:])
+        canvas[:, :, :small.shape[2], :small.shape[3]] = small
+        img = torch.cat([img, canvas], 0)
     meta = dict(img_metas[-1])
     for k in ('img_shape', 'pad_shape'):
         if k in meta:
@@ -175,9 +178,17 @@ class SemiEpochBasedRunner:
             self._inner_iter = i
             if self.scale_invariant:
                 d = data_batch
-                img, gb, gl, gi, metas = append_half_scale(d['img'], d['gt_bboxes'], d['gt_labels'],
-                                                           d.get('gt_bboxes_ignore'), d['img_metas'])
+                det = getattr(self.model, 'module', self.model)
+                im = d['img']
+                # the HIP detector reads the half-scale copy out of the last image inside its stem kernel: no interpolate / zeros /
+                # cat passes on the training stream, the loader's own tensor (and its mark_ready event) reaches forward_train
+                in_stem = (getattr(det, 'half_scale_in_stem', False) and torch.is_tensor(im) and im.is_cuda
+                           and im.shape[2] % 2 == 0 and im.shape[3] % 2 == 0)
+                img, gb, gl, gi, metas = append_half_scale(im, d['gt_bboxes'], d['gt_labels'],
+                                                           d.get('gt_bboxes_ignore'), d['img_metas'], materialize=not in_stem)
                 data_batch = dict(d, img=img, gt_bboxes=gb, gt_labels=gl, img_metas=metas)
+                if in_stem:
+                    data_batch['half_scale_copy'] = True
                 if gi is not None:
                     data_batch['gt_bboxes_ignore'] = gi
             self.call_hook('before_train_iter')

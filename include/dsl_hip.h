@@ -286,6 +286,12 @@ int dsl_pack_image(const float* img_nchw, void* out_nhwc8, int n, int h, int w, 
  * fp32 summation order of the 147 products. */
 int dsl_stem_pool(const float* img_nchw, const void* w_groups, const float* scale, const float* bias, void* out, int ld_out,
                   int n, int h, int w, void* stream);
+/* The same with half_last = 1: img_nchw holds n - 1 images; image n - 1 is SemiEpochBasedRunner's scale-invariant copy of the
+ * last one (semi_epoch_based_runner.py:186-204: F.interpolate(img[-1:], size = (h / 2, w / 2), mode = 'bilinear') pasted at the
+ * top-left of a zero canvas), sampled from its source while the patch is loaded - no interpolate / zeros / cat passes, no
+ * second copy of the batch; bit-identical to them (h, w even). */
+int dsl_stem_pool_half(const float* img_nchw, const void* w_groups, const float* scale, const float* bias, void* out, int ld_out,
+                       int n, int h, int w, int half_last, void* stream);
 
 /* Activation-stationary 3x3 / stride 1 / pad 1 convolution 64 -> 64 + folded BatchNorm (scale, bias) [+ ReLU], NHWC bf16: the middle
  * convolution of the frozen layer1 bottlenecks (resnet.py:262-301 Bottleneck.forward: conv2 / bn2 / relu).  src: [n][h][w] rows of
@@ -558,7 +564,7 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_QUANT_FP8_W = 23, /* dsl_quant_fp8_weights(p[0] = w, p[1] = w8, p[2] = comb, p[3] = bn_scale, i[0] = cout, i[1] = cout_pad, i[2] = k,
                                 * inv_act_scale = the float whose bits are l[1]) */
        DSL_OP_STEM_POOL = 25,  /* dsl_stem_pool(p[0] = img, p[1] = w_groups, l[0] / l[1] = scale / bias pointers, p[2] = out, i[0] = ld_out,
-                                * i[1..3] = n, h, w) */
+                                * i[1..3] = n, h, w, i[4] = half_last: dsl_stem_pool_half) */
        DSL_OP_BNECK64 = 26,    /* desc = dsl_bneck64_desc -> dsl_bottleneck64 */
        DSL_OP_PROF = 21 };     /* phase mark (dsl_prof_enable(3) only, else a no-op): i[0] = class >= 4, i[1] = 0 begin | 1 end, l[0] / l[1] =
                                 * algorithmic FLOPs / bytes of the phase as IEEE doubles' bit patterns (begin only) */

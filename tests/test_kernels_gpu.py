@@ -177,6 +177,41 @@ def test_conv_stem_small_c(K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 64, 96), (3, 70, 132), (2, 800, 1344)])
+def test_stem_pool_reads_the_half_scale_copy_out_of_the_last_image(K, shape):
+    """dsl_stem_pool_half: the batch's last image is SemiEpochBasedRunner's scale-invariant copy (semi_epoch_based_runner.py:186-204:
+    F.interpolate(img[-1:], (H / 2, W / 2), mode='bilinear') in the top-left corner of a zero canvas), sampled from its source inside
+    the stem kernel - bit for bit the output of the same kernel on the batch the framework ops build."""
+    L, ops = K
+    from dsl_amd.runner import append_half_scale
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = (torch.randn(B, 3, H, W, generator=g) * 50).cuda()
+    w = rnd(64, 3, 7, 7, g=g, scale=0.05)
+    wg = torch.zeros(64, 7, 24)
+    wg[:, :, :21] = w.permute(0, 2, 3, 1).reshape(64, 7, 21)
+    wg = torch.cat([wg.reshape(64, 21, 8).permute(1, 0, 2), torch.zeros(1, 64, 8)], 0).bfloat16().cuda().contiguous()
+    sc_d, bi_d = (torch.rand(64, generator=g) + 0.5).cuda(), torch.randn(64, generator=g).cuda()
+    boxes = [torch.zeros(0, 4, device='cuda')] * B
+    labels = [torch.zeros(0, dtype=torch.long, device='cuda')] * B
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3))] * B
+    full = append_half_scale(x, boxes, labels, None, metas)[0].contiguous()
+    assert full.shape[0] == B + 1
+    same = append_half_scale(x, boxes, labels, None, metas, materialize=False)
+    assert same[0] is x and len(same[1]) == B + 1 and len(same[4]) == B + 1
+    PH, PW = (H + 1) // 2, (W + 1) // 2
+    PH, PW = (PH + 1) // 2, (PW + 1) // 2
+    a = torch.empty(B + 1, PH, PW, 64, dtype=torch.bfloat16, device='cuda')
+    b = torch.empty_like(a)
+    L.check(L.lib.dsl_stem_pool(L.ptr(full), L.ptr(wg), L.ptr(sc_d), L.ptr(bi_d), L.ptr(a), 64, B + 1, H, W, L.stream_ptr()))
+    L.check(L.lib.dsl_stem_pool_half(L.ptr(x), L.ptr(wg), L.ptr(sc_d), L.ptr(bi_d), L.ptr(b), 64, B + 1, H, W, 1, L.stream_ptr()))
+    sync()
+    assert torch.equal(a, b)
+    assert float(b[B].float().abs().max()) > 0
+    assert L.lib.dsl_stem_pool_half(L.ptr(x), L.ptr(wg), L.ptr(sc_d), L.ptr(bi_d), L.ptr(b), 64, B + 1, H + 1, W, 1, L.stream_ptr()) != 0     # odd size: refused
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 37, 45), (1, 64, 96), (2, 128, 192), (1, 800, 1344), (3, 70, 131)])
 def test_stem_pool_fused_kernel(K, shape):
     """dsl_stem_pool (image layout + conv1 7x7 / 2 + BN + ReLU + max pool 3x3 / 2 in one kernel) against (a) torch fp32 on the

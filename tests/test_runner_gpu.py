@@ -389,3 +389,36 @@ def test_bench_loop_and_train_detector_enqueue_the_same_step(tmp_path):
     for k in la:
         assert la[k] == lb[k], k
     assert torch.equal(a.store.train, det.store.train) and torch.equal(a.store.train16, det.store.train16)
+
+
+def test_half_scale_copy_read_in_the_stem_trains_to_the_same_bits():
+    """SemiEpochBasedRunner(scale_invariant=True) hands the HIP detector the loader's own two-image tensor and lets the stem kernel
+    sample the half-scale third image out of the second (forward_train(half_scale_copy=True), dsl_stem_pool_half): the same
+    losses and the same weights, bit for bit, as with the batch the framework ops build (semi_epoch_based_runner.py:186-204)."""
+    from dsl_amd.optim import FlatSGD
+    from dsl_amd.runner import OptimizerHook, SemiEpochBasedRunner
+    head = dict(loss_weight=3.0, soft_weight=1.0, soft_warm_up=0)
+    res = []
+    for in_stem in (False, True):
+        model = build(**head)
+        model.bbox_head.cur_iter = 1
+        model.half_scale_in_stem = in_stem
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, grad_clip=dict(max_norm=35, norm_type=2))
+        runner = SemiEpochBasedRunner(model, optimizer=opt, max_epochs=1, scale_invariant=True)
+        runner.register_hook(OptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)), priority=30)
+        seen = []
+
+        class Spy:
+            priority = 45
+
+            def __getattr__(self, name):
+                return lambda runner: None
+
+            def after_train_iter(self, r):
+                seen.append({k: float(v) for k, v in r.outputs['log_vars'].items()})
+        runner.register_hook(Spy(), priority=45)
+        runner.run([make_batches(3)], max_epochs=1)
+        torch.cuda.synchronize()
+        res.append((seen, model.store.train.clone()))
+    assert res[0][0] == res[1][0] and len(res[0][0]) == 3
+    assert torch.equal(res[0][1], res[1][1])
