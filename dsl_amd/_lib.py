@@ -203,7 +203,7 @@ _SIGS = {
     'dsl_fcos_points': [_vp, _vp, _vp], 'dsl_fcos_workspace_bytes': [_vp], 'dsl_fcos_assign': [_vp, _vp], 'dsl_fcos_loss': [_vp, _vp],
     'dsl_sumsq': [_vp, _l, _vp, _vp], 'dsl_sumsq_det': [_vp, _l, _vp, _vp, _vp],
     'dsl_sgd_step': [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _i, _vp],
-    'dsl_ema_lerp': [_vp, _vp, _l, _f, _vp], 'dsl_cast_bf16': [_vp, _vp, _l, _vp],
+    'dsl_ema_lerp': [_vp, _vp, _l, _f, _vp], 'dsl_ema_lerp_bf16': [_vp, _vp, _vp, _l, _f, _vp], 'dsl_cast_bf16': [_vp, _vp, _l, _vp],
     'dsl_pack_dgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_pack_dgrad_batched': [_vp, _i, _i, _vp],
     'dsl_detect_workspace_bytes': [_vp], 'dsl_fcos_detect': [_vp, _vp],
     'dsl_pseudo_label_fuse': [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],

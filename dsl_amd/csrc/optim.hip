@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
-__global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long long n, float keep) {
+__global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long long n, float keep, uint16_t* __restrict__ t16) {
   const long long n4 = n / 4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 tv = *reinterpret_cast<const f32x4*>(t + 4 * i);
@@ -76,6 +76,7 @@ __global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, l
 #pragma unroll
     for (int e = 0; e < 4; ++e) tv[e] = tv[e] * keep + sv[e] * (1.f - keep);
     *reinterpret_cast<f32x4*>(t + 4 * i) = tv;
+    if (t16) *reinterpret_cast<u32x2*>(t16 + 4 * i) = u32x2{pack2bf(tv[0], tv[1]), pack2bf(tv[2], tv[3])};     // the forward copy
   }
 }
 
@@ -189,7 +190,15 @@ extern "C" int dsl_sgd_step(float* p, const float* g, float* m, void* p16, const
 extern "C" int dsl_ema_lerp(float* teacher, const float* student, long n, float keep, void* stream) {
   DSL_CHECK(teacher && student && n % 4 == 0, "dsl_ema_lerp: bad arguments");
   hipLaunchKernelGGL(ema_kernel, dim3(nblocks(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream, teacher, student,
-                     (long long)n, keep);
+                     (long long)n, keep, (uint16_t*)nullptr);
+  DSL_LAUNCH_CHECK("ema_kernel");
+  return 0;
+}
+
+extern "C" int dsl_ema_lerp_bf16(float* teacher, const float* student, void* teacher_bf16, long n, float keep, void* stream) {
+  DSL_CHECK(teacher && student && teacher_bf16 && n % 4 == 0, "dsl_ema_lerp_bf16: bad arguments");
+  hipLaunchKernelGGL(ema_kernel, dim3(nblocks(n / 4, 4096)), dim3(256), 0, (hipStream_t)stream, teacher, student,
+                     (long long)n, keep, (uint16_t*)teacher_bf16);
   DSL_LAUNCH_CHECK("ema_kernel");
   return 0;
 }

@@ -225,11 +225,13 @@ class SemiEpochBasedRunner:
         if ev is not None:                                # teacher's weights: the update waits for it
             torch.cuda.current_stream().wait_event(ev)
             self._sweep_event = None
-        L.check(L.lib.dsl_ema_lerp(L.ptr(t.train), L.ptr(s.train), s.n_train, float(keep_rate), L.stream_ptr()), 'dsl_ema_lerp')
         if t.train16 is None or t.dirty:
+            L.check(L.lib.dsl_ema_lerp(L.ptr(t.train), L.ptr(s.train), s.n_train, float(keep_rate), L.stream_ptr()), 'dsl_ema_lerp')
             t.refresh()
         else:
-            L.check(L.lib.dsl_cast_bf16(L.ptr(t.train), L.ptr(t.train16), t.n_train, L.stream_ptr()), 'dsl_cast_bf16')
+            # one pass: the lerp and the teacher's bf16 forward copy (384 + 64 MB instead of 384 + 192)
+            L.check(L.lib.dsl_ema_lerp_bf16(L.ptr(t.train), L.ptr(s.train), L.ptr(t.train16), s.n_train, float(keep_rate), L.stream_ptr()),
+                    'dsl_ema_lerp_bf16')
             # RLA_ResNet keeps the affine parameters of its eval-mode BatchNorms trainable: the teacher's forward reads the
             # FOLDED (scale, bias), so they are re-made from the lerped gamma / beta (no-op for the plain ResNet)
             t.refold_bn(L.stream_ptr())

@@ -455,6 +455,8 @@ int dsl_sgd_step(float* p, const float* g, float* m, void* p16, const uint8_t* g
                  float lr, float momentum, float wd, float bias_lr_mult, float bias_decay_mult,
                  const float* gnorm_sq, float max_norm, int first_step, void* stream);
 int dsl_ema_lerp(float* teacher, const float* student, long n, float keep, void* stream);
+/* the same, and the teacher's bf16 forward copy written in the same pass (what dsl_cast_bf16 would re-read the result for) */
+int dsl_ema_lerp_bf16(float* teacher, const float* student, void* teacher_bf16, long n, float keep, void* stream);
 int dsl_cast_bf16(const float* x, void* y, long n, void* stream);
 /* bf16 -> fp32 (n % 4 == 0): the way back of a gradient bucket that crossed xGMI as bf16 (dsl_allreduce_bucket_bf16). */
 int dsl_cast_f32(const void* x_bf16, float* y, long n, void* stream);

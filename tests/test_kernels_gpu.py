@@ -862,6 +862,10 @@ def test_sgd_ema_cast_packdgrad(K):
     L.check(L.lib.dsl_ema_lerp(L.ptr(td), L.ptr(sd_), n, 0.99, L.stream_ptr()))
     sync()
     assert torch.allclose(td.cpu(), O.ema_update({'w': t}, {'w': s}, 0.99)['w'], rtol=1e-6, atol=1e-7)
+    td2, t16 = t.clone().cuda(), torch.zeros(n, dtype=torch.bfloat16, device='cuda')      # the same with the bf16 forward copy in the same pass
+    L.check(L.lib.dsl_ema_lerp_bf16(L.ptr(td2), L.ptr(sd_), L.ptr(t16), n, 0.99, L.stream_ptr()))
+    sync()
+    assert torch.equal(td2, td) and torch.equal(t16, td.bfloat16())
     w = torch.randn(80, 3, 3, 256, generator=g)
     sc = torch.rand(80, generator=g) + 0.5
     out = torch.full((256, 3, 3, 128), 5.0).bfloat16().cuda()
