@@ -3318,6 +3318,7 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
       if (d->cd_pad % kCfgs[c].bco) continue;
       if (force >= 1 && force <= kNumCfg && force - 1 != c) continue;
       if (c >= 5 && conv_v2_only(d)) continue;       // the small tiles exist for the pipelined kernel only
+      if (d->gn_x && c > 1) continue;                // backward GroupNorm records: the 256-cout tiles carry them (conv_gn_ok)
       if (smallc && c != 4) continue;                // the 8-channel-source variant is instantiated for the 64x256 tile
       if ((d->flags & DSL_CONV_FP8) && c != 0 && c != 1 && c != 3) continue;     // fp8: instantiated for 256x192, 256x128, 128x128
       for (int sp = 1; sp <= 16; ++sp) {
