@@ -862,7 +862,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvK& p, f32x16 (&acc)
         constexpr int RPT = T / GPR, NW = T / 64, NV = 26;
         static_assert(GPR <= 64 && 64 % GPR == 0, "lanes of one channel group inside a wave");
         constexpr int FREE = RING - BPX * ROWH;
-        constexpr int WPR = (FREE / (GPR * NV * 4)) >= NW ? NW : ((FREE / (GPR * NV * 4)) >= NW / 2 ? NW / 2 : NW / 4);
+        constexpr int WFIT = FREE / (GPR * NV * 4);
+        constexpr int WPR = WFIT >= NW ? NW : (WFIT >= NW / 2 ? NW / 2 : (WFIT >= NW / 4 ? NW / 4 : 1));
         static_assert(WPR >= 1 && WPR * GPR * NV * 4 <= FREE && NW % WPR == 0, "reduction scratch behind the staged tile");
         float* red = reinterpret_cast<float*>(smem + BPX * ROWH);
         const unsigned char* rd = smem + row0 * ROWH + cgp * 16;
@@ -1104,6 +1105,12 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvK& p, f32x16 (&acc)
     }
     stamp(3 + 3 * pt);
   }
+}
+
+// LDS the epilogue may use: the K loop's ring, or - the 256 x 256 tile, whose bf16 rows do not fit in its two-stage ring - the staged
+// tile plus the GroupNorm reduction scratch (the host sizes the launch's LDS the same way)
+constexpr int conv_epi_ring(int bco, int bpx, int ring, int t) {
+  return (bco == 256 && bpx == 256 && bpx * (bco * 2 + 16) + t * 8 > ring) ? bpx * (bco * 2 + 16) + t * 8 : ring;
 }
 
 template <int BCO, int BPX, int WCO, int WPX, int NST, bool SMC = false, int HB = 1, int LW = 0, bool GNB = false>
@@ -1519,9 +1526,9 @@ __global__ __launch_bounds__(64 * (WCO * WPX + LW)) void conv_pipe_kernel(const 
 
   // ---- epilogue (conv_tile_epilogue)
 #ifdef DSL_TRACE_BUILD
-  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, NST * STAGE, GNB>(p, acc, smem, co0, px0, totpx, [&](int i_) { TRE(i_); });
+  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, conv_epi_ring(BCO, BPX, NST * STAGE, T), GNB>(p, acc, smem, co0, px0, totpx, [&](int i_) { TRE(i_); });
 #else
-  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, NST * STAGE, GNB>(p, acc, smem, co0, px0, totpx, [](int) {});
+  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, conv_epi_ring(BCO, BPX, NST * STAGE, T), GNB>(p, acc, smem, co0, px0, totpx, [](int) {});
 #endif
 #ifdef DSL_TRACE_BUILD
   trace_dump();
@@ -3262,12 +3269,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, const RedK r, 
 namespace {
 // DMA-to-LDS tile configurations {BCO, BPX, workgroups per CU, ring depth}
 struct TileCfg { int bco, bpx, occ, nst, wpx; };     // wpx: pixel-waves of the pipelined kernel (epilogue staging = 32*wpx pixels)
-constexpr int kNumCfg = 8;
+constexpr int kNumCfg = 9;
 const TileCfg kCfgs[kNumCfg] = {{256, 192, 1, 2, 2}, {256, 128, 1, 3, 2}, {128, 256, 1, 3, 4}, {128, 128, 2, 2, 4}, {64, 256, 2, 2, 8},
                                 {128, 64, 2, 3, 2},
                                 // small tiles for the layers with few pixels (layer3/4: 8 400 / 2 100 pixels at N = 2): enough
                                 // workgroups to use every CU without split-K partials, several resident per CU
-                                {64, 64, 3, 3, 2}, {64, 128, 2, 3, 4}};
+                                {64, 64, 3, 3, 2}, {64, 128, 2, 3, 4},
+                                // 256 x 256 (round 4 experiment, DSL_CONV_256=1 or forced): 14 % fewer DMA bytes and 10 % fewer fragment
+                                // reads per MFMA than 256 x 192, 175 instead of 234 workgroups on the head shape
+                                {256, 256, 1, 2, 2}};
 
 // strided data-gradients gather with per-tap divisibility tests: only the v2 kernel's general address path does that
 inline bool conv_v2_only(const dsl_conv_desc* d) { return d->mode == 1 && d->stride > 1; }
@@ -3281,7 +3291,7 @@ inline bool conv_v2_only(const dsl_conv_desc* d) { return d->mode == 1 && d->str
 double conv_cost_us(int ci, long long px, int cd_pad, int ktiles, int sp, bool out_f32) {
   const TileCfg& c = kCfgs[ci];
   // per-config efficiency of the K loop (the 8-wave 128x128 tile keeps 2 waves per SIMD even alone on a CU)
-  static const double kEff[kNumCfg] = {1.0, 1.0, 1.0, 0.7, 0.95, 0.9, 1.3, 1.25};     // 6, 7: measured best on one shape of tools/bench_conv.py only
+  static const double kEff[kNumCfg] = {1.0, 1.0, 1.0, 0.7, 0.95, 0.9, 1.3, 1.25, 1.0};     // 6, 7: measured best on one shape of tools/bench_conv.py only
   const long long wgs = (long long)(cd_pad / c.bco) * ((px + c.bpx - 1) / c.bpx) * sp;
   const long long slots = 256LL * c.occ;
   const long long rounds = (wgs + slots - 1) / slots;
@@ -3311,6 +3321,15 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
   const bool dma_ok = conv_v2_only(d) || (d->kh <= 8 && d->kw <= 8 && src_px * lds_ * 2 + (long long)d->kw * lds_ * 2 < 0x7fff0000LL);
   const bool smallc_pipe = smallc && d->cd_pad % 64 == 0 && !getenv("DSL_STEM_V1");    // stem: pipelined kernel, 64-cout tile
   const bool v1_only = ((smallc && !smallc_pipe) || (d->flags & DSL_CONV_RELU_IN) || !dma_ok) && !(d->flags & DSL_CONV_FP8);
+  static const int mode_256 = [] { const char* e = getenv("DSL_CONV_256"); return e ? atoi(e) : 0; }();
+  const bool use_256 = mode_256 != 0;
+  // (2: every 256-cout convolution over >= 40 000 pixels takes the 256 x 256 tile whatever the model says - the CU-time experiment)
+  if (mode_256 == 2 && !v1_only && force == 0 && !smallc && !(d->flags & DSL_CONV_FP8) && !conv_v2_only(d) && d->cd_pad % 256 == 0 &&
+      px >= 40000 && !d->gn_x && !getenv("DSL_CONV_V2") && !getenv("DSL_CONV_KT")) {
+    *pick_out = 8;
+    *splits_out = 1;
+    return;
+  }
   if (!v1_only && force != 15) {
     double best = 1e300;
     const bool out_f32 = (d->flags & DSL_CONV_OUT_F32) != 0;
@@ -3318,6 +3337,8 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
       if (d->cd_pad % kCfgs[c].bco) continue;
       if (force >= 1 && force <= kNumCfg && force - 1 != c) continue;
       if (c >= 5 && conv_v2_only(d)) continue;       // the small tiles exist for the pipelined kernel only
+      if (c == 8 && force - 1 != 8 && !use_256) continue;
+      if (c == 8 && (smallc || getenv("DSL_CONV_V2") || getenv("DSL_CONV_KT"))) continue;
       if (d->gn_x && c > 1) continue;                // backward GroupNorm records: the 256-cout tiles carry them (conv_gn_ok)
       if (smallc && c != 4) continue;                // the 8-channel-source variant is instantiated for the 64x256 tile
       if ((d->flags & DSL_CONV_FP8) && c != 0 && c != 1 && c != 3) continue;     // fp8: instantiated for 256x192, 256x128, 128x128
@@ -3333,6 +3354,7 @@ void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out
       for (int c = 0; c < kNumCfg; ++c) {
         if (d->cd_pad % kCfgs[c].bco || (force >= 1 && force <= kNumCfg && force - 1 != c)) continue;
         if (c >= 5 && conv_v2_only(d)) continue;
+        if (c == 8 && force - 1 != 8 && !use_256) continue;
         const double t = conv_cost_us(c, px, d->cd_pad, ktiles, 1, out_f32);
         if (t < best) { best = t; pick = c; splits = 1; }
       }
@@ -3526,6 +3548,10 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
     if (!force_v2_kernel) {                // the pipelined kernel stages its epilogue in LDS: 32*wpx pixel rows of fp32
       const size_t stg = (size_t)32 * c.wpx * (c.bco * 4 + 16);
       if (stg > lds) lds = stg;
+      if (pick == 8) {                     // ... or the whole tile as bf16 rows + the GroupNorm scratch (conv_epi_ring)
+        const size_t pure = (size_t)c.bpx * (c.bco * 2 + 16) + 512 * 8;
+        if (pure > lds) lds = pure;
+      }
     }
 #ifdef DSL_TRACE_BUILD
     lds += 8 * 40 * 8 * 8 + 8 * 16 * 8;    // the stamp area behind the ring
@@ -3665,6 +3691,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
             LAUNCH3(64, 256, 1, 8, 2);
           }
           break;
+        case 8: LAUNCH3(256, 256, 4, 2, 2); break;
         case 5: LAUNCH3(128, 64, 2, 2, 3); break;
         case 6: LAUNCH3(64, 64, 1, 2, 3); break;
         default: LAUNCH3(64, 128, 1, 4, 3); break;

@@ -126,7 +126,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 4 + (3 << 4), 5 + (2 << 4), 6 + (5 << 4), 7 + (2 << 4), 0 + (16 << 4)])
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 4 + (3 << 4), 5 + (2 << 4), 6 + (5 << 4), 7 + (2 << 4), 0 + (16 << 4)])
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_forward(K, case, force):
     """force: 0 = library's own tile choice, 1..5 = v2 (DMA-to-LDS) tile configs, 15 = v1 kernel."""
@@ -134,7 +134,7 @@ def test_conv_forward(K, case, force):
     _, N, Ci, Co, H, W, k, s, p = case
     ws = torch.empty(64 << 20, dtype=torch.uint8, device='cuda') if force >> 4 else None
     force = (force & 15) | ((force >> 4) & 15) << 4         # bits 8-11 tile config, bits 12-15 forced split-K (16 -> auto)
-    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64}.get(force & 15)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256}.get(force & 15)
     if bco and ((Co + 63) // 64 * 64) % bco:
         pytest.skip('tile does not divide Cout')
     g = torch.Generator().manual_seed(hash(case[0]) % 1000)
@@ -359,13 +359,13 @@ DGRAD_CASES = [('3x3_s1', 2, 128, 64, 11, 13, 3, 1, 1), ('3x3_s2', 1, 128, 128, 
                ('1x1_s1', 2, 256, 128, 7, 9, 1, 1, 0), ('3x3_s1_pad80', 1, 256, 80, 9, 9, 3, 1, 1)]
 
 
-@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 15])
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15])
 @pytest.mark.parametrize('case', DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
 def test_conv_dgrad_transposed(K, case, force):
     """mode 1 gather == autograd input-gradient; epilogue (acc + addend) * (mask > 0)."""
     L, ops = K
     _, N, Ci, Co, H, W, k, s, p = case
-    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64}.get(force)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256}.get(force)
     if bco and Ci % bco:
         pytest.skip('tile does not divide Cin')
     g = torch.Generator().manual_seed(len(case[0]))
@@ -695,6 +695,7 @@ def test_groupnorm_relu_fwd_bwd(K):
     (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 4),       # 128 x 128 tile (two cout tiles write one record)
     (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 7),       # 64 x 64 tile
     (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 3),       # 128 x 256 tile
+    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 9),       # 256 x 256 tile (its staged tile lies beyond the K loop's ring)
 ])
 def test_groupnorm_statistics_from_the_conv_epilogue(K, N, sizes, force):
     """conv -> GN -> ReLU (ConvModule, anchor_free_head.py:104-133) with the statistics left by the convolution's epilogue
@@ -905,7 +906,7 @@ def test_conv_in_register_epilogue_equals_staged_epilogue(K, force, flavour):
     both must equal the fp32 reference rounded to bf16 to within one bf16 step."""
     L, ops = K
     N, Ci, Co, H, W, k = 2, 128, 256, 24, 40, 3
-    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64}.get(force)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256}.get(force)
     if bco and Co % bco:
         pytest.skip('tile does not divide Cout')
     g = torch.Generator().manual_seed(11 + force)
