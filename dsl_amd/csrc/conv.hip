@@ -1107,6 +1107,215 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvK& p, f32x16 (&acc)
   }
 }
 
+// ================================================================================================
+// conv_h4_kernel: conv_pipe_kernel's tile, operands, arithmetic and summation order with the K loop re-cut into HALF K tiles
+// (32 channels: two MFMA k-steps) in a ring of FOUR half stages.  Why: with two whole stages the first fragment reads of K tile
+// kt + 1 can only be issued behind the barrier that ends tile kt - nothing guarantees earlier that every wave's DMA of that tile
+// has landed - and the matrix pipe drains behind every barrier until they return (tools/trace_conv.py: 350 - 500 of a tile's
+// ~2 450 cycles, the held-back MFMAs cover 190 of them).  With four half stages the half AFTER the next one is already complete at
+// a barrier, so the next half's first fragments are read BEFORE the barrier and its MFMAs issue right behind it; the DMA keeps the
+// same look-ahead in time (a half is fetched two half-stages before it is needed = one whole K tile).
+// LDS: per half stage a weight plane [BCO][64 B] and a pixel plane [BPXP][64 B] (BPXP: BPX rounded up to whole DMA passes of T / 4
+// rows; the surplus rows are out-of-range lanes: zeros nobody reads); 16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3) -
+// sixteen consecutive rows of a ds_read_b128 pass then cover all 64 banks once.
+// ================================================================================================
+template <int BCO, int BPX, int WCO, int WPX, bool GNB = false>
+__global__ __launch_bounds__(64 * WCO * WPX) void conv_h4_kernel(const ConvK p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int T = 64 * WCO * WPX;
+  constexpr int RPI = T / 4;                  // tile rows one DMA pass fills (4 lanes per 64-byte row)
+  constexpr int WPASS = BCO / RPI, XPASS = (BPX + RPI - 1) / RPI;
+  constexpr int BPXP = XPASS * RPI;
+  constexpr int PLANE_W = BCO * 64;
+  constexpr int HSTAGE = (BCO + BPXP) * 64;
+  constexpr int NH = 4;
+  constexpr int PT = BPX / WPX / 32, CT = BCO / WCO / 32;
+  constexpr int LPT = WPASS + XPASS;
+  static_assert(BCO % RPI == 0 && BCO == WCO * CT * 32 && BPX == WPX * PT * 32, "tile / thread mismatch");
+  static_assert(LPT % 2 == 0 && 2 * LPT <= 63, "pieces per half stage");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_co = wave / WPX, wave_px = wave % WPX;
+  const int wi = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.xcd_chunk || wi >= p.gx * p.gy * p.splits) return;
+  const int bz = wi / (p.gx * p.gy);
+  const int rem_t = wi - bz * (p.gx * p.gy);
+  const int by = rem_t / p.gx;
+  const int co0 = (rem_t - by * p.gx) * BCO;
+  const int px0 = by * BPX;
+  const int totpx = p.pxstart[p.nseg];
+  const int lrow = tid >> 2;
+  const int chunk = (tid & 3) ^ ((tid >> 4) & 3);       // source chunk (of the half's four) that belongs in LDS slot (tid & 3) of this row
+
+  const unsigned margin = (unsigned)(p.kw * p.lds * 2);
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.src) - margin), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, 0x7fffffff, 0x00020000);
+
+  const int kt0 = bz * p.kt_per_split;
+  const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+  const int h0 = 2 * kt0, hend = 2 * kt1;
+  int cidx = kt0 % p.kc;
+  int tap_r = (kt0 / p.kc) / p.kw, tap_s = (kt0 / p.kc) % p.kw;
+
+  unsigned r_cur[XPASS], r_step[XPASS], r_mask[XPASS];
+#pragma unroll
+  for (int i = 0; i < XPASS; ++i) {
+    const int trow = lrow + RPI * i;
+    const int gp = px0 + trow;
+    int seg = 0, img = 0, y = 0, x = 0;
+    const bool ok = gp < totpx && trow < BPX;
+    if (ok) decode_pixel(p, gp, seg, img, y, x);
+    const int sh = p.sh[seg], sw = p.sw[seg];
+    const int row0 = p.mode == 0 ? y * p.stride - p.pad : y + p.pad;
+    const int col0 = p.mode == 0 ? x * p.stride - p.pad : x + p.pad - (p.kw - 1);
+    unsigned m = 0;
+    for (int r = 0; r < p.kh; ++r) {
+      const int sy = p.mode == 0 ? row0 + r : row0 - r;
+      if (ok && (unsigned)sy < (unsigned)sh) m |= 1u << r;
+    }
+    for (int s_ = 0; s_ < p.kw; ++s_) {
+      const int sx = p.mode == 0 ? col0 + s_ : x + p.pad - s_;
+      if (ok && (unsigned)sx < (unsigned)sw) m |= 0x100u << s_;
+    }
+    r_mask[i] = m;
+    const unsigned pitch = (unsigned)(sw * p.lds * 2);
+    r_step[i] = p.mode == 0 ? pitch : 0u - pitch;
+    const unsigned base = (unsigned)(((int)(p.soff[seg]) + img * sh * sw + row0 * sw + col0) * p.lds + chunk * 8) * 2u + margin;
+    r_cur[i] = base + (unsigned)tap_r * r_step[i];
+  }
+  const unsigned w_voff = (unsigned)(lrow * (int)p.wrow + chunk * 8) * 2u;
+  const unsigned w_pass = (unsigned)(RPI * (int)p.wrow) * 2u;
+  unsigned w_soff = (unsigned)(co0 * (int)p.wrow + kt0 * BK) * 2u;
+
+  int h_next = h0;                  // half tile being fetched
+  unsigned t_sel = (1u << tap_r) | (0x100u << tap_s);
+  unsigned t_soff = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds * 2 + cidx * 128);
+  unsigned t_wv = w_voff;
+  int c_left = 2 * (p.kc - cidx);   // halves until the channel blocks wrap (tap advance)
+  unsigned r_v[XPASS];
+#pragma unroll
+  for (int i = 0; i < XPASS; ++i) r_v[i] = (r_mask[i] & t_sel) == t_sel ? r_cur[i] : 0x80000000u;
+  auto pieces = [&](auto lo_c, auto hi_c, const unsigned ld_off) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+    unsigned char* stage = smem + ld_off;
+#pragma unroll
+    for (int j = LO; j < HI; ++j) {
+      if (j < XPASS) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lptr_t)(stage + PLANE_W + (j * RPI + wave * 16) * 64), 16, (unsigned)r_v[j], (unsigned)t_soff, 0, 0);
+      } else {
+        const int i = j - XPASS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lptr_t)(stage + (i * RPI + wave * 16) * 64), 16, (unsigned)t_wv, (unsigned)(w_soff + i * w_pass), 0, 0);
+      }
+    }
+    if (HI == LPT) {                // half fully issued: advance to the next (r, s, channel block, half)
+      ++h_next;
+      w_soff += 64;
+      if (--c_left != 0) {
+        t_soff += 64;
+      } else {
+        c_left = 2 * p.kc;
+        const bool s_wrap = tap_s + 1 == p.kw;
+        tap_s = s_wrap ? 0 : tap_s + 1;
+        if (s_wrap) {
+          ++tap_r;
+#pragma unroll
+          for (int i = 0; i < XPASS; ++i) r_cur[i] += r_step[i];
+        }
+        t_sel = (1u << tap_r) | (0x100u << tap_s);
+        t_soff = (unsigned)((p.mode == 0 ? tap_s : p.kw - 1 - tap_s) * p.lds * 2);
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) r_v[i] = (r_mask[i] & t_sel) == t_sel ? r_cur[i] : 0x80000000u;
+      }
+      if (__builtin_expect(h_next >= hend, 0)) {      // past the last half: every lane out of range (zeros into a slot nobody reads)
+        asm volatile("" ::: "memory");
+        t_sel = 0xffffffffu;
+        t_wv = 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) r_v[i] = 0x80000000u;
+      }
+    }
+  };
+  using c0_t = std::integral_constant<int, 0>;
+  using cmid_t = std::integral_constant<int, LPT / 2>;
+  using clpt_t = std::integral_constant<int, LPT>;
+
+  f32x16 acc[CT][PT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int fswz = (frow >> 2) & 3;
+  const int a_off = (wave_co * (32 * CT) + frow) * 64;
+  const int b_off = PLANE_W + (wave_px * (32 * PT) + frow) * 64;
+  bf16x8 fa[2][CT], fb[2][PT];
+  auto lds_read = [&](const unsigned char* base, int kk, int f) {
+    const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) fa[f][ct] = *reinterpret_cast<const bf16x8*>(base + a_off + ct * 32 * 64 + coff);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) fb[f][pt] = *reinterpret_cast<const bf16x8*>(base + b_off + pt * 32 * 64 + coff);
+  };
+  auto mma = [&](int f) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
+  };
+  if (WCO * WPX == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  // prologue: three whole halves in flight; the first two have landed (for every wave: barrier) when the loop starts
+#pragma unroll
+  for (int s_ = 0; s_ < NH - 1; ++s_) pieces(c0_t{}, clpt_t{}, (unsigned)(s_ * HSTAGE));
+  wait_vmcnt<LPT>();
+  __builtin_amdgcn_s_barrier();
+  lds_read(smem, 0, 0);
+  unsigned slot = 0;                        // byte offset of the half stage being read
+  unsigned fslot = (NH - 1) * HSTAGE;       // ... of the one half h + 3 goes to (vacated by half h - 1 at the last barrier)
+#pragma nounroll
+  for (int h = h0; h < hend; ++h) {
+    const unsigned char* base = smem + slot;
+    const unsigned nslot = (slot + HSTAGE == NH * HSTAGE) ? 0u : slot + HSTAGE;
+    lds_read(base, 1, 1);
+    pieces(c0_t{}, cmid_t{}, fslot);
+    mma(0);
+    lds_read(smem + nslot, 0, 0);           // the NEXT half's first fragments: it landed two barriers ago
+    pieces(cmid_t{}, clpt_t{}, fslot);
+    mma(1);
+    sched_stage<CT * PT, CT + PT, LPT / 2>();
+    sched_stage<CT * PT, CT + PT, LPT - LPT / 2>();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own reads of half h done (its slot may be refilled), next fragments in registers
+    wait_vmcnt<LPT>();                      // own pieces of half h + 2 landed (half h + 3 may stay in flight)
+    __builtin_amdgcn_s_barrier();           // ... for every wave
+    fslot = slot;
+    slot = nslot;
+  }
+  wait_vmcnt<0>();                          // the out-of-range tail DMAs still write (zeros) into the ring
+
+  if (p.splits > 1) {                       // split-K: raw fp32 partial tile -> workspace [split][pixel][cd_pad]
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int gp = px0 + wave_px * (32 * PT) + pt * 32 + (lane & 31);
+      if (gp >= totpx) continue;
+      float* row = p.ws + ((long long)bz * totpx + gp) * p.cd_pad;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = co0 + wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 o = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(row + co) = o;
+        }
+    }
+    return;
+  }
+  conv_tile_epilogue<BCO, BPX, WCO, WPX, CT, PT, NH * HSTAGE, GNB>(p, acc, smem, co0, px0, totpx, [](int) {});
+}
+
 // LDS the epilogue may use: the K loop's ring, or - the 256 x 256 tile, whose bf16 rows do not fit in its two-stage ring - the staged
 // tile plus the GroupNorm reduction scratch (the host sizes the launch's LDS the same way)
 constexpr int conv_epi_ring(int bco, int bpx, int ring, int t) {
@@ -3311,7 +3520,8 @@ double conv_cost_us(int ci, long long px, int cd_pad, int ktiles, int sp, bool o
 // picks the tile configuration (-1 = v1 kernel) and the split-K factor for a conv
 void conv_choose(const dsl_conv_desc* d, long long px, int ktiles, int* pick_out, int* splits_out) {
   const bool smallc = (d->flags & DSL_CONV_SMALL_C) != 0;
-  const int force = (d->flags >> 8) & 15;          // test hook: 1..6 = tile config, 15 = v1 kernel
+  int force = (d->flags >> 8) & 15;                // test hook: 1..9 = tile config, 10 = 256 x 192 with the half-stage K loop, 15 = v1 kernel
+  if (force == 10) force = 1;
   const int force_split = (d->flags >> 12) & 15;   // test hook: split-K factor
   int pick = -1, splits = 1;
   long long src_px = 0;
@@ -3670,7 +3880,24 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
         default: LAUNCH2(64, 256, 1, 4, 2); break;
       }
     } else {
-      if (k.gnx) {            // (conv_gn_ok: one of the two tiles below, none of the variant knobs)
+      // the half-stage K loop (conv_h4_kernel) for the 256 x 192 tile: DSL_CONV_H4=1 (off by default: neutral in the step,
+      // LAB_NOTES.md), or tile hook 10 of the tests
+      static const int h4_env = [] { const char* e = getenv("DSL_CONV_H4"); return e ? atoi(e) : 0; }();
+      const bool h4 = pick == 0 && !smallc && !(tall & 1) && !hold && !ldw && (h4_env != 0 || ((d->flags >> 8) & 15) == 10);
+      if (h4) {
+        lds = (size_t)4 * (256 + 256) * 64;
+#define LAUNCHH(G_)                                                                                           \
+  do {                                                                                                        \
+    static bool attr_h = false;                                                                               \
+    if (!attr_h) {                                                                                            \
+      hipFuncSetAttribute((const void*)conv_h4_kernel<256, 192, 4, 2, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_h = true;                                                                                          \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_h4_kernel<256, 192, 4, 2, G_>), dim3(8 * k.xcd_chunk), dim3(512), lds, st, k);   \
+  } while (0)
+        if (k.gnx) LAUNCHH(true); else LAUNCHH(false);
+#undef LAUNCHH
+      } else if (k.gnx) {            // (conv_gn_ok: one of the two tiles below, none of the variant knobs)
         if (pick == 0) LAUNCH3G(256, 192, 4, 2, 2); else LAUNCH3G(256, 128, 4, 2, 3);
       } else
       switch (pick) {

@@ -126,7 +126,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 4 + (3 << 4), 5 + (2 << 4), 6 + (5 << 4), 7 + (2 << 4), 0 + (16 << 4)])
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 10 + (2 << 4), 4 + (3 << 4), 5 + (2 << 4), 6 + (5 << 4), 7 + (2 << 4), 0 + (16 << 4)])
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_forward(K, case, force):
     """force: 0 = library's own tile choice, 1..5 = v2 (DMA-to-LDS) tile configs, 15 = v1 kernel."""
@@ -134,7 +134,7 @@ def test_conv_forward(K, case, force):
     _, N, Ci, Co, H, W, k, s, p = case
     ws = torch.empty(64 << 20, dtype=torch.uint8, device='cuda') if force >> 4 else None
     force = (force & 15) | ((force >> 4) & 15) << 4         # bits 8-11 tile config, bits 12-15 forced split-K (16 -> auto)
-    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256}.get(force & 15)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256, 10: 256}.get(force & 15)
     if bco and ((Co + 63) // 64 * 64) % bco:
         pytest.skip('tile does not divide Cout')
     g = torch.Generator().manual_seed(hash(case[0]) % 1000)
@@ -153,6 +153,32 @@ def test_conv_forward(K, case, force):
     got = from_nhwc(y)
     assert torch.allclose(got, ref, rtol=1e-2, atol=1e-2), (got - ref).abs().max()
     assert (got - bf(ref)).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('k,Ci', [(3, 256), (1, 512), (3, 64)])
+def test_conv_half_stage_k_loop_is_bit_identical(K, mode, k, Ci):
+    """conv_h4_kernel (tile hook 10: the 256 x 192 tile with the K loop cut into half stages in a ring of four) against
+    conv_pipe_kernel on the same tile: same operands, same k order, same epilogue - the same bits; forward and transposed (data
+    gradient) addressing, ragged pixel count, multi-level segments."""
+    L, ops = K
+    g = torch.Generator().manual_seed(77 + k + Ci + mode)
+    N, sizes, Co = 2, [(37, 45), (19, 23), (5, 7)], 256
+    P = sum(h * w for h, w in sizes) * N
+    x = _multiseg([rnd(N, Ci, h, w, g=g) for h, w in sizes])
+    w = (torch.randn(Co if mode == 0 else Ci, k * k * (Ci if mode == 0 else Co), generator=g) * 0.05).bfloat16().cuda()
+    if mode == 1:
+        w = (torch.randn(Ci, k, k, Co, generator=g) * 0.05).bfloat16().cuda()
+    scale, bias = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    outs = []
+    for force in (1, 10):
+        y = torch.zeros(P, Co, dtype=torch.bfloat16, device='cuda')
+        ops.conv2d(x, w, y, n=N, grid=sizes, src_hw=sizes, dst_hw=sizes, cs=Ci, cd=Co, cd_pad=Co, ldd=Co, kh=k, kw=k, stride=1,
+                   pad=k // 2, mode=mode, flags=L.CONV_RELU_OUT | (force << 8), scale=scale, bias=bias)
+        sync()
+        outs.append(y)
+    assert float(outs[0].float().abs().max()) > 0
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_conv_stem_small_c(K):
@@ -359,13 +385,13 @@ DGRAD_CASES = [('3x3_s1', 2, 128, 64, 11, 13, 3, 1, 1), ('3x3_s2', 1, 128, 128, 
                ('1x1_s1', 2, 256, 128, 7, 9, 1, 1, 0), ('3x3_s1_pad80', 1, 256, 80, 9, 9, 3, 1, 1)]
 
 
-@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15])
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15])
 @pytest.mark.parametrize('case', DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
 def test_conv_dgrad_transposed(K, case, force):
     """mode 1 gather == autograd input-gradient; epilogue (acc + addend) * (mask > 0)."""
     L, ops = K
     _, N, Ci, Co, H, W, k, s, p = case
-    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256}.get(force)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256, 10: 256}.get(force)
     if bco and Ci % bco:
         pytest.skip('tile does not divide Cin')
     g = torch.Generator().manual_seed(len(case[0]))
@@ -906,7 +932,7 @@ def test_conv_in_register_epilogue_equals_staged_epilogue(K, force, flavour):
     both must equal the fp32 reference rounded to bf16 to within one bf16 step."""
     L, ops = K
     N, Ci, Co, H, W, k = 2, 128, 256, 24, 40, 3
-    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256}.get(force)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256, 10: 256}.get(force)
     if bco and Co % bco:
         pytest.skip('tile does not divide Cout')
     g = torch.Generator().manual_seed(11 + force)

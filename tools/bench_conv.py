@@ -46,7 +46,7 @@ def bench(name, ci, co, k, s, sizes_in):
     import ctypes as C
     res = [f'{name:28s}']
     for force in FORCE:
-        bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256}.get(force & 15)
+        bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64, 9: 256, 10: 256}.get(force & 15)
         if bco and co % bco:
             res.append(f'f{force}: n/a')
             continue
