@@ -373,7 +373,16 @@ class TextLoggerHook(Hook):
         if not buf:
             return
         keys = list(buf[0][0].keys())
-        avg = {k: float(sum(float(lv[k]) * n for lv, n in buf) / sum(n for _, n in buf)) for k in keys}
+        # ONE device-to-host read for the whole interval (lazy log vars are 0-dim device tensors: float() on each of interval x keys
+        # of them is as many stream synchronisations - 40 per line at the default interval, ≈ 2 % of the supervised step's throughput)
+        flat = [lv[k] for lv, _ in buf for k in keys]
+        if flat and all(torch.is_tensor(v) and v.is_cuda for v in flat):
+            host = torch.stack([v.detach().reshape(()) for v in flat]).tolist()
+        else:
+            host = [float(v) for v in flat]
+        nk = len(keys)
+        tot = sum(n for _, n in buf)
+        avg = {k: float(sum(host[i * nk + j] * buf[i][1] for i in range(len(buf))) / tot) for j, k in enumerate(keys)}
         rec = dict(mode='train', epoch=runner.epoch + 1, iter=runner.inner_iter + 1, lr=runner.current_lr()[0], **avg)
         if runner.logger:
             runner.logger.info('Epoch [%d][%d/%d]\tlr: %.3e, %s', rec['epoch'], rec['iter'], len(runner.data_loader),
