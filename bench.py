@@ -72,12 +72,25 @@ def synth_batch(rank, n_img=2, H=800, W=1344, device='cuda'):
     return dict(img=img.to(device), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
 
 
+def _release_earlier_models():
+    """Before an extra's model is built: collect the models earlier measurements left behind NOW.  Otherwise the garbage collector
+    finds them some iterations into the next timed window, and releasing a model's device-side state (events, the library's cached
+    tables) stalls the device once for ~30 ms - 375 instead of 437 img/s over a 40-step window, and never again in later windows of
+    the same model (tools/second_model_probe.py, profiles/r04_second_model.txt)."""
+    import gc
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+
 def fp8_step_timing(batch, steps=20, warm=5):
     """BASELINE.json configs[4], first slice (beside the bf16 headline, never instead of it): the same supervised step with the head
     towers' forward convolutions on the fp8 MFMA path (FCOS(fp8=dict(layers='towers')), dynamic per-tensor activation scales)."""
     from dsl_amd.data import mark_ready
     from dsl_amd.optim import FlatSGD
     from dsl_amd.registry import build_detector
+    _release_earlier_models()
     model = build_detector(model_cfg(fp8=True)).cuda()
     opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
     ev = torch.cuda.Event()
@@ -139,6 +152,7 @@ def train_detector_timing(batch, steps=20, warm=5):
     from dsl_amd.apis import train_detector
     from dsl_amd.registry import Config, build_detector
     import tempfile
+    _release_earlier_models()
     model = build_detector(model_cfg())
     loader = _ResidentLoader(batch, warm + steps, warm)
     with tempfile.TemporaryDirectory() as wd:
@@ -257,6 +271,7 @@ def dsl_iteration_timing(steps=12, warm=6, variants=None):
     out = {}
     for refresh, rla, asyn in variants or ((False, False, False), (True, False, False), (True, False, True), (False, True, False),
                                            (True, True, False), (True, True, True)):
+        _release_earlier_models()
         student, teacher = build_detector(model_cfg(dsl=True, rla=rla)).cuda(), build_detector(model_cfg(dsl=True, rla=rla)).cuda()
         if rla:
             import warnings
