@@ -547,7 +547,7 @@ def main():
         # (train_detector last: every model instance creates streams, and stream creation order decides which streams share one of
         # the four hardware queues - DESIGN 3.2i; the semi-supervised variants keep the order their round-3 numbers were taken in)
         extra = dict(dsl_iteration=dsl_iteration_timing(), fp8_towers=fp8_step_timing(batch), datapath=datapath_timing())
-        extra['train_detector'] = train_detector_timing(batch)
+        extra['train_detector'] = train_detector_timing(batch, steps=60, warm=10)
         if roof is not None:        # BASELINE.json configs[2] beside the headline, also where a record that keeps `roofline` keeps it
             roof['configs2_dsl_iteration_ms'] = {k: v for k, v in extra['dsl_iteration'].items() if k.startswith('ms_per_iter')}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
