@@ -353,7 +353,9 @@ int launch_bneck(const BnK& k, hipStream_t st) {
     }
     attr = true;
   }
-  const unsigned grid = (unsigned)(k.tiles < 256 ? k.tiles : 256);
+  // persistent workgroups, one per CU at most; DSL_BNECK_GRID caps the grid (a narrower prefix leaves CUs to the pass it runs beside)
+  static const int cap = [] { const char* e = getenv("DSL_BNECK_GRID"); const int v = e ? atoi(e) : 256; return v >= 8 && v <= 256 ? v : 256; }();
+  const unsigned grid = (unsigned)(k.tiles < cap ? k.tiles : cap);
   hipLaunchKernelGGL((bottleneck64_kernel<CIN, DS>), dim3(grid), dim3(BN_T), lds, st, k);
   return 0;
 }
