@@ -962,6 +962,34 @@ class Plan:
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
             if li == PREFIX_LI:
                 ol.record(L.SLOT_TAIL, stream=0)       # from here on the next step's frozen prefix may run beside this pass
+            # Last segment, round 4: behind the data-gradient chains nothing but this stage's weight gradients is left, and four of them
+            # used to run ONE AFTER THE OTHER on the weight-gradient stream (conv3's group, block 0's conv1 and downsample, conv1's
+            # group: 272 us in profiles/r04_sequence.txt, each a launch that cannot fill the chip) while the caller's stream ran
+            # conv2's group and stream 3 nothing.  DSL_TAIL_SPREAD: 1 = block 0's two single launches go to stream 3, 2 = conv1's
+            # group as well; the weight-gradient stream waits for stream 3 before the bucket's event is recorded.
+            spread = int(os.environ.get('DSL_TAIL_SPREAD', '0')) if (li == 1 and BB and self._multi_on and GROUP and GROUP_LAST) else 0
+            on_br = []
+            if spread:
+                on_br = [sub for sub in self._wg_pending if len(sub) == 1]
+                self._wg_pending = [sub for sub in self._wg_pending if len(sub) != 1]
+                if spread >= 2 and g1:
+                    on_br.append(list(g1))
+                    g1 = []
+                if on_br:
+                    ol.fork(BB)          # stream 3 behind the caller's stream, which has joined both chains
+                    for sub in on_br:
+                        if len(sub) == 1:
+                            need = L.lib.dsl_wgrad_workspace_bytes(C.byref(sub[0]))
+                            ws = self._wg_buf(need, 'wg_ws_tail')
+                            sub[0].workspace, sub[0].workspace_bytes = L.ptr(ws), ws.numel()
+                            ol._add(L.OP_WGRAD, sub[0], i=(0, 0, 0, 0, 0, 0, BB))
+                        else:
+                            arr0 = (L.WgradDesc * len(sub))()
+                            for i_, d_ in enumerate(sub):
+                                C.memmove(C.addressof(arr0[i_]), C.addressof(d_), C.sizeof(L.WgradDesc))
+                            need = L.lib.dsl_wgrad_group_workspace_bytes(arr0, len(sub))
+                            arr = ops.wgrad_group(sub, workspace=self._wg_buf(need, 'wg_ws_tail'))
+                            ol._add(L.OP_WGRAD_GROUP, arr, i=(len(arr), 0, 0, 0, 0, 0, BB))
             if GROUP and (li > 1 or GROUP_LAST):
                 # last segment: the caller's stream has nothing left to do, it takes part of the groups itself
                 on_main = os.environ.get('DSL_TAIL_MAIN', '2') if li == 1 else '0'     # measured: tools/experiments_r2.txt (exp_r2w)
@@ -970,6 +998,8 @@ class Plan:
                     mine = str(gi) in on_main
                     self._wgrad_group(ol, grp_descs, side=SIDE and not mine, ws_name='wg_ws_main' if mine else 'wg_ws')
             self._flush_wgrads(ol, side=SIDE)
+            if on_br:
+                ol.fork(1, other=BB)          # the bucket's event (recorded on the weight-gradient stream) covers stream 3's launches too
             seg = 4 - li                      # 1, 2, 3
             ol.record(seg)
             if li == 1:                       # last segment: everything must be complete when the list returns
