@@ -72,6 +72,13 @@ def synth_batch(rank, n_img=2, H=800, W=1344, device='cuda'):
     return dict(img=img.to(device), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
 
 
+def _lib_option(name):
+    from dsl_amd import _lib as L
+    v = C.c_int(0)
+    L.check(L.lib.dsl_get_option(name.encode(), C.byref(v)), 'dsl_get_option')
+    return int(v.value)
+
+
 def _release_earlier_models():
     """Before an extra's model is built: collect the models earlier measurements left behind NOW.  Otherwise the garbage collector
     finds them some iterations into the next timed window, and releasing a model's device-side state (events, the library's cached
@@ -317,8 +324,6 @@ def dsl_iteration_timing(steps=12, warm=6, variants=None):
         gaps = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
         dt = gaps[len(gaps) // 2] * 1e-3
         out.setdefault('spread', {})
-        if os.environ.get('DSL_BENCH_VERBOSE'):
-            print(f'dsl_iteration refresh={refresh} rla={rla} async={asyn}: {dt * 1e3:.3f} ms', file=sys.stderr, flush=True)
         key = ('ms_per_iter' if not refresh else 'ms_per_iter_with_teacher_refresh' + ('_async' if asyn else '')) + ('_rla_backbone' if rla else '')
         out[key] = round(dt * 1e3, 3)
         out['spread'][key] = [round(gaps[0], 3), round(gaps[-1], 3)]           # min / max interval, ms
@@ -365,8 +370,6 @@ def main():
     # (no attribute is set here that dsl_amd.apis.train_detector does not set: lazy log vars, the eager backward and the pipelined
     # frozen prefix are the detector's defaults - the headline is the product path; extra.train_detector times the same step
     # through train_detector + the runner's hooks)
-    if os.environ.get('DSL_BENCH_PIPE', '1') == '0':      # A/B knob; the product default (on) is what the headline uses
-        model.pipeline_prefix = False
     if world > 1:
         model = HipDistributedDataParallel(model)
     det = model.module if world > 1 else model
@@ -534,7 +537,7 @@ def main():
         extra = dict(comm=dict(carrier='C-ABI rcclComm_t (dsl_allreduce_bucket)' if det.rccl is not None else 'torch.distributed process group',
                                backend=dist.get_backend(), rccl_ranks=int(L.lib.dsl_comm_size(det.rccl.comm)) if det.rccl is not None else dist.get_world_size(),
                                devices=devs, grad_dtype='bf16' if det.grad_bf16 else 'fp32',
-                               wgrad_slots=int(os.environ.get('DSL_WGRAD_SLOTS', '128')),
+                               wgrad_slots=_lib_option('wgrad_slots'),
                                buckets=bk, step_ms=round(tr['t0'].elapsed_time(ev_end), 3),
                                ms_per_step_comm_disabled=round(float(t_off) / max(5, args.steps // 2) * 1e3, 3),
                                ms_per_step=round(dt / args.steps * 1e3, 3),

@@ -28,11 +28,9 @@ CONV_FP8 = 128
 OP_RLA = 17
 OP_PACK_DGRAD = 18
 OP_WGRAD_MULTI = 19
-OP_PAIR = 20
 OP_PROF = 21
 OP_QUANT_FP8, OP_QUANT_FP8_W, OP_FP8_COMB = 22, 23, 24
 OP_STEM_POOL = 25
-OP_BNECK64 = 26
 PROF_CLASSES = 8
 MAX_MULTI = 16
 SLOT_TAIL, SLOT_PREFIX = 13, 14     # pipelined frozen prefix: 'previous backward's data-gradient chain done', 'prefix of this step done'
@@ -113,13 +111,6 @@ class PackItem(C.Structure):
                 ('block_start', C.c_int32), ('tiles_ci', C.c_int32), ('tiles_co', C.c_int32), ('tapmap', C.c_int32)]
 
 
-class Bneck64Desc(C.Structure):
-    _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('w1', C.c_void_p), ('w2', C.c_void_p), ('w3', C.c_void_p), ('wds', C.c_void_p),
-                ('s1', C.c_void_p), ('b1', C.c_void_p), ('s2', C.c_void_p), ('b2', C.c_void_p), ('s3', C.c_void_p), ('b3', C.c_void_p),
-                ('sds', C.c_void_p), ('bds', C.c_void_p),
-                ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('ld_x', C.c_int32), ('ld_out', C.c_int32)]
-
-
 class RlaDesc(C.Structure):
     _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 8), ('f', C.c_float * 2), ('rows', C.c_int64), ('p', C.c_void_p * 10)]
 
@@ -132,14 +123,6 @@ class BnPostItem(C.Structure):
 
 class RecSumItem(C.Structure):
     _fields_ = [('rec', C.c_void_p), ('out_a', C.c_void_p), ('out_b', C.c_void_p), ('nrec', C.c_int32), ('pad_', C.c_int32)]
-
-
-class PairDesc(C.Structure):
-    _fields_ = [('m', C.c_int32), ('p', C.c_int32), ('a', C.c_void_p), ('lda', C.c_int32), ('relu1', C.c_int32), ('wa', C.c_void_p),
-                ('scale1', C.c_void_p), ('bias1', C.c_void_p), ('addend', C.c_void_p), ('ldadd', C.c_int32), ('ldm1', C.c_int32),
-                ('mask1', C.c_void_p), ('mid', C.c_void_p), ('ldmid', C.c_int32), ('relu2', C.c_int32), ('wb', C.c_void_p),
-                ('scale2', C.c_void_p), ('bias2', C.c_void_p), ('mask2', C.c_void_p), ('ldm2', C.c_int32), ('ldo', C.c_int32),
-                ('out', C.c_void_p)]
 
 
 class ImagePrepItem(C.Structure):
@@ -184,9 +167,8 @@ _SIGS = {
     'dsl_wgrad_multi_config': [_vp], 'dsl_wgrad_multi_table_bytes': [], 'dsl_wgrad_multi_workspace_bytes': [_vp, _vp, _i],
     'dsl_wgrad_multi_build': [_vp, _vp, _i, _vp, C.c_size_t, _vp, C.c_size_t], 'dsl_conv2d_wgrad_multi': [_vp, _vp, _vp], 'dsl_wgrad_multi_info': [_vp, _vp, _vp, _vp, _vp, _vp],
     'dsl_wgrad_plan_probe': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    'dsl_image_prep': [_vp, _i, _vp, _i, _i, _vp], 'dsl_conv1x1_pair': [_vp, _vp], 'dsl_bottleneck64': [_vp, _vp],
+    'dsl_image_prep': [_vp, _i, _vp, _i, _i, _vp],
     'dsl_pack_image': [_vp, _vp, _i, _i, _i, _vp], 'dsl_stem_pool': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_stem_pool_half': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], 'dsl_maxpool3x3s2': [_vp, _vp, _i, _i, _i, _i, _vp],
-    'dsl_conv3x3_c64_patch': [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_maxpool3x3s2_ld': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_avgpool2x2': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_avgpool2x2_bwd': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
@@ -216,6 +198,7 @@ _SIGS = {
     'dsl_allreduce_bucket_bf16': [_vp, _vp, C.c_size_t, _vp],
     'dsl_cast_f32': [_vp, _vp, _l, _vp], 'dsl_sumsq_partial': [_vp, _l, _vp, _vp], 'dsl_sumsq_fold': [_vp, _i, _vp, _vp],
     'dsl_pseudo_label_fuse_history': [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
+    'dsl_set_option': [C.c_char_p, _i], 'dsl_get_option': [C.c_char_p, _vp],
     'dsl_run_ops': [_vp, _i, _vp], 'dsl_stream_wait_slot': [_i, _vp], 'dsl_stream_record_slot': [_i, _vp], 'dsl_side_stream': [_i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_prof_read2': [_vp, _vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
 }
 MISSING = []
@@ -224,6 +207,11 @@ for _name, _args in _SIGS.items():
         getattr(lib, _name).argtypes = _args
     except AttributeError:      # reported by tests/test_abi.py; calling it raises AttributeError
         MISSING.append(_name)
+
+
+if 'dsl_set_option' not in MISSING:
+    from . import tuning as _tuning
+    _tuning.push_lib_options(lib)       # DSL_TUNE's lib.* keys -> the library's option table (it reads no environment variable)
 
 
 def check(rc, what=''):

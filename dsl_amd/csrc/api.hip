@@ -20,6 +20,37 @@ void dsl_set_error(const char* fmt, ...) {
 extern "C" const char* dsl_last_error(void) { return g_err; }
 extern "C" int dsl_version(void) { return 100; }
 
+// ---- library options (dsl_set_option): the library reads no environment variable; a host (dsl_amd/tuning.py reads DSL_TUNE once)
+// sets these before the first launch.  Values are read where the work is planned, so an option set later applies to later plans.
+namespace {
+struct Option { const char* name; int value; };
+Option g_options[] = {
+    {"wgrad_slots", 128},    // workgroup budget of a weight-gradient launch that runs beside the caller's chain (dsl_wgrad_desc.slots = 0)
+    {"side_cus", 0},         // > 0: side stream 1 (weight gradients) is confined to this many CUs per XCD (before the first dsl_run_ops)
+    {"debug_sync", 0},       // 1: drain the device after every op of dsl_run_ops and name it on stderr
+    {"skip_kinds", 0},       // step-level ablation (tools/step_ablation.sh): bit mask of op kinds dsl_run_ops does not launch - timing only
+};
+}  // namespace
+int dsl_option(const char* name) {
+  for (const Option& o : g_options)
+    if (!strcmp(o.name, name)) return o.value;
+  return 0;
+}
+extern "C" int dsl_set_option(const char* name, int value) {
+  DSL_CHECK(name != nullptr, "dsl_set_option: null name");
+  for (Option& o : g_options)
+    if (!strcmp(o.name, name)) { o.value = value; return 0; }
+  dsl_set_error("dsl_set_option: unknown option '%s'", name);
+  return -1;
+}
+extern "C" int dsl_get_option(const char* name, int* value) {
+  DSL_CHECK(name != nullptr && value != nullptr, "dsl_get_option: null argument");
+  for (const Option& o : g_options)
+    if (!strcmp(o.name, name)) { *value = o.value; return 0; }
+  dsl_set_error("dsl_get_option: unknown option '%s'", name);
+  return -1;
+}
+
 namespace {
 // side streams + a ring of events per device, created lazily (host objects, no device memory)
 constexpr int kEvRing = 256, kSide = 3;
@@ -29,14 +60,11 @@ int g_evpos[16] = {};
 bool g_init[16] = {};
 hipEvent_t g_named[16][16] = {};        // DSL_OP_RECORD / DSL_OP_WAIT slots
 bool g_named_set[16][16] = {};
-// Side stream 1 carries the weight gradients.  DSL_SIDE_CUS=k (k < 32) confines it to k of the 32 CUs of every XCD
+// Side stream 1 carries the weight gradients.  Option side_cus = k (k < 32) confines it to k of the 32 CUs of every XCD
 // (hipExtStreamCreateWithCUMask; bit i of the mask = CU i/8 of XCD i%8, pinned by tests/test_kernels_gpu.py::
 // test_probe_cu_mask): its long-running 128 KB-LDS workgroups then cannot occupy the CUs the caller's latency-critical
 // kernel chain needs.  Streams 2, 3 (forward tower overlap) stay unrestricted.
-int side_cus() {
-  static const int k = [] { const char* e = getenv("DSL_SIDE_CUS"); return e ? atoi(e) : 0; }();
-  return k;
-}
+int side_cus() { return dsl_option("side_cus"); }
 void side_init(int dev) {
   if (g_init[dev]) return;
   for (int i = 0; i < kSide; ++i) {
@@ -47,15 +75,6 @@ void side_init(int dev) {
       for (int b = 0; b < 256; ++b)
         if (b / 8 < k) mask[b >> 5] |= 1u << (b & 31);
       if (hipExtStreamCreateWithCUMask(&g_side[dev][i], 8, mask) == hipSuccess) continue;
-      (void)hipGetLastError();
-    }
-    // DSL_SIDE_PRIO: a = lowest priority for side stream 1 (weight gradients), b = lowest for all side streams; the caller's
-    // stream keeps its own (normal) priority, so its kernels' workgroups win the dispatcher when slots free up
-    static const char prio = [] { const char* e = getenv("DSL_SIDE_PRIO"); return e ? e[0] : '0'; }();
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);        // lo = numerically greatest = least priority
-    if ((prio == 'a' && i == 0) || prio == 'b') {
-      if (hipStreamCreateWithPriority(&g_side[dev][i], hipStreamNonBlocking, lo) == hipSuccess) continue;
       (void)hipGetLastError();
     }
     hipStreamCreateWithFlags(&g_side[dev][i], hipStreamNonBlocking);
@@ -83,7 +102,7 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
     const dsl_op& o = ops[k];
     int rc = 0;
     hipStream_t st = main_st;
-    static const bool dbg_pre = [] { const char* e = getenv("DSL_DEBUG_SYNC"); return e && e[0] == '1'; }();
+    const bool dbg_pre = dsl_option("debug_sync") == 1;
     if (dbg_pre) {
       fprintf(stderr, "[dsl_run_ops] start op %d/%d kind %d stream %d desc %p p0 %p p1 %p\n", k, n_ops, o.kind, o.i[6], o.desc, o.p[0], o.p[1]);
       if (o.kind == DSL_OP_CONV && o.desc) {
@@ -97,10 +116,10 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
       dsl_prof_phase(o.i[0], o.i[1], o.l[0], o.l[1], pick(o.i[6]));
       continue;
     }
-    // Step-level ablation (tools/step_ablation.sh; results are WRONG, only the clock is read): DSL_SKIP_KINDS = bit mask of op kinds
+    // Step-level ablation (tools/step_ablation.sh; results are WRONG, only the clock is read): option skip_kinds = bit mask of op kinds
     // that are not launched (ordering ops are never skipped) - "what would the step gain if this component cost nothing?", measured
     // under the step's real contention instead of estimated from standalone kernel times.  Bit 30: only the ops of side stream 1.
-    static const unsigned skip_kinds = [] { const char* e = getenv("DSL_SKIP_KINDS"); return e ? (unsigned)strtoul(e, nullptr, 0) : 0u; }();
+    static const unsigned skip_kinds = (unsigned)dsl_option("skip_kinds");     // (read once: set it before the first dsl_run_ops)
     if (skip_kinds && o.kind < 30 && (skip_kinds >> o.kind & 1u) && o.kind != DSL_OP_FORK && o.kind != DSL_OP_JOIN &&
         o.kind != DSL_OP_RECORD && o.kind != DSL_OP_WAIT && (!(skip_kinds >> 30 & 1u) || o.i[6] == 1))
       continue;
@@ -134,8 +153,6 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
       case DSL_OP_WGRAD: rc = dsl_conv2d_wgrad((const dsl_wgrad_desc*)o.desc, stream); break;
       case DSL_OP_WGRAD_GROUP: rc = dsl_conv2d_wgrad_group((const dsl_wgrad_desc*)o.desc, o.i[0], stream); break;
       case DSL_OP_WGRAD_MULTI: rc = dsl_conv2d_wgrad_multi(o.p[0], o.p[1], stream); break;
-      case DSL_OP_PAIR: rc = dsl_conv1x1_pair((const dsl_pair_desc*)o.desc, stream); break;
-      case DSL_OP_BNECK64: rc = dsl_bottleneck64((const dsl_bneck64_desc*)o.desc, stream); break;
       case DSL_OP_GN_FWD: rc = dsl_groupnorm_relu_fwd((const dsl_gn_desc*)o.desc, stream); break;
       case DSL_OP_GN_BWD: rc = dsl_groupnorm_relu_bwd((const dsl_gn_desc*)o.desc, stream); break;
       case DSL_OP_MAXPOOL: rc = dsl_maxpool3x3s2_ld(o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] > 0 ? o.i[4] : o.i[3], stream); break;
@@ -181,9 +198,8 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
         return -1;
     }
     if (rc != 0) return rc;
-    // DSL_DEBUG_SYNC=1: drain the device after every op and name it - a faulting launch is then the last line on stderr
-    static const bool dbg_sync = [] { const char* e = getenv("DSL_DEBUG_SYNC"); return e && e[0] == '1'; }();
-    if (dbg_sync) {
+    // option debug_sync = 1: drain the device after every op and name it - a faulting launch is then the last line on stderr
+    if (dbg_pre) {
       const hipError_t e = hipDeviceSynchronize();
       fprintf(stderr, "[dsl_run_ops] op %d/%d kind %d stream %d -> %s\n", k, n_ops, o.kind, o.i[6], hipGetErrorString(e));
       fflush(stderr);

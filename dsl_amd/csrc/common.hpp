@@ -17,6 +17,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define WAVE 64
 
 void dsl_set_error(const char* fmt, ...);
+int dsl_option(const char* name);        // library options (dsl_set_option, api.hip)
 bool dsl_prof_active();
 int dsl_prof_begin(int cls, double flops, hipStream_t st, double bytes = 0.0);
 void dsl_prof_end(int id, hipStream_t st);

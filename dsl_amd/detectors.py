@@ -220,13 +220,24 @@ _ROLE_STREAMS = {}
 def role_stream(role, device=None, priority=0):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     key = (role, dev)
-    if os.environ.get('DSL_ROLE_STREAMS', '1') == '0':          # (experiment: a stream per instance, as before round 4)
-        return torch.cuda.Stream(device=dev, priority=priority) if priority else torch.cuda.Stream(device=dev)
     st = _ROLE_STREAMS.get(key)
     if st is None:
         st = torch.cuda.Stream(device=dev, priority=priority) if priority else torch.cuda.Stream(device=dev)
         _ROLE_STREAMS[key] = st
     return st
+
+
+def _check_grad_now(det):
+    """Should this backward call verify its incoming gradient (one host sync)?  Always when the step syncs anyway or the tuning key
+    asks for it; otherwise on the detector's first three backward calls only."""
+    from .tuning import tune
+    if not det.lazy_log or tune('check_backward_grad') != '0':
+        return True
+    left = getattr(det, '_grad_checks_left', 3)
+    if left > 0:
+        det._grad_checks_left = left - 1
+        return True
+    return False
 
 
 class _LossDict(OrderedDict):
@@ -249,7 +260,7 @@ class _TotalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         det = ctx.det
-        if not det.lazy_log or os.environ.get('DSL_CHECK_BACKWARD_GRAD'):
+        if _check_grad_now(det):
             if float(g) != 1.0:
                 raise NotImplementedError(f'dsl_amd: loss.backward() with a gradient of {float(g)} for the total loss: scale through '
                                           'FCOS.loss_scale (folded into the loss kernel), not by scaling the loss tensor')
@@ -277,10 +288,11 @@ class _TrainStepFn(torch.autograd.Function):
         """The backward lists compute d(sum of the losses)/d(parameters): the loss kernel already produced the head
         gradients for d(total)/d(loss_k) = grad_scale (1/world).  Any other incoming gradient - loss scaling, loss / k for
         gradient accumulation, re-weighted loss keys - is NOT representable: it is rejected instead of silently ignored.
-        The check reads g back (one host sync), so it runs whenever the step syncs anyway (lazy_log False) or when
-        DSL_CHECK_BACKWARD_GRAD=1; fold a constant factor into `FCOS.loss_scale` instead."""
+        The check reads g back (one host sync), so it runs whenever the step syncs anyway (lazy_log False), on a detector's first
+        backward calls (a loop that scales its loss does so from the first step on) and on every step under the tuning key
+        check_backward_grad=1; fold a constant factor into `FCOS.loss_scale` instead."""
         det = ctx.det
-        if not det.lazy_log or os.environ.get('DSL_CHECK_BACKWARD_GRAD'):
+        if _check_grad_now(det):
             k = ctx.n_losses
             gh = g.tolist()       # d(total)/d(term) = 1 for every term: either through the terms or through the kernel's own sum
             if not (all(v == 1 for v in gh[:k]) and gh[k] == 0) and not (all(v == 0 for v in gh[:k]) and gh[k] == 1):
@@ -326,8 +338,8 @@ class FCOS(nn.Module):
         # (detectors/base.py:175-208 calls .item() per key per iteration).  False: python floats, one host sync per iteration.
         self.lazy_log = True
         # SemiEpochBasedRunner(scale_invariant=True) may hand the batch over WITHOUT its half-scale third image: the stem kernel reads
-        # it out of the second one (forward_train(half_scale_copy=True)); DSL_HALF_IN_STEM=0: the runner builds it with framework ops
-        self.half_scale_in_stem = os.environ.get('DSL_HALF_IN_STEM', '1') != '0' and os.environ.get('DSL_STEM_FUSED', '1') != '0'
+        # it out of the second one (forward_train(half_scale_copy=True)); set it False and the runner builds the copy with framework ops
+        self.half_scale_in_stem = True
         self._onehot = {}          # cached gradient of the total loss w.r.t. the step's log vector (_TotalFn)
         # eager_backward True: INSIDE train_step the backward kernel lists are queued right behind the loss kernel (and the few
         # log-variable ops) instead of when `loss.backward()` reaches the autograd bridge.  The gradient of the summed loss is 1
@@ -448,11 +460,7 @@ class FCOS(nn.Module):
             plan.set_parity(plan._parity ^ 1)
             plan.bind_image(img, half_last=half_scale_copy)
             if self._prefix_stream is None:
-                prio = int(os.environ.get('DSL_PREFIX_PRIO', '0'))        # -1: high-priority queue (experiment)
-                # streams share four hardware queues in creation order: DSL_PREFIX_SKIP = n takes n streams from torch's pool first,
-                # which moves the prefix stream to another hardware queue (experiment)
-                self._skipped_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get('DSL_PREFIX_SKIP', '0')))]
-                self._prefix_stream = role_stream('prefix', self.store.device, prio)
+                self._prefix_stream = role_stream('prefix', self.store.device)
             if img.is_cuda:
                 img.record_stream(self._prefix_stream)
             ready = getattr(img, '_dsl_ready', None)          # event of the image's producer (dsl_amd.data.mark_ready)
@@ -520,8 +528,7 @@ class FCOS(nn.Module):
         if sw != 0.0:
             losses['loss_sisoft'] = out[3]
         losses.vec = out[:len(losses)]      # the same scalars as ONE tensor: lets _parse_losses avoid per-key device ops
-        if os.environ.get('DSL_LOG_TOTAL', '1') != '0':      # (0: the stack + sum + cat device ops of the generic path; A/B only)
-            losses.vec_total = out          # ... and with their sum (the loss kernel's) as the last element: no device op at all
+        losses.vec_total = out              # ... and with their sum (the loss kernel's) as the last element: no device op at all
         return losses
 
     def _all_reduce_async(self, t, after_current=False):

@@ -17,6 +17,7 @@ from . import _lib as L
 from . import ops
 from .head_loss import FcosLossPlan
 from .params import STAGE_BLOCKS, STAGE_PLANES
+from .tuning import skip_items, tune, tune_int
 
 BF = torch.bfloat16
 
@@ -50,8 +51,16 @@ class OpList:
         if not getattr(self, '_fork1_fresh', False):
             self._add(L.OP_FORK)
 
+    # Step-level ablation by graph region (tools/step_ablation_regions.sh; results are WRONG, only the clock is read): the tuning key
+    # `skip` lists region tags (fwd.l2 fwd.l3 fwd.l4 fwd.fpn fwd.head bwd.head bwd.fpn bwd.l4 bwd.l3 bwd.l2) whose convolution /
+    # data-gradient launches are left out of the op lists
+    tag = ''
+
     def conv(self, d, side=False):
         """side: False/0 = the caller's stream, True/1..3 = that side stream of the library."""
+        if self.tag and self.tag in skip_items():
+            self.keep.append(d)
+            return
         self._add(L.OP_CONV, d, i=(0, 0, 0, 0, 0, 0, int(side)))
 
     def fork(self, side=1, other=0):
@@ -79,9 +88,6 @@ class OpList:
             self._fork1()
         self._add(L.OP_WGRAD_MULTI, i=(0, 0, 0, 0, 0, 0, 1 if side else 0), p=(plan.host.data_ptr(), plan.dev.data_ptr()))
         self.keep.append(plan)
-
-    def pair(self, d):
-        self._add(L.OP_PAIR, d)
 
     @staticmethod
     def _fbits(x):
@@ -173,7 +179,7 @@ class Plan:
         # 33-66-workgroup launches), followed by the head + FPN bucket's optimizer step; the forward list waits for that update where
         # it first reads the bucket (SLOT_HEADW, in front of the FPN).  Same kernels, same arithmetic, same bits.
         self.defer = bool(training and getattr(store, 'defer_head', False) and store.backbone != 'rla'
-                          and os.environ.get('DSL_SIDE', '1') != '0' and not single_stream)
+                          and tune('side') != '0' and not single_stream)
         dev = store.device
         self.dev = dev
         self.bufs = {}
@@ -189,7 +195,7 @@ class Plan:
         self._gn_ws = {}          # GroupNorm block-record workspaces, one per stream that runs GroupNorm launches
         self._build_forward()
         self.prefix = None
-        if training and store.backbone != 'rla' and os.environ.get('DSL_PIPE_PREFIX', '1') != '0' and os.environ.get('DSL_SIDE', '1') != '0':
+        if training and store.backbone != 'rla' and tune('pipe_prefix') != '0' and tune('side') != '0':
             self._split_prefix()
         if training:
             self.lossplan = FcosLossPlan(N, self.level_sizes, dev, max_gt=max_gt)
@@ -233,32 +239,18 @@ class Plan:
         cv = st.convs
         h1, w1 = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
         h, w = conv_out(h1, 3, 2, 1), conv_out(w1, 3, 2, 1)
-        # The frozen stem: image layout + conv1 + BN + ReLU + max pool as ONE kernel (dsl_stem_pool, csrc/stem.hip; DSL_STEM_FUSED=0:
-        # the three launches it replaced - an 8-channel bf16 copy of the image, the implicit-GEMM convolution with K = 448 stored
-        # columns for 147 real ones, the pooling pass over its 400 x 672 x 64 output)
-        fused = os.environ.get('DSL_STEM_FUSED', '1') != '0'
-        self._stem_fused = fused
-        if fused:
-            s1 = None
-        else:
-            x8 = self.buf('x8', N, H, W, 8)
-            self._img_op = len(f.items)         # bind_image() points this op at the caller's tensor
-            f.pack_image(self.img, x8, N, H, W)
-            s1 = self.buf('stem', N, h1, w1, 64)
-            f.conv(self._conv(cv['backbone.conv1'], x8, s1, N, [(H, W)], [(h1, w1)], relu=True, small_c=True))
+        # The frozen stem: image layout + conv1 + BN + ReLU + max pool as ONE kernel (dsl_stem_pool, csrc/stem.hip)
+        self._stem_fused = True
 
         def emit_pool(out, ld):
             """The pooled stem output into rows of `ld` elements."""
-            if fused:
-                sc, bi = st.bn_ptrs(cv['backbone.conv1'].bn)
-                self._img_op = len(f.items)
-                f.stem_pool(self.img, st.stem_groups16, sc, bi, out, ld, N, H, W)
-            else:
-                f._add(L.OP_MAXPOOL, i=(N, h1, w1, 64, ld), p=(s1, out))
+            sc, bi = st.bn_ptrs(cv['backbone.conv1'].bn)
+            self._img_op = len(f.items)         # bind_image() points this op at the caller's tensor
+            f.stem_pool(self.img, st.stem_groups16, sc, bi, out, ld, N, H, W)
         self.stage_out, self.stage_ld = [], []      # per stage: (tensor / pointer of the output's first channel, (h, w)), row stride
         # independent branches of the forward graph (a stage's downsample conv next to conv1 -> conv2; P5 -> P6 -> P7 next to
         # the P4 / P3 path) run on side stream 3: their kernels are too small to fill the chip alone
-        self.BR = 3 if (os.environ.get('DSL_SIDE', '1') != '0' and os.environ.get('DSL_FWD_BRANCH', '1') != '0' and not self.single_stream) else 0
+        self.BR = 3 if (tune('side') != '0' and not self.single_stream) else 0
         self.conv_ws_br = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
         if st.backbone == 'rla':
             from . import engine_rla
@@ -268,6 +260,7 @@ class Plan:
             emit_pool(x, 64)
             self._fwd_resnet(x, h, w)
         # ---- FPN (start_level=1) ----
+        f.tag = 'fwd.fpn'
         (c3, hw3), (c4, hw4), (c5, hw5) = self.stage_out[1], self.stage_out[2], self.stage_out[3]
         hw6 = (conv_out(hw5[0], 3, 2, 1), conv_out(hw5[1], 3, 2, 1))
         hw7 = (conv_out(hw6[0], 3, 2, 1), conv_out(hw6[1], 3, 2, 1))
@@ -312,12 +305,12 @@ class Plan:
         if BR:
             f.join(BR)
         # ---- head: shared weights, all 5 levels per launch ----
+        f.tag = 'fwd.head'
         ls = self.level_sizes
         self.tower = {}
         # the two towers are independent chains: the regression tower (+ its predictor) runs on the side stream
         self.conv_ws_side = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)
-        GN_FUSE = os.environ.get('DSL_GN_FUSE', '1') != '0'
-        FSIDE = 2 if (os.environ.get('DSL_SIDE', '1') != '0' and not self.single_stream) else 0      # side stream 1 carries the weight gradients (and may be CU-masked)
+        FSIDE = 2 if (tune('side') != '0' and not self.single_stream) else 0      # side stream 1 carries the weight gradients (and may be CU-masked)
         # phase marks for bench.py: 8 tower convs + 2 predictors over all M locations, 8 GroupNorm+ReLU passes
         self._head_flops = 2.0 * self.M * (8 * 256 * 2304 + (80 + 5) * 2304)
         self._head_bytes = self.M * 256 * 2.0 * (8 * 2 + 8 * 3 + 2) + self.M * (80 + 8) * 4.0
@@ -365,8 +358,8 @@ class Plan:
                 gd = ops.gn_desc(pre, act, st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'), stats,
                                  self._gn_workspace('side' if side else 'main'), n=N, hw=ls)
                 # conv -> GN -> ReLU (ConvModule, anchor_free_head.py:104-133): the convolution's epilogue leaves the statistics
-                # records, GroupNorm is then ONE pass over the tensor (DSL_GN_FUSE=0: its own statistics pass)
-                if GN_FUSE and not f8 and L.lib.dsl_conv2d_gn_fusable(C.byref(cd_)):
+                # records, GroupNorm is then ONE pass over the tensor (a launch that cannot leave them: its own statistics pass)
+                if not f8 and L.lib.dsl_conv2d_gn_fusable(C.byref(cd_)):
                     cd_.gn_ws = gd.workspace
                     gd.conv_stats = 1
                 f.conv(cd_, side=side)
@@ -398,8 +391,6 @@ class Plan:
         cv = st.convs
         self.blocks = []        # per block: dict(xin, a1, a2, out, idt, in_hw, out_hw, prefix, stride)
         self._pp = {}           # descriptors that touch layer1's output (pipelined prefix: two buffers, patched per step)
-        PAIR_FWD = os.environ.get('DSL_PAIR_FWD', '')      # stages (layer numbers) whose conv3 -> next conv1 pairs run fused, e.g. '23'
-        pair_done = False
         # Image-split stages (DSL_IMG_SPLIT; measured in round 3's first half: none 372.6, 3: 384.0, 34: 383.4, 4: 372.1, 23: -0.5 % vs 3; re-measured on
         # the final kernels, two boxes, both orders (profiles/r03_step_boundary.txt): 3: 416.8 / 432.1, 34: 420.3 / 435.1, 23: 420.0, 24: 420.9 (second
         # box), 234: 420.9 / 436.2 img/s -> default layer2 + layer3 + layer4, + 1 %;
@@ -407,15 +398,15 @@ class Plan:
         # fill, epilogue and kernel boundary on half a chip.  The images of a batch are independent through the backbone, so the
         # batch goes through these stages as TWO chains (images [0, ceil(N/2)) on the caller's stream, the rest on stream 3) of
         # half-size launches: one chain's fixed per-launch costs hide under the other chain's kernels.
-        SPLIT = os.environ.get('DSL_IMG_SPLIT', '234') if (self.BR and N >= 2 and not PAIR_FWD and self.training) else ''
+        SPLIT = tune('img_split') if (self.BR and N >= 2 and self.training) else ''
         split_open = False
-        DS_INLINE = os.environ.get('DSL_PREFIX_DS_INLINE', '0') != '0'      # measured: 421.5 (inline) vs 425.7 img/s
 
         def br_ws(d_):
             d_.workspace, d_.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
             return d_
         for li, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
             split = str(li + 1) in SPLIT
+            f.tag = f'fwd.l{li + 1}'
             if split and not split_open:
                 f.fork(self.BR)
                 split_open = True
@@ -423,33 +414,12 @@ class Plan:
                 f.join(self.BR)
                 split_open = False
             groups = [(0, (N + 1) // 2, 0), ((N + 1) // 2, N, self.BR)] if split else [(0, N, 0)]
-            # The frozen layer1: every bottleneck as ONE launch (dsl_bottleneck64, csrc/bneck.hip): no backward pass needs its
-            # intermediates, so a1 / a2 / the downsample identity never leave the CU.  OPT-IN (DSL_BNECK64=1): bit-identical, 246 vs 336 us
-            # alone (N = 2), but the step is 0.8 % SLOWER with it (421.2 vs 424.7 img/s, three alternations): one 129 KB / 494-register
-            # workgroup per CU shares its CU with nothing, and layer1 runs beside the previous backward pass (the lesson of 3.9 again).
-            fused1 = (li == 0 and planes == 64 and not split and not PAIR_FWD and os.environ.get('DSL_BNECK64', '0') != '0'
-                      and all(not cv[f'backbone.layer1.{b_}.conv1'].trainable for b_ in range(nb)))
             for b in range(nb):
                 p = f'backbone.layer{li + 1}.{b}'
                 c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
                 s = c1.stride
                 oh, ow = conv_out(h, 1, s, 0), conv_out(w, 1, s, 0)
-                if fused1 and s == 1:
-                    out = self.buf(p + '.out', N, oh, ow, planes * 4)
-                    dsp = cv[p + '.downsample.0'] if b == 0 else None
-                    (s1_, b1_), (s2_, b2_), (s3_, b3_) = st.bn_ptrs(c1.bn), st.bn_ptrs(c2.bn), st.bn_ptrs(c3.bn)
-                    sd_, bd_ = st.bn_ptrs(dsp.bn) if dsp is not None else (None, None)
-                    bd = ops.bneck64_desc(x, out, st.w16_ptr(c1), st.w16_ptr(c2), st.w16_ptr(c3), s1_, b1_, s2_, b2_, s3_, b3_, n=N, h=h, w=w,
-                                          cin=int(x.shape[-1]), ld_x=int(x.shape[-1]), ld_out=planes * 4,
-                                          wds=st.w16_ptr(dsp) if dsp is not None else None, sds=sd_, bds=bd_)
-                    f._add(L.OP_BNECK64, bd)
-                    if b == nb - 1:
-                        self._pp['c3'], self._pp['out'] = bd, out
-                    self.blocks.append(dict(prefix=p, xin=x, a1=None, a2=None, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
-                                            stage=li, b=b, planes=planes))
-                    x, h, w = out, oh, ow
-                    continue
-                a1 = self.bufs[p + '.a1'] if pair_done else self.buf(p + '.a1', N, oh, ow, planes)
+                a1 = self.buf(p + '.a1', N, oh, ow, planes)
                 a2 = self.buf(p + '.a2', N, oh, ow, planes)
                 out = self.buf(p + '.out', N, oh, ow, planes * 4)
                 idt = x
@@ -475,12 +445,7 @@ class Plan:
                                             stage=li, b=b, planes=planes))
                     x, h, w = out, oh, ow
                     continue
-                # DSL_PREFIX_DS_INLINE=1 keeps layer1's downsample conv on the list's own stream: layer1 belongs to the pipelined frozen
-                # prefix, and side stream 3 is in order behind everything the PREVIOUS backward pass queued on it - a prefix that
-                # forks onto it ends with that pass however early it starts (tools/prefix_probe.py).  Measured: inline, the prefix
-                # is through 0.26 ms before the previous step is, and the step is 1 % SLOWER - the forward pass cannot start before
-                # the caller's stream has joined the weight gradients and SGD anyway, and the fork hides 40 us
-                use_br = self.BR if not (li == 0 and DS_INLINE) else 0
+                use_br = self.BR
                 if b == 0:
                     dd = self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)])
                     if use_br:
@@ -489,29 +454,17 @@ class Plan:
                     f.conv(dd, side=use_br)
                 if li == 1 and b == 0:
                     self._pp['ds'] = [(dd, 0)]
-                if not pair_done:       # (else: computed by the previous block's pair launch)
-                    d1 = self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True)
-                    if li == 1 and b == 0:
-                        self._pp['c1'] = [(d1, 0)]
-                    f.conv(d1)
+                d1 = self._conv(c1, x, a1, N, [(h, w)], [(oh, ow)], relu=True)
+                if li == 1 and b == 0:
+                    self._pp['c1'] = [(d1, 0)]
+                f.conv(d1)
                 f.conv(self._conv(c2, a1, a2, N, [(oh, ow)], [(oh, ow)], relu=True))
                 if b == 0 and use_br:
                     f.join(self.BR)
-                pair_done = False
-                if PAIR_FWD and b + 1 < nb and planes in (128, 256) and str(li + 1) in PAIR_FWD:
-                    # this block's expand conv + the next block's reduce conv as one launch (csrc/pair.hip)
-                    nxt = cv[f'backbone.layer{li + 1}.{b + 1}.conv1']
-                    a1n = self.buf(f'backbone.layer{li + 1}.{b + 1}.a1', N, oh, ow, planes)
-                    s3, b3 = st.bn_ptrs(c3.bn)
-                    s1n, b1n = st.bn_ptrs(nxt.bn)
-                    f.pair(ops.pair_desc(a2, st.w16_ptr(c3), out, st.w16_ptr(nxt), a1n, m=N * oh * ow, p=planes, scale1=s3, bias1=b3,
-                                         addend=idt, ldadd=planes * 4, relu1=True, scale2=s1n, bias2=b1n, relu2=True))
-                    pair_done = True
-                else:
-                    d3 = self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt)
-                    if li == 0 and b == nb - 1:
-                        self._pp['c3'], self._pp['out'] = d3, out
-                    f.conv(d3)
+                d3 = self._conv(c3, a2, out, N, [(oh, ow)], [(oh, ow)], relu=True, addend=idt)
+                if li == 0 and b == nb - 1:
+                    self._pp['c3'], self._pp['out'] = d3, out
+                f.conv(d3)
                 self.blocks.append(dict(prefix=p, xin=x, a1=a1, a2=a2, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
                                         stage=li, b=b, planes=planes))
                 x, h, w = out, oh, ow
@@ -523,7 +476,7 @@ class Plan:
             f.join(self.BR)
 
     def _gn_workspace(self, key):
-        """Launches on one stream run one after the other and may share the block-record scratch."""
+        """The block-record scratch of one chain of (record-writing launch, GroupNorm pass) pairs that run one after the other."""
         ws = self._gn_ws.get(key)
         if ws is None:
             d = L.GnDesc()
@@ -641,21 +594,22 @@ class Plan:
         lp = self.lossplan
         reg = st.train_regions
         M = self.M
-        SIDE = os.environ.get('DSL_SIDE', '1') != '0'
+        SIDE = tune('side') != '0'
         # tuning knobs (both measured: on is better): group the last segment's weight gradients too, although nothing
         # is left on the caller's stream to overlap their tail with ...
-        GROUP_LAST = os.environ.get('DSL_GROUP_LAST', '1') != '0'
-        TAIL_SLOTS = int(os.environ.get('DSL_TAIL_SLOTS', '192'))      # (round 3, tools/exp_env.sh: 160 / 192 / 224 / 256 = 421.3 / 421.9 / 419.8 / 418.2 img/s)
+        GROUP_LAST = True
+        TAIL_SLOTS = tune_int('tail_slots')      # (round 3, tools/exp_env.sh: 160 / 192 / 224 / 256 = 421.3 / 421.9 / 419.8 / 418.2 img/s)
         GROUP = True       # same-geometry weight gradients (tower layers, the blocks of a stage) as one launch
         # ... and all weight gradients of a segment that share a tile configuration as one multi launch
-        self._multi_on = SIDE and os.environ.get('DSL_WGRAD_MULTI', '1') != '0'
+        self._multi_on = SIDE
         self._wg_pending = []
         g_feats = self.buf('g_feats', M, 256)
         # ================= segment 0: head + FPN =================
         # where in this pass the next step's frozen prefix (FCOS.pipeline_prefix) may start: 0 = with the pass, 3 / 2 / 1 = behind
         # layer4's / layer3's / layer2's data gradients (1 = the whole chain, the round-2 setting)
-        PREFIX_LI = int(os.environ.get('DSL_PREFIX_AT', '2'))       # measured (tools/exp_env.sh): 1: 355.5, 3: 360, 2 / 0: +0.2 % over 3
+        PREFIX_LI = 2       # measured (tools/exp_env.sh): 1: 355.5, 3: 360, 2 / 0: +0.2 % over 3
         ol = OpList()
+        ol.tag = 'bwd.head'
         ol.wait(L.SLOT_PACKS, stream=0)      # the data-gradient weight packs of the last optimizer step (ParamStore.repack_dgrad)
         if PREFIX_LI == 0:
             ol.record(L.SLOT_TAIL, stream=0)
@@ -664,7 +618,7 @@ class Plan:
         # the two towers' backward chains are independent until both have added into g_feats: the regression tower's runs on
         # side stream 2 (as in the forward pass); its last data gradient - the one that adds into g_feats - waits for the
         # classification tower's
-        BT = 2 if (SIDE and os.environ.get('DSL_BWD_TOWERS', '1') != '0') else 0
+        BT = 2 if SIDE else 0
         if BT:
             ol.fork(BT)
 
@@ -679,22 +633,18 @@ class Plan:
                     bregion='head.regctr_b', side=SIDE)
         # (measured, tools/experiments_r2.txt (exp_r2t) / exp_r2u.sh: weight gradients that start while the head's large data-gradient launches
         # still run cost more than the idle side stream saves - predictors first: 5.97 vs 5.94 ms, tower halves: 6.10 vs 6.05)
-        if os.environ.get('DSL_PRED_EARLY', '0') != '0':
-            self._flush_wgrads(ol, side=SIDE)
         g_act = {}
         # The data gradient that produces dY of a tower layer's GroupNorm + ReLU also leaves that norm's backward block records
         # (dsl_conv_desc.gn_x: x is read once more in the epilogue, dY never again): GroupNorm backward is then ONE pass
-        # (DSL_GN_FUSE_BWD=0: its own reduction pass first)
-        GN_FUSE_BWD = os.environ.get('DSL_GN_FUSE_BWD', '1') != '0'
+        # (a data gradient that cannot leave them: GroupNorm's own reduction pass first)
         gn_from_conv = set()
 
         def gn_records(cd_, tower, j, sd):
-            if not GN_FUSE_BWD:
-                return cd_
             lay = self.tower[tower][j]
             cd_.gn_x = L.ptr(lay['pre'])                 # (set first: the query answers for the backward records' tiles)
             if L.lib.dsl_conv2d_gn_fusable(C.byref(cd_)):
-                cd_.gn_ws = L.ptr(self._gn_workspace('side' if sd else 'main'))
+                cd_.gn_ws = L.ptr(self._gn_workspace('bwd.' + tower))      # per tower: with one stream for both (tuning side=0) the second
+                #                                                             tower's data gradient would overwrite the first one's records
                 cd_.gn_gamma, cd_.gn_beta = L.ptr(st.t32_ptr(lay['gn'] + '.weight')), L.ptr(st.t32_ptr(lay['gn'] + '.bias'))
                 cd_.gn_stats = L.ptr(lay['stats'])
                 gn_from_conv.add((tower, j))
@@ -713,7 +663,6 @@ class Plan:
         # layer by layer, both towers: their weight gradients go out in two groups of four (layers 3, 2 and layers 1, 0 of
         # both towers) as soon as the GroupNorm backward passes that produce their dY are queued - the side stream works from
         # the first quarter of this segment on instead of waiting for its end
-        HALVES = os.environ.get('DSL_TOWER_HALVES', '0') != '0'
         for i in (3, 2, 1, 0):
             g_pre = {}
             for tower, sd in towers:
@@ -723,15 +672,14 @@ class Plan:
                 # the GroupNorm backward also yields the conv bias gradient (sum over pixels of g_pre) from its block
                 # records: the weight gradient below runs without its column-sum pass
                 gd = ops.gn_desc(lay['pre'], lay['act'], st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'),
-                                 lay['stats'], self._gn_workspace('side' if sd else 'main'), n=N, hw=ls, dy=g_act[tower], dx=g_pre[tower],
+                                 lay['stats'], self._gn_workspace('bwd.' + tower), n=N, hw=ls, dy=g_act[tower], dx=g_pre[tower],
                                  dgamma=st.t32_ptr(base + '.weight', st.grad), dbeta=st.t32_ptr(base + '.bias', st.grad),
                                  dbias=st.t32_ptr(lay['spec'].name + '.bias', st.grad))
                 gd.conv_stats = 1 if (tower, i) in gn_from_conv else 0
                 ol.gn_bwd(gd, side=sd)
                 tower_group.append(self._wgrad(ol, lay['spec'], g_pre[tower], lay['xin'], N, ls, ls, side=SIDE, emit=False, no_db=True,
-                                               slots=int(os.environ.get('DSL_DEFER_SLOTS', '144')) if self.defer else
-                                               int(os.environ.get('DSL_TOWER_SLOTS', '72'))))     # measured: tools/experiments_r2.txt (exp_r2z) (48-128: 5.84 ms, 160-192: 5.89); round 3: 72 / 96 / 128: 5.435 / 5.461 / 5.456
-            if (HALVES and i in (2, 0)) or i == 0:
+                                               slots=tune_int('defer_slots') if self.defer else tune_int('tower_slots')))     # measured: tools/experiments_r2.txt (exp_r2z) (48-128: 5.84 ms, 160-192: 5.89); round 3: 72 / 96 / 128: 5.435 / 5.461 / 5.456
+            if i == 0:
                 if BT and SIDE:
                     ol.fork(1, other=BT)       # the weight-gradient stream also waits for the regression tower's stream
                 if self.defer:
@@ -753,19 +701,13 @@ class Plan:
                 # the regression tower's last data gradient adds into g_feats, after the classification tower's: on the caller's
                 # stream behind a JOIN of the tower stream (a FORK -> side launch -> JOIN round trip with nothing else to do on the
                 # caller's stream costs ~27 us, tools/microbench/sync_cost.hip)
-                RFM = os.environ.get('DSL_REG_FINAL_MAIN', '1') != '0'
-                if BT and not RFM:
-                    ol.fork(BT)
-                if BT and RFM:
+                if BT:
                     ol.join(BT)
-                sd_f = BT if (BT and not RFM) else 0
-                ol.conv((side_ws if sd_f else (lambda c: c))(self._dgrad(rl['spec'].name, g_pre['reg_convs'], g_feats, N, ls, ls, cs=256,
-                                                                         cd=256, k=3, stride=1, pad=1, addend=g_feats)), side=sd_f)
-                if BT and not RFM:
-                    ol.join(BT)
+                ol.conv(self._dgrad(rl['spec'].name, g_pre['reg_convs'], g_feats, N, ls, ls, cs=256, cd=256, k=3, stride=1, pad=1, addend=g_feats))
                 ol.prof(5, 1)
         self._flush_wgrads(ol, side=SIDE)          # towers + predictors: ready now, the FPN's follow below
         # ---- FPN backward ----
+        ol.tag = 'bwd.fpn'
         cv = st.convs
         fc = [cv[f'neck.fpn_convs.{i}.conv'] for i in range(5)]
         lc = [cv[f'neck.lateral_convs.{i}.conv'] for i in range(3)]
@@ -781,7 +723,7 @@ class Plan:
         # independent chains of this part of the graph run on side stream 3 beside the caller's (small launches, as in the
         # forward pass): the P3 / P4 output convs next to P7 -> P6 -> P5; the C3 / C4 laterals next to layer4's backward
         rla = st.backbone == 'rla'
-        BB = 3 if (SIDE and not rla and os.environ.get('DSL_BWD_BRANCH', '1') != '0') else 0
+        BB = 3 if (SIDE and not rla) else 0
 
         def br_ws(cd_):
             if BB:
@@ -848,13 +790,14 @@ class Plan:
         if rla:
             from . import engine_rla
             # (the recurrent path's BatchNorm post-pass runs on the weight-gradient stream behind the stage's flush)
-            self._multi_on = SIDE and os.environ.get('DSL_WGRAD_MULTI', '1') != '0' and os.environ.get('DSL_RLA_MULTI', '1') != '0'
+            self._multi_on = SIDE
             engine_rla.build_backward(self, buckets, SIDE)
             return
         blocks_by_stage = {li: [b for b in self.blocks if b['stage'] == li] for li in (1, 2, 3)}
-        BSPLIT = os.environ.get('DSL_IMG_SPLIT_BWD', '23')      # measured (tools/exp_env.sh): '' 372-377, 3: 378.5, 23: 382.5, 34: 381.5, 234: 379.7 img/s
+        BSPLIT = tune('img_split_bwd')      # measured (tools/exp_env.sh): '' 372-377, 3: 378.5, 23: 382.5, 34: 381.5, 234: 379.7 img/s
         for li in (3, 2, 1):
             ol = OpList()
+            ol.tag = f'bwd.l{li + 1}'
             if li == 1:
                 self._multi_on = False         # layer2: four tile configurations, and the caller's stream takes the tail group itself
             blks = blocks_by_stage[li]
@@ -871,12 +814,6 @@ class Plan:
                 ol.join(BB)          # whatever stream 3 still runs (laterals, an earlier scatter) is visible to the caller's stream ...
                 ol.fork(BB)          # ... and stream 3 starts behind everything the caller's stream has queued
                 self._br_pending = False
-            # Last segment (layer2), round 4: its weight gradients used to go out behind the whole data-gradient chain - 250 us of
-            # memory-bound launches with nothing else left to run (profiles/r03b_sequence.txt: 2 284 -> 2 533 us).  With the towers'
-            # group deferred the weight-gradient stream is idle by then, so the groups of the blocks that are already through
-            # (all but block 0) go out as soon as block 1's data gradients are queued and run under block 0's chain; the tail is
-            # block 0's four launches.  DSL_L2_EARLY=0: the round-3 order.
-            early = bsplit and li == 1 and len(blks) > 2 and os.environ.get('DSL_L2_EARLY', '0') != '0'
             for blk in reversed(blks):
                 p = blk['prefix']
                 c1, c2, c3 = cv[p + '.conv1'], cv[p + '.conv2'], cv[p + '.conv3']
@@ -885,8 +822,6 @@ class Plan:
                 grp = GROUP and (li > 1 or GROUP_LAST)
                 tsl = TAIL_SLOTS if li == 1 else 0      # last segment: nothing else is left to run beside these launches
                 if bsplit:
-                    if early and blk['b'] > 0:
-                        tsl = 0          # these run beside the chain: the weight-gradient stream's usual workgroup budget
                     g3.append(self._wgrad(ol, c3, g_pre, blk['a2'], N, [hw], [hw], side=SIDE, emit=False, slots=tsl))
                     g2.append(self._wgrad(ol, c2, gA2, blk['a1'], N, [hw], [hw], side=SIDE, emit=False, slots=tsl))
                     g_prev = self.buf(p + '.g_in', N, hw[0], hw[1], planes * 4) if blk['b'] > 0 else None
@@ -909,13 +844,6 @@ class Plan:
                     if blk['b'] > 0:
                         g1.append(self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, emit=False, slots=tsl))
                         g_pre = g_prev
-                        if early and blk['b'] == 1:
-                            # blocks nb-1 .. 1 are through on both chains: their three groups leave now (the weight-gradient stream
-                            # waits for both chains' streams; the chains themselves go on without a join)
-                            ol.fork(1, other=BB)
-                            for grp_descs in (g3, g2, g1):
-                                self._wgrad_group(ol, grp_descs, side=SIDE, ws_name='wg_ws')
-                            g3, g2, g1 = [], [], []
                     else:
                         ol.join(BB)       # both chains are done: the weight gradients below (and the groups) read whole-batch tensors
                         d1 = self._wgrad(ol, c1, gA1, blk['xin'], N, [hw], [blk['in_hw']], side=SIDE, emit=True, slots=tsl)
@@ -962,44 +890,14 @@ class Plan:
                                                 stride=1, pad=0, os=2, addend=tgt, mask=blk['xin'], mask_first=True))
             if li == PREFIX_LI:
                 ol.record(L.SLOT_TAIL, stream=0)       # from here on the next step's frozen prefix may run beside this pass
-            # Last segment, round 4: behind the data-gradient chains nothing but this stage's weight gradients is left, and four of them
-            # used to run ONE AFTER THE OTHER on the weight-gradient stream (conv3's group, block 0's conv1 and downsample, conv1's
-            # group: 272 us in profiles/r04_sequence.txt, each a launch that cannot fill the chip) while the caller's stream ran
-            # conv2's group and stream 3 nothing.  DSL_TAIL_SPREAD: 1 = block 0's two single launches go to stream 3, 2 = conv1's
-            # group as well; the weight-gradient stream waits for stream 3 before the bucket's event is recorded.
-            spread = int(os.environ.get('DSL_TAIL_SPREAD', '0')) if (li == 1 and BB and self._multi_on and GROUP and GROUP_LAST) else 0
-            on_br = []
-            if spread:
-                on_br = [sub for sub in self._wg_pending if len(sub) == 1]
-                self._wg_pending = [sub for sub in self._wg_pending if len(sub) != 1]
-                if spread >= 2 and g1:
-                    on_br.append(list(g1))
-                    g1 = []
-                if on_br:
-                    ol.fork(BB)          # stream 3 behind the caller's stream, which has joined both chains
-                    for sub in on_br:
-                        if len(sub) == 1:
-                            need = L.lib.dsl_wgrad_workspace_bytes(C.byref(sub[0]))
-                            ws = self._wg_buf(need, 'wg_ws_tail')
-                            sub[0].workspace, sub[0].workspace_bytes = L.ptr(ws), ws.numel()
-                            ol._add(L.OP_WGRAD, sub[0], i=(0, 0, 0, 0, 0, 0, BB))
-                        else:
-                            arr0 = (L.WgradDesc * len(sub))()
-                            for i_, d_ in enumerate(sub):
-                                C.memmove(C.addressof(arr0[i_]), C.addressof(d_), C.sizeof(L.WgradDesc))
-                            need = L.lib.dsl_wgrad_group_workspace_bytes(arr0, len(sub))
-                            arr = ops.wgrad_group(sub, workspace=self._wg_buf(need, 'wg_ws_tail'))
-                            ol._add(L.OP_WGRAD_GROUP, arr, i=(len(arr), 0, 0, 0, 0, 0, BB))
             if GROUP and (li > 1 or GROUP_LAST):
                 # last segment: the caller's stream has nothing left to do, it takes part of the groups itself
-                on_main = os.environ.get('DSL_TAIL_MAIN', '2') if li == 1 else '0'     # measured: tools/experiments_r2.txt (exp_r2w)
+                on_main = '2' if li == 1 else '0'     # measured: tools/experiments_r2.txt (exp_r2w)
                 order = sorted(((3, g3), (2, g2), (1, g1)), key=lambda t: str(t[0]) in on_main)     # side-stream groups first: one FORK
                 for gi, grp_descs in order:
                     mine = str(gi) in on_main
                     self._wgrad_group(ol, grp_descs, side=SIDE and not mine, ws_name='wg_ws_main' if mine else 'wg_ws')
             self._flush_wgrads(ol, side=SIDE)
-            if on_br:
-                ol.fork(1, other=BB)          # the bucket's event (recorded on the weight-gradient stream) covers stream 3's launches too
             seg = 4 - li                      # 1, 2, 3
             ol.record(seg)
             if li == 1:                       # last segment: everything must be complete when the list returns
@@ -1026,8 +924,8 @@ class Plan:
         f, end = self.fwd, self._prefix_end
         pre, rest = OpList(), OpList()
         pre.items, rest.items = f.items[:end], f.items[end:]
-        if os.environ.get('DSL_SKIP_PREFIX_CONVS'):      # step-level ablation (tools/step_ablation.sh): layer1 costs nothing - timing only
-            pre.items = [o for o in pre.items if o.kind not in (L.OP_CONV, L.OP_BNECK64)]
+        if 'prefix' in skip_items():      # step-level ablation (tools/step_ablation.sh): layer1 costs nothing - timing only
+            pre.items = [o for o in pre.items if o.kind != L.OP_CONV]
         pre.keep = rest.keep = f.keep
         ws = torch.empty(32 << 20, dtype=torch.uint8, device=self.dev)      # the prefix runs beside the caller's convs: own split-K scratch
         for o in pre.items:
@@ -1055,10 +953,7 @@ class Plan:
     def set_parity(self, p):
         """Points the five descriptors that touch layer1's output at buffer p."""
         ptr = self._l1out[p].data_ptr()
-        if isinstance(self._pp['c3'], L.Bneck64Desc):
-            self._pp['c3'].out = ptr
-        else:
-            self._pp['c3'].dst = ptr
+        self._pp['c3'].dst = ptr
         for d_, off in self._pp['c1'] + self._pp['ds']:
             d_.src = ptr + off
         self._pp['wg_c1'].x = ptr

@@ -29,6 +29,7 @@ import torch
 from . import _lib as L
 from . import ops
 from .params import RLA_C, RLA_PAD, STAGE_BLOCKS, STAGE_PLANES
+from .tuning import tune, tune_int
 
 BF = torch.bfloat16
 
@@ -62,11 +63,10 @@ def build_forward(plan, emit_pool, h1, w1):
     xh = plan.buf('rla.xh.0.0', N * h * w, cx + RLA_PAD, zero=True)
     emit_pool(xh, cx + RLA_PAD)
     plan.rla_blocks = []
-    import os
     # image-split stages (as in Plan._fwd_resnet): the images of a batch are independent through the backbone - eval-mode
     # BatchNorms, per-image recurrent state - so the batch runs through these stages as two chains of half-batch launches on two
-    # streams (DSL_RLA_SPLIT: stage indices, default 1, 2, 3; the DSL iteration has N = 3: images [0, 2) and [2, 3))
-    SPLIT = os.environ.get('DSL_RLA_SPLIT', '123') if (plan.BR and N >= 2 and plan.training) else ''
+    # streams (tuning key rla_split: stage indices, default 1, 2, 3; the DSL iteration has N = 3: images [0, 2) and [2, 3))
+    SPLIT = tune('rla_split') if (plan.BR and N >= 2 and plan.training) else ''
     split_open = False
 
     def br_ws(d_):
@@ -153,19 +153,18 @@ def build_backward(plan, buckets, SIDE):
     bn_p = lambda bn, leaf: st.t32_ptr('bn_train.' + leaf) + st.bn_train_off[bn][0] * 4
     bn_f = lambda bn, leaf: st.frozen.data_ptr() + (st.frozen_regions['bn_train.' + leaf][0] + st.bn_train_off[bn][0]) * 4
     from .engine import OpList
-    import os
     # Image-split data-gradient chains (as in the forward pass and in Plan's ResNet backward): the images of a batch are
     # independent through the backbone's backward too - per-image recurrent state, eval-mode BatchNorms - so the chain of a stage
     # runs as two chains of part-batch launches, images [0, ceil(N/2)) on the caller's stream and the rest on stream 3
-    # (DSL_RLA_SPLIT_BWD: stage indices).  What sums over the batch waits behind the JOIN at the stage's end: the weight gradients
+    # (BSPLIT: stage indices).  What sums over the batch waits behind the JOIN at the stage's end: the weight gradients
     # (deferred into the stage's grouped / multi launches anyway) and the (dgamma, dbeta) of the recurrent path's BatchNorms,
     # whose block records the two chains write side by side (dsl_rec_sum_multi, one launch per stage).
     # OFF by default - measured on the DSL iteration (N = 3: a 2 + 1 split; tools/exp_env.sh, three alternations in one box):
     # '' 11.99 / 12.00 / 12.12 ms, '123' 12.17 / 12.16 / 12.15, '23' 12.07 / 12.13 / 12.01: unlike the forward chains and the
     # ResNet engine's backward, the caller's stream is full of kernel time here (10.7 of 12.1 ms busy, profiles/r03_rla_timeline.txt),
     # not of launch gaps, and the weight-gradient grids already hold the CUs a second chain would use.
-    BSPLIT = os.environ.get('DSL_RLA_SPLIT_BWD', '') if (SIDE and plan._multi_on and plan.BR and N >= 2) else ''
-    S2_CLASSES = os.environ.get('DSL_S2_CLASSES', '1') != '0'          # stride-2 3x3 data gradients as four parity-class launches
+    BSPLIT = ''               # (image-split backward chains: built, same gradients, slower - LAB_NOTES.md; the group loops below stay general)
+    S2_CLASSES = True         # stride-2 3x3 data gradients as four parity-class launches
     BB = plan.BR
 
     def br_ws(d_):
@@ -184,7 +183,7 @@ def build_backward(plan, buckets, SIDE):
         rec_items = []
         # the last stage's weight gradients go out behind the whole data-gradient chain, with nothing left to run beside them (0.8 ms
         # of the iteration, profiles/r03_rla_sequence.txt): they take the chip instead of the weight-gradient stream's usual budget
-        tsl = int(os.environ.get('DSL_RLA_TAIL_SLOTS', '192')) if s_ == 1 else 0
+        tsl = tune_int('rla_tail_slots') if s_ == 1 else 0
         if bsplit:
             ol.fork(BB)
 

@@ -83,42 +83,6 @@ def dgrad_s2_descs(dy, packs, dst, *, n, dy_hw, dst_hw, cs, cd, cd_pad=None, ldd
     return out
 
 
-def bneck64_desc(x, out, w1, w2, w3, s1, b1, s2, b2, s3, b3, *, n, h, w, cin, ld_x=None, ld_out=256, wds=None, sds=None, bds=None):
-    """dsl_bottleneck64: a frozen 64-plane bottleneck as one launch (csrc/bneck.hip).  Tensors or raw pointers."""
-    d = L.Bneck64Desc()
-    for k_, v in dict(x=x, out=out, w1=w1, w2=w2, w3=w3, wds=wds, s1=s1, b1=b1, s2=s2, b2=b2, s3=s3, b3=b3, sds=sds, bds=bds).items():
-        setattr(d, k_, L.ptr(v).value or 0)
-    d.n, d.h, d.w, d.cin, d.ld_x, d.ld_out = n, h, w, cin, ld_x or cin, ld_out
-    d._keep = (x, out, w1, w2, w3, wds, s1, b1, s2, b2, s3, b3, sds, bds)
-    return d
-
-
-def bottleneck64(*a, **k):
-    d = bneck64_desc(*a, **k)
-    L.check(lib.dsl_bottleneck64(C.byref(d), L.stream_ptr()), 'dsl_bottleneck64')
-    return d
-
-
-def pair_desc(a, wa, mid, wb, out, *, m, p, lda=None, ldmid=None, ldo=None, scale1=None, bias1=None, addend=None, ldadd=0, mask1=None,
-              ldm1=0, relu1=False, scale2=None, bias2=None, mask2=None, ldm2=0, relu2=False):
-    """dsl_conv1x1_pair descriptor: mid = epi1(a . wa^T), out = epi2(mid . wb^T); wa [4p][p], wb [p][4p] bf16."""
-    d = L.PairDesc()
-    d.m, d.p = m, p
-    d.a, d.wa, d.wb, d.mid, d.out = L.ptr(a), L.ptr(wa), L.ptr(wb), L.ptr(mid), L.ptr(out)
-    d.lda, d.ldmid, d.ldo = lda or p, ldmid or 4 * p, ldo or p
-    d.scale1, d.bias1, d.scale2, d.bias2 = L.ptr(scale1), L.ptr(bias1), L.ptr(scale2), L.ptr(bias2)
-    d.addend, d.ldadd, d.mask1, d.ldm1, d.mask2, d.ldm2 = L.ptr(addend), ldadd, L.ptr(mask1), ldm1, L.ptr(mask2), ldm2
-    d.relu1, d.relu2 = int(relu1), int(relu2)
-    d._keep = (a, wa, wb, mid, out, scale1, bias1, scale2, bias2, addend, mask1, mask2)
-    return d
-
-
-def conv1x1_pair(*a, **k):
-    d = pair_desc(*a, **k)
-    L.check(lib.dsl_conv1x1_pair(C.byref(d), L.stream_ptr()), 'dsl_conv1x1_pair')
-    return d
-
-
 def conv_workspace_bytes(d):
     return lib.dsl_conv2d_workspace_bytes(C.byref(d))
 

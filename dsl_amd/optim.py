@@ -11,8 +11,10 @@ from . import _lib as L
 from .registry import OPTIMIZERS
 
 
-_BUCKET_SGD = os.environ.get('DSL_BUCKET_SGD', '1') != '0'    # per-bucket optimizer steps beside the backward pass (no clipping only)
-_PACK_SIDE = os.environ.get('DSL_PACK_SIDE', '1') != '0'     # data-gradient weight packs off the caller's stream (measured: tools/experiments_r2.txt (exp_r2l))
+from .tuning import skip_items, tune
+
+_BUCKET_SGD = tune('bucket_sgd') != '0'    # per-bucket optimizer steps beside the backward pass (no clipping only)
+_PACK_SIDE = True                          # data-gradient weight packs off the caller's stream (measured: tools/experiments_r2.txt (exp_r2l))
 
 
 @OPTIMIZERS.register_module(name='SGD')
@@ -40,8 +42,8 @@ class FlatSGD:
     def _sync_defer(self):
         """Deferred head update (engine.Plan.defer): possible when the update is element-wise per bucket - no gradient
         clipping (a global norm needs every gradient first), per-bucket steps on, packs on the side stream.  The flag lives on
-        the parameter store because it shapes the op lists; DSL_DEFER_HEAD=0 turns it off."""
-        want = (self.max_norm is None and _BUCKET_SGD and _PACK_SIDE and os.environ.get('DSL_DEFER_HEAD', '0') != '0'
+        the parameter store because it shapes the op lists; opt-in (tuning key defer_head=1)."""
+        want = (self.max_norm is None and _BUCKET_SGD and _PACK_SIDE and tune('defer_head') != '0'
                 and self.store.backbone != 'rla')
         if bool(getattr(self.store, 'defer_head', False)) != want:
             self.store.wait_pending() if self.store.train.is_cuda else None
@@ -149,7 +151,7 @@ class FlatSGD:
                     if (info['main'] or never != 0) and tgt is not cur:
                         tgt.wait_stream(cur)
                 o4, o2, o1 = lo * 4, lo * 2, lo
-                if os.environ.get('DSL_SKIP_SGD'):          # step-level ablation (tools/step_ablation.sh): timing only
+                if 'sgd' in skip_items():          # step-level ablation (tools/step_ablation.sh): timing only
                     continue
                 L.check(L.lib.dsl_sgd_step(C.c_void_p(st.train.data_ptr() + o4), C.c_void_p(st.grad.data_ptr() + o4),
                                            C.c_void_p(self.momentum_buf.data_ptr() + o4), C.c_void_p(st.train16.data_ptr() + o2),

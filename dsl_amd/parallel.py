@@ -73,12 +73,13 @@ class HipDistributedDataParallel(nn.Module):
     collective skipped: a timing probe that attributes a scaling loss to communication - the gradients are then WRONG);
     env DSL_COMM.  grad_dtype: 'fp32' (default) or 'bf16' - gradient buckets cross xGMI as bf16 copies (64 MB instead of 128 MB per
     step; the master gradient, the clipping norm and the update stay fp32); env DSL_GRAD_DTYPE.
-    Workgroup budget: with more than one rank RCCL's own kernels need CUs beside a backward pass that otherwise fills the chip, so the
-    persistent weight-gradient grids are capped lower (DSL_DDP_WGRAD_SLOTS, default 112 instead of 128; an explicit DSL_WGRAD_SLOTS
-    wins).  Unmeasured on hardware until a multi-GPU node runs bench.py."""
+    wgrad_slots: workgroup budget of the persistent weight-gradient grids (library option "wgrad_slots", default 128).  With more than
+    one rank RCCL's own kernels need CUs beside a backward pass that otherwise fills the chip; a lower cap (e.g. 112) is the knob
+    prepared for that - opt-in and unmeasured until a multi-GPU node runs bench.py: it changes the weight-gradient
+    planner's split factors, hence summation order, so a run with it is not bit-comparable with a single-GPU run."""
 
     def __init__(self, module, process_group=None, broadcast_buffers=False, find_unused_parameters=False,
-                 device_ids=None, comm=None, grad_dtype=None, **kw):
+                 device_ids=None, comm=None, grad_dtype=None, wgrad_slots=None, **kw):
         super().__init__()
         assert dist.is_initialized(), 'init_process_group first (tools/train.py:116-123)'
         self.module = module
@@ -91,9 +92,9 @@ class HipDistributedDataParallel(nn.Module):
         grad_dtype = grad_dtype if grad_dtype is not None else os.environ.get('DSL_GRAD_DTYPE', 'fp32')
         assert grad_dtype in ('fp32', 'bf16'), grad_dtype
         module.grad_bf16 = grad_dtype == 'bf16'
-        if module.world_size > 1 and 'DSL_WGRAD_SLOTS' not in os.environ:
-            # read once by the library, at its first weight-gradient launch: set before the first step
-            os.environ['DSL_WGRAD_SLOTS'] = os.environ.get('DSL_DDP_WGRAD_SLOTS', '112')
+        if wgrad_slots is not None:
+            from .tuning import set_tune
+            set_tune('lib.wgrad_slots', int(wgrad_slots))      # (an explicit library setter: read when a launch is planned)
         module.rccl = RcclComm(process_group) if (comm == 'rccl' and module.store.train.is_cuda) else None
         # initial parameter broadcast from rank 0 (what DDP's constructor does)
         st = module.store

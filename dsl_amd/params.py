@@ -319,7 +319,8 @@ class ParamStore:
                     continue      # fed by frozen layer1: no data gradient needed
                 lay[s.name] = (off, s.cin_store * s.k * s.k * s.cout_pad)
                 off += _round_up(lay[s.name][1], 8)
-                if s.k == 3 and s.stride == 2:
+                if s.k == 3 and s.stride == 2 and self.backbone == 'rla' and s.name.startswith('backbone.'):
+                    # (RLA_ResNet's stage-entry 3x3 / 2 convolutions; the FPN's P6 / P7 convolutions keep the general strided gather)
                     # + the four parity-class packs of its data gradient (ops.dgrad_s2_descs): [Cin][k_c * k_c][CoutPad], k_c = 1 for
                     # the even-even pixels, 2 for the rest
                     from .ops import s2_class

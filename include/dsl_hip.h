@@ -29,6 +29,12 @@ extern "C" {
 
 int dsl_version(void);
 const char* dsl_last_error(void);
+/* Library options - the library reads no environment variable.  Names: "wgrad_slots" (default 128: workgroup budget of a
+ * weight-gradient launch whose descriptor leaves `slots` 0), "side_cus" (0; > 0 confines dsl_run_ops' weight-gradient stream to that
+ * many CUs per XCD, set before the first dsl_run_ops), "debug_sync" (0; 1 = dsl_run_ops drains the device after every op and names
+ * it on stderr), "skip_kinds" (0; timing-only ablation: bit mask of op kinds dsl_run_ops skips).  Unknown name: -1. */
+int dsl_set_option(const char* name, int value);
+int dsl_get_option(const char* name, int* value);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on MFMA (forward, data-gradient) — replaces F.conv2d / cuDNN in
@@ -122,7 +128,7 @@ typedef struct dsl_wgrad_desc {
   int32_t ldx;                                       /* 0 = cs; else X's pixel stride in elements (X is a channel slice of wider rows) */
   int32_t shared;                                    /* group launches: 1 = the members are applications of ONE convolution (same dw):
                                                       * their gradients are summed into dw (RLA's recurrent / conv_out layers) */
-  int32_t slots;                                     /* 0 = default (env DSL_WGRAD_SLOTS, 160); else the workgroup budget the split factor
+  int32_t slots;                                     /* 0 = default (option "wgrad_slots", 128); else the workgroup budget the split factor
                                                       * is chosen for: launches that run beside the caller's stream leave it CUs, the
                                                       * ones at the very end of a pass can take the chip (group launches: descs[0]'s) */
   int32_t pad_;
@@ -142,7 +148,7 @@ int dsl_conv2d_wgrad_group(const dsl_wgrad_desc* descs, int count, void* stream)
 /* Multi launch: the weight gradients of up to DSL_MAX_MULTI sub-launches (sub-launch s = counts[s] consecutive descriptors
  * of one geometry, as in dsl_conv2d_wgrad_group) that share one tile configuration (dsl_wgrad_multi_config: 1..4; 0 = has
  * no multi form) as ONE grid and ONE reduce grid: the backward pass of a whole FPN or ResNet stage instead of one launch
- * pair per layer.  Split factors are chosen for the launch as a whole (every workgroup gets about 1/DSL_WGRAD_SLOTS of its
+ * pair per layer.  Split factors are chosen for the launch as a whole (every workgroup gets about 1/wgrad_slots of its
  * K iterations), sub-launches that end up with one split write dW directly and have no partial tiles or reduce pass.
  * The launch plan is a table the caller owns: dsl_wgrad_multi_build fills `table_host` (dsl_wgrad_multi_table_bytes()
  * bytes of host memory), the caller copies those bytes to device memory once and passes both to
@@ -182,43 +188,6 @@ int dsl_quant_fp8_dyn(const void* x_bf16, void* y_fp8, long rows, int c, int ld_
 int dsl_fp8_comb(const float* winv, float* comb, int n, const float* partials, int n_partials, void* stream);
 int dsl_quant_fp8_weights(const float* w, void* w8, float* comb, const float* bn_scale, int cout, int cout_pad, int k,
                           float inv_act_scale, void* stream);
-
-/* Two back-to-back 1x1 convolutions as one launch (csrc/pair.hip): a bottleneck's expand conv and the next bottleneck's reduce
- * conv in the forward pass (resnet.py:262-301), the reduce conv's and the expand conv's data gradients in the backward pass.
- *   mid[m][4p] = epi1( a[m][p] . wa[4p][p]^T )      epi1: x scale1 + bias1, + addend, x (mask1 > 0), relu1   (each optional)
- *   out[m][p]  = epi2( mid[m][4p] . wb[p][4p]^T )   epi2: x scale2 + bias2, x (mask2 > 0), relu2
- * bf16 tensors, fp32 accumulation; `mid` is written (bf16) and consumed from LDS, never read back.  Bit-identical to two
- * dsl_conv2d launches with the same epilogues.  p = 128 or 256; row strides in elements, multiples of 8. */
-typedef struct dsl_pair_desc {
-  int32_t m, p;
-  const void* a; int32_t lda; int32_t relu1;
-  const void* wa;
-  const float* scale1; const float* bias1;
-  const void* addend; int32_t ldadd; int32_t ldm1;
-  const void* mask1;
-  void* mid; int32_t ldmid; int32_t relu2;
-  const void* wb;
-  const float* scale2; const float* bias2;
-  const void* mask2; int32_t ldm2; int32_t ldo;
-  void* out;
-} dsl_pair_desc;
-int dsl_conv1x1_pair(const dsl_pair_desc* d, void* stream);
-
-/* A whole 64-plane bottleneck of the frozen layer1 (mmdet/models/backbones/resnet.py:262-301, caffe style, stride 1, eval-mode
- * BatchNorms folded to (scale, bias); frozen by frozen_stages=1, :616-632) as ONE launch (csrc/bneck.hip):
- *   out = relu( bn3(conv3( relu(bn2(conv2_3x3( relu(bn1(conv1(x))) ))) )) + identity ),
- *   identity = x (cin == 256: blocks 1, 2) or bn_ds(conv_ds(x)) (cin == 64 with wds: block 0).
- * x [n][h][w][ld_x] bf16 (cin real channels), out [n][h][w][ld_out] bf16 (256 channels); weights bf16 in the forward layout
- * ([cout][kh][kw][cin]): w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wds [256][64] or NULL.  No intermediate is written: the
- * launch is for frozen blocks (nothing is needed by a backward pass).  Bit-identical to the dsl_conv2d launches it replaces. */
-typedef struct dsl_bneck64_desc {
-  const void* x; void* out;
-  const void* w1; const void* w2; const void* w3; const void* wds;
-  const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3;
-  const float* sds; const float* bds;
-  int32_t n, h, w, cin, ld_x, ld_out;
-} dsl_bneck64_desc;
-int dsl_bottleneck64(const dsl_bneck64_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GPU data path
@@ -292,15 +261,6 @@ int dsl_stem_pool(const float* img_nchw, const void* w_groups, const float* scal
  * second copy of the batch; bit-identical to them (h, w even). */
 int dsl_stem_pool_half(const float* img_nchw, const void* w_groups, const float* scale, const float* bias, void* out, int ld_out,
                        int n, int h, int w, int half_last, void* stream);
-
-/* Activation-stationary 3x3 / stride 1 / pad 1 convolution 64 -> 64 + folded BatchNorm (scale, bias) [+ ReLU], NHWC bf16: the middle
- * convolution of the frozen layer1 bottlenecks (resnet.py:262-301 Bottleneck.forward: conv2 / bn2 / relu).  src: [n][h][w] rows of
- * ld_src elements (>= 64, the first 64 are read), wgt: [64][3][3][64] bf16 (the forward layout of dsl_conv2d), dst rows of ld_dst.
- * The pixel tile + halo is staged in LDS once and all nine taps are multiplied out of it; the weights stay in registers.  Same
- * arithmetic as dsl_conv2d with flags DSL_CONV_RELU_OUT (same k order, same one-rounding scale / bias), which routes eligible
- * descriptors here when DSL_PATCH3=1 (off by default: faster alone, not in the step - DESIGN 3.9). */
-int dsl_conv3x3_c64_patch(const void* src, int ld_src, const void* wgt, const float* scale, const float* bias, void* dst, int ld_dst,
-                          int n, int h, int w, int relu, void* stream);
 
 /* 3x3 stride-2 pad-1 max pool, NHWC bf16 (resnet.py:610,638). */
 int dsl_maxpool3x3s2(const void* x, void* y, int n, int h, int w, int c, void* stream);
@@ -559,7 +519,6 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_WAIT = 16,   /* stream i[0] waits for named event slot i[1] (no-op if the slot was never recorded) */
        DSL_OP_PACK_DGRAD = 18, /* dsl_pack_dgrad_batched(p[0] = item table, i[0] = items, i[1] = blocks) */
        DSL_OP_WGRAD_MULTI = 19, /* dsl_conv2d_wgrad_multi(p[0] = table_host, p[1] = table_dev) */
-       DSL_OP_PAIR = 20,       /* desc = dsl_pair_desc -> dsl_conv1x1_pair */
        DSL_OP_QUANT_FP8 = 22,  /* p[2] == NULL: dsl_quant_fp8(p[0] = x, p[1] = y, l[0] = rows, i[0] = c, i[1] = ld_x, scale = the float whose bits are
                                 * l[1]); else dsl_absmax(.., p[2] = partials, i[2] = n_partials) + dsl_quant_fp8_dyn(..) */
        DSL_OP_FP8_COMB = 24,   /* dsl_fp8_comb(p[0] = winv, p[1] = comb, i[0] = n, p[2] = partials, i[2] = n_partials) */
@@ -567,7 +526,6 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
                                 * inv_act_scale = the float whose bits are l[1]) */
        DSL_OP_STEM_POOL = 25,  /* dsl_stem_pool(p[0] = img, p[1] = w_groups, l[0] / l[1] = scale / bias pointers, p[2] = out, i[0] = ld_out,
                                 * i[1..3] = n, h, w, i[4] = half_last: dsl_stem_pool_half) */
-       DSL_OP_BNECK64 = 26,    /* desc = dsl_bneck64_desc -> dsl_bottleneck64 */
        DSL_OP_PROF = 21 };     /* phase mark (dsl_prof_enable(3) only, else a no-op): i[0] = class >= 4, i[1] = 0 begin | 1 end, l[0] / l[1] =
                                 * algorithmic FLOPs / bytes of the phase as IEEE doubles' bit patterns (begin only) */
 typedef struct dsl_op {

@@ -2,6 +2,7 @@
 device tensors) run forward + loss + hand-written backward with the bucketed, event-ordered gradient all-reduce, and
 the result must equal ONE process training on the concatenated batch (DDP averaging + reduce_mean normalisers ==
 the bigger batch)."""
+import ctypes as C
 import os
 import socket
 
@@ -239,8 +240,10 @@ def _worker_opts(rank, world, port, q):
         from dsl_amd.optim import FlatSGD
         from dsl_amd.parallel import HipDistributedDataParallel
         model = build()
-        ddp = HipDistributedDataParallel(model, grad_dtype='bf16')
-        assert model.grad_bf16 and os.environ.get('DSL_WGRAD_SLOTS') == '112'
+        ddp = HipDistributedDataParallel(model, grad_dtype='bf16', wgrad_slots=112)
+        slots = C.c_int(0)
+        L.check(L.lib.dsl_get_option(b'wgrad_slots', C.byref(slots)))
+        assert model.grad_bf16 and slots.value == 112
         opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
                       grad_clip=dict(max_norm=1.0, norm_type=2))
         norms = []

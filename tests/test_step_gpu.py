@@ -296,7 +296,7 @@ def test_pipelined_prefix_equals_inline_forward(golden):
 def test_deferred_head_update_trains_to_the_same_bits(golden, monkeypatch):
     """Deferred head update (engine.Plan.defer, FlatSGD without clipping): the towers' weight gradients and the head + FPN bucket's
     optimizer step run under the NEXT step's backbone forward, which waits for them in front of the FPN (SLOT_HEADW).  Same kernels
-    and summation order (DSL_DEFER_SLOTS = the inline budget) => bit-identical losses and weights over steps with changing images;
+    and summation order (tuning key defer_slots = the inline budget) => bit-identical losses and weights over steps with changing images;
     a state_dict() read right behind opt.step() already sees the finished update (ParamStore.wait_pending)."""
     from dsl_amd.optim import FlatSGD
     d = golden('net_tiny.npz')
@@ -305,11 +305,13 @@ def test_deferred_head_update_trains_to_the_same_bits(golden, monkeypatch):
     g = torch.Generator().manual_seed(5)
     imgs = [(T(d['img']) + 0.5 * k * torch.randn(T(d['img']).shape, generator=g)).cuda() for k in range(5)]
     metas = [dict(img_shape=tuple(imgs[0].shape[2:]) + (3,), pad_shape=tuple(imgs[0].shape[2:]) + (3,), scale_factor=1.0)] * B
-    monkeypatch.setenv('DSL_DEFER_SLOTS', '72')
-    monkeypatch.setenv('DSL_TOWER_SLOTS', '72')
+    from dsl_amd import tuning
+    tuning.tune('side')                                    # (DSL_TUNE parsed before the overrides below)
+    monkeypatch.setitem(tuning._values, 'defer_slots', '72')
+    monkeypatch.setitem(tuning._values, 'tower_slots', '72')
     finals = []
     for defer in ('0', '1'):
-        monkeypatch.setenv('DSL_DEFER_HEAD', defer)
+        monkeypatch.setitem(tuning._values, 'defer_head', defer)
         model = build()
         opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
         assert bool(getattr(model.store, 'defer_head', False)) == (defer == '1')
@@ -340,8 +342,10 @@ def test_deferred_plan_with_a_clipping_optimizer_still_sees_every_gradient(golde
     gtb, gtl = [T(d[f'gt{i}']) for i in range(B)], [T(d[f'gl{i}']) for i in range(B)]
     img = T(d['img']).cuda()
     metas = [dict(img_shape=tuple(img.shape[2:]) + (3,), pad_shape=tuple(img.shape[2:]) + (3,), scale_factor=1.0)] * B
-    monkeypatch.setenv('DSL_DEFER_SLOTS', '72')
-    monkeypatch.setenv('DSL_DEFER_HEAD', '1')
+    from dsl_amd import tuning
+    tuning.tune('side')
+    monkeypatch.setitem(tuning._values, 'defer_slots', '72')
+    monkeypatch.setitem(tuning._values, 'defer_head', '1')
     res = []
     for late_clip in (False, True):
         model = build()
