@@ -79,6 +79,14 @@ def _lib_option(name):
     return int(v.value)
 
 
+def _streams_probe():
+    """How many of the library's three concurrently used streams sit on hardware queues of their own (dsl_streams_init; 3 = all)."""
+    from dsl_amd import _lib as L
+    v = C.c_int(0)
+    L.check(L.lib.dsl_streams_init(L.stream_ptr(), C.byref(v)), 'dsl_streams_init')
+    return int(v.value)
+
+
 def _release_earlier_models():
     """Before an extra's model is built: collect the models earlier measurements left behind NOW.  Otherwise the garbage collector
     finds them some iterations into the next timed window, and releasing a model's device-side state (events, the library's cached
@@ -348,6 +356,8 @@ def main():
     ap.add_argument('--no-dsl', action='store_true', help='skip the extra.dsl_iteration timing (configs[2]) after the timed region')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket the conv kernels with HIP events')
     ap.add_argument('--prof-light', action='store_true', help='bracket only the dominant kernel class in the instrumented pass')
+    ap.add_argument('--foreign-streams', default='', help="'before' / 'after' / 'before,after': the process creates and uses streams of its own "
+                    "(as a DataLoader's copy stream or an evaluation hook would) before / after the model is built - the stream-layout robustness probe")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -366,6 +376,25 @@ def main():
     from dsl_amd.parallel import HipDistributedDataParallel
     from dsl_amd.registry import build_detector
 
+    foreign = []
+
+    def foreign_streams(n=3):
+        """n streams from torch's pool, each USED (a small copy): a stream takes its hardware queue at first use."""
+        src = torch.ones(1 << 16, device='cuda')
+        for _ in range(n):
+            st_ = torch.cuda.Stream()
+            with torch.cuda.stream(st_):
+                dst = src.clone()
+            foreign.append((st_, dst))
+        torch.cuda.synchronize()
+
+    def foreign_tick():
+        """What a loader's copy stream does beside the step: a small asynchronous copy per step on every foreign stream."""
+        for st_, dst in foreign:
+            with torch.cuda.stream(st_):
+                dst.add_(1.0)
+    if 'before' in args.foreign_streams:
+        foreign_streams()
     model = build_detector(model_cfg()).cuda()      # random init, reference style, same seed on every rank
     # (no attribute is set here that dsl_amd.apis.train_detector does not set: lazy log vars, the eager backward and the pipelined
     # frozen prefix are the detector's defaults - the headline is the product path; extra.train_detector times the same step
@@ -383,6 +412,8 @@ def main():
                             # profiles/r04_streams.txt: 350 instead of 425 img/s.)
 
     def step():
+        if foreign:
+            foreign_tick()
         mark_ready(batch['img'], event=ready)
         out = model.train_step(batch, opt)
         out['loss'].backward()
@@ -392,6 +423,11 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    if 'after' in args.foreign_streams:
+        foreign_streams()
+        for _ in range(3):
+            out = step()
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     def timed(k):
@@ -525,6 +561,13 @@ def main():
         # attribution: the same steps with every collective skipped (gradients then wrong - timing only, after everything that is reported)
         devs = [None] * world
         dist.all_gather_object(devs, dict(rank=rank, device=torch.cuda.current_device(), name=torch.cuda.get_device_name()))
+        # a scaling number is only one if every rank had a GPU of its own and the communicator spans them all: fail loudly otherwise
+        # (the 1-GPU dry run of tests/test_ddp_gpu.py puts every rank on cuda:0 on purpose: DSL_BENCH_ONE_GPU)
+        n_comm = int(L.lib.dsl_comm_size(det.rccl.comm)) if det.rccl is not None else dist.get_world_size()
+        if n_comm != world:
+            raise RuntimeError(f'bench.py --gpus {world}: the communicator has {n_comm} ranks')
+        if not os.environ.get('DSL_BENCH_ONE_GPU') and len({d['device'] for d in devs}) != world:
+            raise RuntimeError(f'bench.py --gpus {world}: ranks share devices {[d["device"] for d in devs]} - one process per GPU expected')
         det.comm_off = True
         for _ in range(2):
             step()
@@ -545,12 +588,28 @@ def main():
                                     '(per-bucket SGD), so only traffic still in flight at step_ms is exposed; ms_per_step_comm_disabled = the '
                                     'same loop with every collective skipped (max over ranks): the difference to ms_per_step is what '
                                     'communication costs, the difference to the 1-GPU figure is what running beside other ranks costs'))
+    layout = None
+    if rank == 0 and world == 1 and not args.no_dsl and not foreign:
+        # stream-layout robustness (which streams share a hardware queue is a 20 % variable): the same loop again with
+        # three foreign streams of torch's pool created now and used in every step, as a loader's copy stream would be
+        dt_a, _ = timed(args.steps)
+        foreign_streams()
+        for _ in range(3):
+            step()
+        dt_b, _ = timed(args.steps)
+        layout = dict(ms_per_step_clean=round(dt_a / args.steps * 1e3, 3), ms_per_step_with_foreign_streams=round(dt_b / args.steps * 1e3, 3),
+                      ratio=round(dt_b / dt_a, 4), streams_on_own_queues=_streams_probe(),
+                      note="three torch.cuda.Stream()s created after the model and used (a small op each) in every step; the library's own "
+                           'streams are created AND picked by the C library (csrc/api.hip side_init: a spin-kernel probe finds three on hardware queues of their own); tests/test_stream_layout_gpu.py runs '
+                           'the before / after variants in fresh processes')
+        foreign.clear()
     if rank == 0 and world == 1 and not args.no_dsl:
         del opt
         # (train_detector last: every model instance creates streams, and stream creation order decides which streams share one of
         # the four hardware queues - DESIGN 3.2i; the semi-supervised variants keep the order their round-3 numbers were taken in)
         extra = dict(dsl_iteration=dsl_iteration_timing(), fp8_towers=fp8_step_timing(batch), datapath=datapath_timing())
         extra['train_detector'] = train_detector_timing(batch, steps=60, warm=10)
+        extra['stream_layout_check'] = layout
         if roof is not None:        # BASELINE.json configs[2] beside the headline, also where a record that keeps `roofline` keeps it
             roof['configs2_dsl_iteration_ms'] = {k: v for k, v in extra['dsl_iteration'].items() if k.startswith('ms_per_iter')}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -23,6 +23,7 @@ F5 = C.c_float * MAX_SEG
 CONV_RELU_OUT, CONV_RELU_IN, CONV_OUT_F32, CONV_MASK_FIRST, CONV_MASK_LAST, CONV_ADD_UPSAMPLE, \
     CONV_SMALL_C = 1, 2, 4, 8, 16, 32, 64
 CONV_FP8 = 128
+CONV_EPI_STAGED = 1 << 16
 (OP_CONV, OP_WGRAD, OP_GN_FWD, OP_GN_BWD, OP_MAXPOOL, OP_SUM2X2, OP_COLSUM, OP_MEMSET, OP_PACK_IMAGE,
  OP_ASSIGN, OP_LOSS, OP_FORK, OP_JOIN, OP_WGRAD_GROUP, OP_RECORD, OP_WAIT) = range(1, 17)
 OP_RLA = 17
@@ -31,6 +32,7 @@ OP_WGRAD_MULTI = 19
 OP_PROF = 21
 OP_QUANT_FP8, OP_QUANT_FP8_W, OP_FP8_COMB = 22, 23, 24
 OP_STEM_POOL = 25
+OP_BNECK = 26
 PROF_CLASSES = 8
 MAX_MULTI = 16
 SLOT_TAIL, SLOT_PREFIX = 13, 14     # pipelined frozen prefix: 'previous backward's data-gradient chain done', 'prefix of this step done'
@@ -109,6 +111,14 @@ class PackItem(C.Structure):
     _fields_ = [('w', C.c_void_p), ('scale', C.c_void_p), ('out', C.c_void_p),
                 ('cout', C.c_int32), ('cout_pad', C.c_int32), ('taps', C.c_int32), ('cin', C.c_int32),
                 ('block_start', C.c_int32), ('tiles_ci', C.c_int32), ('tiles_co', C.c_int32), ('tapmap', C.c_int32)]
+
+
+class BneckDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w1', C.c_void_p), ('w2', C.c_void_p), ('w3', C.c_void_p), ('idt', C.c_void_p),
+                ('s1', C.c_void_p), ('b1', C.c_void_p), ('s2', C.c_void_p), ('b2', C.c_void_p), ('s3', C.c_void_p), ('b3', C.c_void_p),
+                ('a1', C.c_void_p), ('a2', C.c_void_p), ('out', C.c_void_p),
+                ('n', C.c_int32), ('hin', C.c_int32), ('win', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
+                ('planes', C.c_int32), ('cin', C.c_int32), ('ldx', C.c_int32), ('stride', C.c_int32), ('ldi', C.c_int32), ('ldo', C.c_int32)]
 
 
 class RlaDesc(C.Structure):
@@ -198,8 +208,9 @@ _SIGS = {
     'dsl_allreduce_bucket_bf16': [_vp, _vp, C.c_size_t, _vp],
     'dsl_cast_f32': [_vp, _vp, _l, _vp], 'dsl_sumsq_partial': [_vp, _l, _vp, _vp], 'dsl_sumsq_fold': [_vp, _i, _vp, _vp],
     'dsl_pseudo_label_fuse_history': [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
+    'dsl_bottleneck_fwd': [_vp, _vp], 'dsl_bottleneck_fwd_supported': [_vp],
     'dsl_set_option': [C.c_char_p, _i], 'dsl_get_option': [C.c_char_p, _vp],
-    'dsl_run_ops': [_vp, _i, _vp], 'dsl_stream_wait_slot': [_i, _vp], 'dsl_stream_record_slot': [_i, _vp], 'dsl_side_stream': [_i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_prof_read2': [_vp, _vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
+    'dsl_run_ops': [_vp, _i, _vp], 'dsl_stream_wait_slot': [_i, _vp], 'dsl_stream_record_slot': [_i, _vp], 'dsl_side_stream': [_i, _vp], 'dsl_streams_init': [_vp, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_prof_read2': [_vp, _vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
 }
 MISSING = []
 for _name, _args in _SIGS.items():

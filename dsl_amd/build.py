@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdsl_hip.so')
-SOURCES = ['api.hip', 'conv.hip', 'wgrad.hip', 'misc.hip', 'fcos_loss.hip', 'optim.hip', 'detect.hip', 'rla.hip', 'datapath.hip', 'comm.hip', 'stem.hip']
+SOURCES = ['api.hip', 'conv.hip', 'wgrad.hip', 'misc.hip', 'fcos_loss.hip', 'optim.hip', 'detect.hip', 'rla.hip', 'datapath.hip', 'comm.hip', 'stem.hip', 'bneck.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-unused-value']
 
 

@@ -25,8 +25,9 @@ extern "C" int dsl_version(void) { return 100; }
 namespace {
 struct Option { const char* name; int value; };
 Option g_options[] = {
+    {"conv_addfast", 1},     // (A/B) 0: convolutions with an addend take the staged fp32 epilogue instead of the in-register addend path
     {"wgrad_slots", 128},    // workgroup budget of a weight-gradient launch that runs beside the caller's chain (dsl_wgrad_desc.slots = 0)
-    {"side_cus", 0},         // > 0: side stream 1 (weight gradients) is confined to this many CUs per XCD (before the first dsl_run_ops)
+    {"stream_probe", 1},     // 0: the library takes its streams as the runtime deals them instead of probing for distinct hardware queues
     {"debug_sync", 0},       // 1: drain the device after every op of dsl_run_ops and name it on stderr
     {"skip_kinds", 0},       // step-level ablation (tools/step_ablation.sh): bit mask of op kinds dsl_run_ops does not launch - timing only
 };
@@ -52,35 +53,83 @@ extern "C" int dsl_get_option(const char* name, int* value) {
 }
 
 namespace {
-// side streams + a ring of events per device, created lazily (host objects, no device memory)
-constexpr int kEvRing = 256, kSide = 3;
-hipStream_t g_side[16][kSide] = {};
+// The library's streams + a ring of events per device, created at the first use of any of them (host objects, no device memory).
+//
+// Which of a process's streams share one of the device's hardware queues decides up to 20 % of the step: the runtime
+// deals streams out over FOUR queues per priority class, a fifth busy queue collapses the step (stream_prio experiments, round 5:
+// 235 - 270 instead of 440 img/s with the library's streams in a class of their own), and a host framework's own streams (a
+// DataLoader's copy stream, an evaluation hook - created before or after the model) take part in the deal.  The library therefore
+// owns every stream it uses and PICKS them: it creates candidates and measures, with a 300 us spin kernel on one stream and an empty
+// kernel on the other, which of them run concurrently with the caller's stream and with each other; the three streams that carry
+// the step's concurrent work - weight gradients, second chain, frozen prefix - are three candidates on three different queues,
+// none of them the caller's, whatever else the process has created.
+//   ids 1..3  side streams of dsl_run_ops: 1 = weight gradients (+ the optimizer's per-bucket updates), 2 = second head tower,
+//             3 = second image chain / FPN branch.  2 and 3 are ONE stream: their work never overlaps in time (+ 1 %, round 5)
+//   ids 4..6  role streams handed to the host side (dsl_side_stream): 4 = pipelined frozen prefix, 5 = communication,
+//             6 = asynchronous teacher sweep
+constexpr int kEvRing = 256, kSide = 3, kStreams = 6;
+hipStream_t g_side[16][kStreams] = {};
 hipEvent_t g_ev[16][kEvRing] = {};
 int g_evpos[16] = {};
 bool g_init[16] = {};
+int g_probe_result[16] = {};            // distinct-queue streams found by the probe (3 = all), -1 = probe off
 hipEvent_t g_named[16][16] = {};        // DSL_OP_RECORD / DSL_OP_WAIT slots
 bool g_named_set[16][16] = {};
-// Side stream 1 carries the weight gradients.  Option side_cus = k (k < 32) confines it to k of the 32 CUs of every XCD
-// (hipExtStreamCreateWithCUMask; bit i of the mask = CU i/8 of XCD i%8, pinned by tests/test_kernels_gpu.py::
-// test_probe_cu_mask): its long-running 128 KB-LDS workgroups then cannot occupy the CUs the caller's latency-critical
-// kernel chain needs.  Streams 2, 3 (forward tower overlap) stay unrestricted.
-int side_cus() { return dsl_option("side_cus"); }
-void side_init(int dev) {
+
+__global__ void spin_kernel(long long ticks) {       // wall-clock ticks (100 MHz): bounded, touches no memory
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+// Do streams a and b run concurrently (different hardware queues)?  b's empty kernel finishes while a's spin is still running.
+bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb) {
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 30000LL);      // 300 us
+  hipEventRecord(ea, a);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, 0LL);
+  hipEventRecord(eb, b);
+  hipEventSynchronize(eb);
+  const bool a_running = hipEventQuery(ea) == hipErrorNotReady;
+  hipEventSynchronize(ea);
+  (void)hipGetLastError();
+  return a_running;
+}
+void side_init(int dev, hipStream_t caller) {
   if (g_init[dev]) return;
-  for (int i = 0; i < kSide; ++i) {
-    const int k = side_cus();
-    if (i == 0 && k > 0 && k < 32) {
-      uint32_t mask[8];
-      for (int w = 0; w < 8; ++w) mask[w] = 0;
-      for (int b = 0; b < 256; ++b)
-        if (b / 8 < k) mask[b >> 5] |= 1u << (b & 31);
-      if (hipExtStreamCreateWithCUMask(&g_side[dev][i], 8, mask) == hipSuccess) continue;
-      (void)hipGetLastError();
-    }
-    hipStreamCreateWithFlags(&g_side[dev][i], hipStreamNonBlocking);
-  }
   for (int i = 0; i < kEvRing; ++i) hipEventCreateWithFlags(&g_ev[dev][i], hipEventDisableTiming);
   for (int i = 0; i < 16; ++i) hipEventCreateWithFlags(&g_named[dev][i], hipEventDisableTiming);
+  constexpr int kCand = 12, kNeed = 3;
+  hipStream_t cand[kCand] = {};
+  bool used[kCand] = {};
+  for (int i = 0; i < kCand; ++i) {
+    hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking);
+    hipEventRecord(g_ev[dev][i], cand[i]);         // first use: the candidate takes its hardware queue now
+  }
+  hipStream_t chosen[kNeed] = {};
+  int n = 0;
+  if (dsl_option("stream_probe") != 0) {
+    hipEvent_t ea = g_ev[dev][kEvRing - 1], eb = g_ev[dev][kEvRing - 2];
+    for (int i = 0; i < kCand && n < kNeed; ++i) {
+      bool ok = streams_concurrent(caller, cand[i], ea, eb);
+      for (int j = 0; j < n && ok; ++j) ok = streams_concurrent(chosen[j], cand[i], ea, eb);
+      if (ok) { chosen[n++] = cand[i]; used[i] = true; }
+    }
+    g_probe_result[dev] = n;
+  } else {
+    g_probe_result[dev] = -1;
+  }
+  auto take = [&]() -> hipStream_t {            // any candidate not handed out yet
+    for (int i = 0; i < kCand; ++i)
+      if (!used[i]) { used[i] = true; return cand[i]; }
+    return cand[0];
+  };
+  while (n < kNeed) chosen[n++] = take();        // (probe off, or fewer than three free queues: whatever the runtime dealt)
+  g_side[dev][0] = chosen[0];                    // weight gradients
+  g_side[dev][1] = chosen[1];                    // second tower ...
+  g_side[dev][2] = chosen[1];                    // ... and second image chain: one stream
+  g_side[dev][3] = chosen[2];                    // frozen prefix
+  g_side[dev][4] = take();                       // communication
+  g_side[dev][5] = take();                       // teacher sweep
+  for (int i = 0; i < kCand; ++i)
+    if (!used[i]) hipStreamDestroy(cand[i]);
   g_init[dev] = true;
 }
 hipEvent_t next_event(int dev) {
@@ -124,7 +173,7 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
         o.kind != DSL_OP_RECORD && o.kind != DSL_OP_WAIT && (!(skip_kinds >> 30 & 1u) || o.i[6] == 1))
       continue;
     if (o.kind == DSL_OP_RECORD || o.kind == DSL_OP_WAIT) {
-      side_init(dev);
+      side_init(dev, main_st);
       DSL_CHECK(o.i[1] >= 0 && o.i[1] < 16, "dsl_run_ops: event slot %d out of range", o.i[1]);
       if (o.kind == DSL_OP_RECORD) {
         hipEventRecord(g_named[dev][o.i[1]], pick(o.i[0]));
@@ -135,7 +184,7 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
       continue;
     }
     if (o.i[6] > 0 || o.kind == DSL_OP_FORK || o.kind == DSL_OP_JOIN) {
-      side_init(dev);
+      side_init(dev, main_st);
       if (o.kind == DSL_OP_FORK || o.kind == DSL_OP_JOIN) {
         const int side_id = o.i[0] > 0 ? o.i[0] : 1, other = o.i[1];
         hipStream_t from = o.kind == DSL_OP_FORK ? pick(other) : pick(side_id);
@@ -153,6 +202,7 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
       case DSL_OP_WGRAD: rc = dsl_conv2d_wgrad((const dsl_wgrad_desc*)o.desc, stream); break;
       case DSL_OP_WGRAD_GROUP: rc = dsl_conv2d_wgrad_group((const dsl_wgrad_desc*)o.desc, o.i[0], stream); break;
       case DSL_OP_WGRAD_MULTI: rc = dsl_conv2d_wgrad_multi(o.p[0], o.p[1], stream); break;
+      case DSL_OP_BNECK: rc = dsl_bottleneck_fwd((const dsl_bneck_desc*)o.desc, stream); break;
       case DSL_OP_GN_FWD: rc = dsl_groupnorm_relu_fwd((const dsl_gn_desc*)o.desc, stream); break;
       case DSL_OP_GN_BWD: rc = dsl_groupnorm_relu_bwd((const dsl_gn_desc*)o.desc, stream); break;
       case DSL_OP_MAXPOOL: rc = dsl_maxpool3x3s2_ld(o.p[0], o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] > 0 ? o.i[4] : o.i[3], stream); break;
@@ -227,21 +277,34 @@ extern "C" int dsl_stream_record_slot(int slot, void* stream) {
   int dev = 0;
   hipGetDevice(&dev);
   DSL_CHECK(dev >= 0 && dev < 16 && slot >= 0 && slot < 16, "dsl_stream_record_slot: bad device %d / slot %d", dev, slot);
-  side_init(dev);
+  side_init(dev, (hipStream_t)stream);
   DSL_CHECK(hipEventRecord(g_named[dev][slot], (hipStream_t)stream) == hipSuccess, "dsl_stream_record_slot: hipEventRecord failed");
   g_named_set[dev][slot] = true;
   return 0;
 }
 
-// The library's side stream `id` (1..3) of the current device, for callers that have to queue their own work in order with it:
+// The library's stream `id` of the current device (1..3 side streams of dsl_run_ops, 4 prefix, 5 communication, 6 sweep: side_init),
+// for callers that have to queue their own work in order with it or need a stream whose hardware queue is part of the library's layout:
 // the optimizer puts the deferred bucket's update on side stream 1, right behind the weight gradients it waits for (a stream of
 // its own may share a hardware queue with another of the step's streams and then runs behind THAT stream's backlog).
 extern "C" int dsl_side_stream(int id, void** stream_out) {
   int dev = 0;
   hipGetDevice(&dev);
-  DSL_CHECK(dev >= 0 && dev < 16 && id >= 1 && id <= kSide && stream_out, "dsl_side_stream: bad device %d / stream id %d", dev, id);
-  side_init(dev);
+  DSL_CHECK(dev >= 0 && dev < 16 && id >= 1 && id <= kStreams && stream_out, "dsl_side_stream: bad device %d / stream id %d", dev, id);
+  side_init(dev, (hipStream_t)0);          // (not initialised yet and no caller stream at hand: probe against the default stream)
   *stream_out = (void*)g_side[dev][id - 1];
+  return 0;
+}
+
+// Create (and pick, see side_init) the library's streams of the current device now, measured against `caller_stream` - the stream
+// the step will be queued on.  Optional: the first dsl_run_ops does it otherwise.  *distinct_out (may be NULL): how many of the three
+// concurrently used streams the probe found on hardware queues of their own (3 = all; -1 = probe switched off).
+extern "C" int dsl_streams_init(void* caller_stream, int* distinct_out) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  DSL_CHECK(dev >= 0 && dev < 16, "dsl_streams_init: device index %d out of range", dev);
+  side_init(dev, (hipStream_t)caller_stream);
+  if (distinct_out) *distinct_out = g_probe_result[dev];
   return 0;
 }
 

@@ -34,6 +34,7 @@ struct ConvK {
   int lds;                            // source pixel stride in elements (>= cs: the source may be a channel slice of wider rows)
   int ktiles, kc;
   int ident;                          // 1: destination pixel index == compute-grid pixel index (os 1, same sizes)
+  int addfast;                        // 1: the addend tile can be DMA'd into LDS (ident, 16-byte aligned rows, 32-bit offsets)
   int dbg;                            // ablation knobs, compiled in only by tools/build_ablate.sh (-DDSL_ABLATE_BUILD; DSL_ABLATE env)
   int splits, kt_per_split, cd_pad;   // split-K over K tiles (v2 kernel): fp32 partials -> ws, then conv_splitk_epilogue_kernel
   int gx, gy, xcd_chunk;              // v3: tile grid (cout tiles, pixel tiles) and tiles per XCD of the 1-D XCD-aware launch
@@ -788,9 +789,106 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvK& p, f32x16 (&acc)
   // bytes, same arithmetic in the same order as the staged fp32 path (mul_nc / add_nc: one rounding each).
   constexpr int ROWH = BCO * 2 + 16;
   static_assert((long long)BPX * ROWH <= (long long)RING, "the bf16 tile fits in the ring");
+  // ---- addend epilogue (residual adds of the bottlenecks' forward and data-gradient chains, the FPN's and the head's gradient sums):
+  // the addend TILE is brought into the then-free ring by DMA as dense bf16 rows [pixel][BCO] (16-byte chunk c of row r in slot
+  // c ^ f(r): the swizzle is applied through the source address, the LDS image of a DMA is lane-linear), every lane adds its 4-cout
+  // runs in the accumulator registers - scale, bias, + addend, ReLU, one rounding: the staged fp32 path's operations in its order -
+  // and writes the rounded run back IN PLACE (a run's slot belongs to exactly one lane); the tile then leaves as 16-byte stores like
+  // the pure path's.  A ReLU mask applied last commutes with the rounding (see below).  One DMA round trip, three barriers and
+  // BPX x BCO x 2 bytes of LDS instead of PT slabs of {barrier, fp32 staging, barrier, per-item global loads of the addend}.
+  // (addfast == 2: the addend is nearest-upsampled - the FPN's top-down path in the lateral convolution's epilogue, fpn.py:163-172 - the
+  // DMA lanes compute the addend's pixel, everything else is the same launch-on-its-own-grid case)
+  if ((ef.on || (p.addfast == 2 && !(p.flags & DSL_CONV_OUT_F32))) && ef.has_add && p.addfast && !ef.mask_first && !(ef.mask_last && ef.relu) &&
+      (p.cd & 7) == 0) {
+    constexpr int RB = BCO * 2;                        // bytes per staged row
+    constexpr int NCH = RB / 16;                       // 16-byte chunks per row
+    constexpr int FSH = RB >= 256 ? 0 : (RB == 128 ? 1 : 2);      // rows that share a bank phase before the chunk rotation repeats
+    static_assert((long long)BPX * RB <= (long long)RING, "the dense bf16 tile fits in the ring");
+    static_assert((BPX * RB) % (T * 16) == 0, "whole DMA instructions per wave");
+    constexpr int NDMA = BPX * RB / (T * 16);          // DMA instructions per wave (1 KiB each)
+    lds_barrier();                                     // every wave is done with the ring
+    {
+      const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc((void*)p.addend, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) {
+        const int off = (i * (T / 64) + wave) * 1024 + lane * 16;     // this lane's LDS byte
+        const int row = off / RB, slot = (off % RB) >> 4;
+        const int c = slot ^ ((row >> FSH) & (NCH - 1));              // source chunk that belongs in this slot
+        const int gp = px0 + row;
+        const bool ok = gp < totpx && co0 + c * 8 < p.cd;
+        int arow = gp;
+        if (p.addfast == 2 && ok) {
+          int seg, img, y, x;
+          decode_pixel(p, gp, seg, img, y, x);
+          const int ay = (y * p.ah[seg]) / p.dh[seg], ax = (x * p.aw[seg]) / p.dw[seg];
+          arow = (int)p.aoff[seg] + (img * p.ah[seg] + ay) * p.aw[seg] + ax;
+        }
+        const unsigned v = ok ? (unsigned)(arow * p.lda + co0 + c * 8) * 2u : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_add, (lptr_t)(smem + (i * (T / 64) + wave) * 1024), 16, v, 0, 0, 0);
+      }
+    }
+    wait_vmcnt<0>();
+    lds_barrier();
+    stamp(1);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
+        const bool in = co0 + col + 3 < p.cd;
+        const f32x4 sc = (ef.has_scale && in) ? *reinterpret_cast<const f32x4*>(p.scale + co0 + col) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 bi = (ef.has_bias && in) ? *reinterpret_cast<const f32x4*>(p.bias + co0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const int row = wave_px * (32 * PT) + pt * 32 + frow;
+          unsigned char* cell = smem + row * RB + ((((col >> 3) ^ ((row >> FSH) & (NCH - 1))) << 4) | (fhalf << 3));
+          const u32x2 aa = *reinterpret_cast<const u32x2*>(cell);
+          const float ad[4] = {bflo(aa[0]), bfhi(aa[0]), bflo(aa[1]), bfhi(aa[1])};
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = acc[ct][pt][4 * g + j];
+            if (ef.has_scale) v[j] = mul_nc(v[j], sc[j]);
+            if (ef.has_bias) v[j] = add_nc(v[j], bi[j]);
+            v[j] = add_nc(v[j], ad[j]);
+            if (ef.relu) v[j] = fmaxf(v[j], 0.f);
+          }
+          const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(cell) = o;
+        }
+      }
+    lds_barrier();
+    stamp(2);
+    {
+      constexpr int NITP = BPX * GPR / T;
+      static_assert(BPX * GPR % T == 0, "whole items per thread");
+      constexpr int RPT = T / GPR;
+      const int row0 = tid / GPR, cgp = tid % GPR;
+      if (co0 + cgp * 8 < p.cd) {
+        uint16_t* out = reinterpret_cast<uint16_t*>(p.dst) + (co0 + cgp * 8);
+#pragma unroll 4
+        for (int n_ = 0; n_ < NITP; ++n_) {
+          const int row = row0 + n_ * RPT;
+          const int gp = px0 + row;
+          if (gp < totpx) {
+            u32x4 r = *reinterpret_cast<const u32x4*>(smem + row * RB + ((cgp ^ ((row >> FSH) & (NCH - 1))) << 4));
+            if (ef.mask_last) {
+              const u32x4 mm = *reinterpret_cast<const u32x4*>(ef.mask + (long long)gp * ef.ldm);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                r[e] &= (bflo(mm[e]) > 0.f ? 0xffffu : 0x8000u) | (bfhi(mm[e]) > 0.f ? 0xffff0000u : 0x80000000u);
+            }
+            *reinterpret_cast<u32x4*>(out + (long long)gp * p.ldd) = r;
+          }
+        }
+      }
+    }
+    stamp(3);
+    return;
+  }
   // A ReLU mask applied LAST (the data gradients: round(v * m), m in {0, 1}) commutes with the rounding - m ? round(v) : +-0 with v's
   // sign - so it is applied to the staged bf16 words in the store loop, bit for bit what the fp32 path produces for finite v.
-  if (ef.on && !ef.has_add && !ef.mask_first && !(ef.mask_last && ef.relu) && (p.cd & 7) == 0) {
+  if (ef.on && !(p.flags & DSL_CONV_EPI_STAGED) && !ef.has_add && !ef.mask_first && !(ef.mask_last && ef.relu) && (p.cd & 7) == 0) {
     lds_barrier();                           // every wave is done with the ring (its DMA has landed: wait_vmcnt<0> above)
     // (cout group outermost: a lane keeps ONE group's scale / bias at a time - all of them at once cost 64 registers and an
     // occupancy step on the small tiles)
@@ -1939,6 +2037,13 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   for (int s = 0; s < d->nseg; ++s)
     if (d->gh[s] != d->dh[s] || d->gw[s] != d->dw[s]) k.ident = 0;
   k.cs = d->cs; k.cd = d->cd; k.ldd = d->ldd; k.lda = d->lda; k.ldm = d->ldm;
+  // the in-register addend epilogue (conv_tile_epilogue): the addend tile goes to LDS by DMA with 32-bit buffer offsets
+  bool identd = d->os == 1;               // destination pixel == compute-grid pixel (whatever the addend's grid is)
+  for (int s = 0; s < d->nseg; ++s)
+    if (d->gh[s] != d->dh[s] || d->gw[s] != d->dw[s]) identd = false;
+  k.addfast = (d->addend && identd && dsl_option("conv_addfast") != 0 && !(d->flags & DSL_CONV_EPI_STAGED) && d->lda % 8 == 0 && d->ldd % 8 == 0 &&
+               (!d->mask || d->ldm % 8 == 0) && ((uintptr_t)d->addend & 15) == 0 && ((uintptr_t)d->dst & 15) == 0 &&
+               (dof > ao ? dof : ao) * (long long)d->lda * 2 < 0x7fff0000LL) ? ((d->flags & DSL_CONV_ADD_UPSAMPLE) ? 2 : 1) : 0;
   k.lds = d->lds > 0 ? d->lds : d->cs;
   DSL_CHECK(k.lds >= d->cs && k.lds % (fp8 ? 16 : 8) == 0, "dsl_conv2d: lds=%d must be >= cs=%d and a multiple of 16 bytes", k.lds, d->cs);
   k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad; k.mode = d->mode; k.os = d->os;

@@ -215,14 +215,25 @@ class FCOSHead(nn.Module):
 # new ones from torch's pool - measured: the same loop on a second model in one process ran at 433 or 362 img/s depending on which
 # pool stream it happened to get (profiles/r04_td_first.txt).
 _ROLE_STREAMS = {}
+_ROLE_IDS = dict(prefix=4, comm=5, sweep=6, optimizer=1)      # the library's stream ids (csrc/api.hip side_init)
 
 
-def role_stream(role, device=None, priority=0):
+def role_stream(role, device=None):
+    """The library's own stream for `role` on `device`: created and PICKED by the C library together with its side streams (csrc/api.hip
+    side_init: a spin-kernel probe finds streams on hardware queues of their own) - not drawn from torch's pool, whose streams share
+    hardware queues with whatever else the process created.  The optimizer's per-bucket updates run on the weight-gradient stream itself (id 1): each follows the weight
+    gradients it waits for, which is where a stream of its own ended up anyway (one hardware queue with stream 1)."""
+    import ctypes as C
+    from . import _lib as L
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     key = (role, dev)
     st = _ROLE_STREAMS.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=dev, priority=priority) if priority else torch.cuda.Stream(device=dev)
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            L.check(L.lib.dsl_streams_init(L.stream_ptr(), None), 'dsl_streams_init')     # (picks the streams against the caller's: first call only)
+            L.check(L.lib.dsl_side_stream(_ROLE_IDS[role], C.byref(h)), 'dsl_side_stream')
+        st = torch.cuda.ExternalStream(h.value, device=dev)
         _ROLE_STREAMS[key] = st
     return st
 

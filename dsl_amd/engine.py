@@ -63,6 +63,13 @@ class OpList:
             return
         self._add(L.OP_CONV, d, i=(0, 0, 0, 0, 0, 0, int(side)))
 
+    def bneck(self, d):
+        """A whole bottleneck's forward pass as one launch on the caller's stream (dsl_bottleneck_fwd)."""
+        if self.tag and self.tag in skip_items():
+            self.keep.append(d)
+            return
+        self._add(L.OP_BNECK, d)
+
     def fork(self, side=1, other=0):
         """Side stream `side` waits for everything queued so far on stream `other` (0 = the caller's)."""
         self._add(L.OP_FORK, i=(side, other))
@@ -405,7 +412,10 @@ class Plan:
             d_.workspace, d_.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
             return d_
         for li, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
-            split = str(li + 1) in SPLIT
+            # Fused stages (tuning key bneck_fwd, default layer2 + layer3): every bottleneck's forward pass is ONE launch over the whole
+            # batch (dsl_bottleneck_fwd, csrc/bneck.hip) - the image-split chains of three launches per block and half are its predecessor
+            fuse = str(li + 1) in tune('bneck_fwd') and planes in (128, 256)
+            split = str(li + 1) in SPLIT and not fuse
             f.tag = f'fwd.l{li + 1}'
             if split and not split_open:
                 f.fork(self.BR)
@@ -446,6 +456,25 @@ class Plan:
                     x, h, w = out, oh, ow
                     continue
                 use_br = self.BR
+                bd = None
+                if fuse:
+                    bd = ops.bneck_desc(x, st.w16_ptr(c1), st.w16_ptr(c2), st.w16_ptr(c3), idt, st.bn_ptrs(c1.bn), st.bn_ptrs(c2.bn),
+                                        st.bn_ptrs(c3.bn), a1, a2, out, n=N, hin=h, win=w, h=oh, w=ow, planes=planes, cin=c1.cin_store,
+                                        ldx=int(x.shape[-1]), stride=s)
+                    if not L.lib.dsl_bottleneck_fwd_supported(C.byref(bd)):
+                        bd = None
+                if bd is not None:
+                    if b == 0:          # the downsample branch beside nothing: it IS the block's identity, joined in front of the launch
+                        dd = self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)])
+                        f.conv(dd)
+                        if li == 1:
+                            self._pp['ds'] = [(dd, 0)]
+                            self._pp['c1'] = [(bd, 0)]
+                    f.bneck(bd)
+                    self.blocks.append(dict(prefix=p, xin=x, a1=a1, a2=a2, out=out, in_hw=(h, w), out_hw=(oh, ow), stride=s,
+                                            stage=li, b=b, planes=planes))
+                    x, h, w = out, oh, ow
+                    continue
                 if b == 0:
                     dd = self._conv(cv[p + '.downsample.0'], x, idt, N, [(h, w)], [(oh, ow)])
                     if use_br:
@@ -955,7 +984,10 @@ class Plan:
         ptr = self._l1out[p].data_ptr()
         self._pp['c3'].dst = ptr
         for d_, off in self._pp['c1'] + self._pp['ds']:
-            d_.src = ptr + off
+            if isinstance(d_, L.BneckDesc):
+                d_.x = ptr + off
+            else:
+                d_.src = ptr + off
         self._pp['wg_c1'].x = ptr
         self._pp['wg_ds'].x = ptr
         self._parity = p

@@ -83,6 +83,27 @@ def dgrad_s2_descs(dy, packs, dst, *, n, dy_hw, dst_hw, cs, cd, cd_pad=None, ldd
     return out
 
 
+def bneck_desc(x, w1, w2, w3, idt, bn1, bn2, bn3, a1, a2, out, *, n, hin, win, h, w, planes, cin, ldx=None, stride=1, ldi=None, ldo=None):
+    """dsl_bottleneck_fwd: a trained bottleneck's forward pass as one launch (csrc/bneck.hip).  Tensors or raw pointers; bn_k = (scale, bias)
+    pointers of the folded BatchNorms."""
+    d = L.BneckDesc()
+    raw = lambda t: 0 if t is None else (t if isinstance(t, int) else t.data_ptr())
+    d.x, d.w1, d.w2, d.w3, d.idt = raw(x), raw(w1), raw(w2), raw(w3), raw(idt)
+    (d.s1, d.b1), (d.s2, d.b2), (d.s3, d.b3) = [(raw(s_), raw(b_)) for s_, b_ in (bn1, bn2, bn3)]
+    d.a1, d.a2, d.out = raw(a1), raw(a2), raw(out)
+    d.n, d.hin, d.win, d.h, d.w = n, hin, win, h, w
+    d.planes, d.cin, d.ldx, d.stride = planes, cin, ldx or cin, stride
+    d.ldi, d.ldo = ldi or 4 * planes, ldo or 4 * planes
+    d._keep = (x, w1, w2, w3, idt, bn1, bn2, bn3, a1, a2, out)
+    return d
+
+
+def bottleneck_fwd(*a, **k):
+    d = bneck_desc(*a, **k)
+    L.check(lib.dsl_bottleneck_fwd(C.byref(d), L.stream_ptr()), 'dsl_bottleneck_fwd')
+    return d
+
+
 def conv_workspace_bytes(d):
     return lib.dsl_conv2d_workspace_bytes(C.byref(d))
 

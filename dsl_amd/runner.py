@@ -637,6 +637,9 @@ class UnlabelPredHook(Hook):
             # the reference has no such limit and the lists grow from round to round: keep an image's `cap` best-scoring stored labels
             # (the per-class NMS favours high scores anyway) and say so once, instead of aborting a training run
             trimmed = []
+            dropped = sum(max(len(o['scores']) - cap, 0) for o in olds if o is not None)
+            self.fuse_dropped_total = getattr(self, 'fuse_dropped_total', 0) + dropped       # visible divergence from the reference
+            self.fuse_dropped_sweeps = getattr(self, 'fuse_dropped_sweeps', 0) + 1
             for o in olds:
                 if o is not None and len(o['scores']) > cap:
                     keep = np.sort(np.argsort(-np.asarray(o['scores'], np.float32), kind='stable')[:cap])
@@ -644,11 +647,12 @@ class UnlabelPredHook(Hook):
                              scores=[o['scores'][j] for j in keep], tags=[o['tags'][j] for j in keep])
                 trimmed.append(o)
             olds = trimmed
-            if not getattr(self, '_warned_fuse_cap', False):
-                self._warned_fuse_cap = True
+            if self.fuse_dropped_sweeps == 1 or self.fuse_dropped_sweeps % 100 == 0:       # the first time, then every 100th sweep that trims
                 import logging
-                logging.getLogger('dsl_amd').warning('fuse_history: %d stored labels + %d detections exceed the fuse step\'s 1024 candidates; '
-                                                      'keeping the %d best-scoring stored labels per image', max_old, maxk, cap)
+                logging.getLogger('dsl_amd').warning('fuse_history: %d stored labels + %d detections exceed the fuse step\'s 1024 candidates; keeping '
+                                                      'the %d best-scoring stored labels per image (%d labels dropped in this sweep, %d in %d sweeps '
+                                                      'so far - the reference keeps them all)', max_old, maxk, cap, dropped, self.fuse_dropped_total,
+                                                      self.fuse_dropped_sweeps)
             max_old = cap
         mo = max(max_old, 1)
         hb, hs = torch.zeros(n, mo, 4), torch.zeros(n, mo)

@@ -12,6 +12,7 @@ DEFAULTS = {
     'side': '1',               # library side streams (weight gradients, second tower, image-split chains); 0 = everything on the caller's stream
     'pipe_prefix': '1',        # the next step's frozen prefix (stem + layer1) on its own stream beside the backward tail
     'img_split': '234',        # forward stages (layer numbers) that run as two half-batch chains
+    'bneck_fwd': '23',         # forward stages whose bottlenecks run as one launch each (dsl_bottleneck_fwd; these stages are not image-split)
     'img_split_bwd': '23',     # backward stages whose data-gradient chains do
     'tower_slots': '72',       # workgroup budget of the towers' x8 weight-gradient group
     'tail_slots': '192',       # ... of the last segment's (layer2) weight gradients
@@ -25,8 +26,9 @@ DEFAULTS = {
     'check_backward_grad': '0',    # 1: verify the gradient handed to loss.backward() on every step (default: the first steps only)
     'skip': '',                # timing-only ablation: '+'-separated items - region tags (fwd.l2 ... bwd.l2), 'sgd', 'prefix'
     # ---- C library options (dsl_set_option)
+    'lib.conv_addfast': '1',   # (A/B of round 5's in-register addend epilogue; 0 = the staged fp32 epilogue)
     'lib.wgrad_slots': '128',
-    'lib.side_cus': '0',
+    'lib.stream_probe': '1',   # 0: the library takes its streams as the runtime deals them (no hardware-queue probe)
     'lib.debug_sync': '0',
     'lib.skip_kinds': '0',
 }

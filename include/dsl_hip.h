@@ -30,9 +30,10 @@ extern "C" {
 int dsl_version(void);
 const char* dsl_last_error(void);
 /* Library options - the library reads no environment variable.  Names: "wgrad_slots" (default 128: workgroup budget of a
- * weight-gradient launch whose descriptor leaves `slots` 0), "side_cus" (0; > 0 confines dsl_run_ops' weight-gradient stream to that
- * many CUs per XCD, set before the first dsl_run_ops), "debug_sync" (0; 1 = dsl_run_ops drains the device after every op and names
- * it on stderr), "skip_kinds" (0; timing-only ablation: bit mask of op kinds dsl_run_ops skips).  Unknown name: -1. */
+ * weight-gradient launch whose descriptor leaves `slots` 0), "stream_probe" (1; 0 = the library takes its streams as the runtime deals
+ * them instead of probing for hardware queues of their own, dsl_streams_init), "conv_addfast" (1; 0 = convolutions with an addend take
+ * the staged fp32 epilogue - A/B of the in-register addend path), "debug_sync" (0; 1 = dsl_run_ops drains the device after every op and
+ * names it on stderr), "skip_kinds" (0; timing-only ablation: bit mask of op kinds dsl_run_ops skips).  Unknown name: -1. */
 int dsl_set_option(const char* name, int value);
 int dsl_get_option(const char* name, int* value);
 
@@ -56,8 +57,10 @@ enum {
   DSL_CONV_MASK_LAST = 16,    /* v = (acc + addend)*(mask>0) */
   DSL_CONV_ADD_UPSAMPLE = 32, /* addend is nearest-upsampled (fpn.py:163-172) */
   DSL_CONV_SMALL_C = 64,      /* source has 8 channels (stem, image packed NHWC8) */
-  DSL_CONV_FP8 = 128          /* src and wgt are OCP fp8 e4m3 (dsl_quant_fp8 / dsl_quant_fp8_weights; forward mode, cs % 128 == 0,
+  DSL_CONV_FP8 = 128,         /* src and wgt are OCP fp8 e4m3 (dsl_quant_fp8 / dsl_quant_fp8_weights; forward mode, cs % 128 == 0,
                                * cs / lds count bytes): MX-scaled fp8 MFMA, `scale` carries 1 / (weight scale x activation scale) */
+  /* bits 8-11: tile configuration, bits 12-15: split-K factor (test hooks; 0 = the library's own choice) */
+  DSL_CONV_EPI_STAGED = 1 << 16   /* test hook: the general staged fp32 epilogue even where an in-register one applies (same bits) */
 };
 
 typedef struct dsl_conv_desc {
@@ -188,6 +191,23 @@ int dsl_quant_fp8_dyn(const void* x_bf16, void* y_fp8, long rows, int c, int ld_
 int dsl_fp8_comb(const float* winv, float* comb, int n, const float* partials, int n_partials, void* stream);
 int dsl_quant_fp8_weights(const float* w, void* w8, float* comb, const float* bn_scale, int cout, int cout_pad, int k,
                           float inv_act_scale, void* stream);
+
+/* A whole trained bottleneck's forward pass as ONE launch (csrc/bneck.hip; mmdet/models/backbones/resnet.py:262-301 Bottleneck.forward,
+ * caffe style: stride on conv1; eval-mode BatchNorms folded to (scale, bias)):
+ *   a1 = relu(bn1(conv1_1x1/stride(x))), a2 = relu(bn2(conv2_3x3(a1))), out = relu(bn3(conv3_1x1(a2)) + identity)
+ * x [n][hin][win] rows of ldx elements (cin read), a1 / a2 [n][h][w][planes] (written: the weight gradients read them), identity and out
+ * [n][h][w] rows of ldi / ldo elements (4 planes channels); weights bf16 in the forward layout of dsl_conv2d: w1 [planes][cin],
+ * w2 [planes][3][3][planes], w3 [4 planes][planes].  planes = 128 or 256 (ResNet-50's layer2 / layer3), stride 1 or 2.  Bit-identical to
+ * the three dsl_conv2d launches it replaces (same K order, same rounding points). */
+typedef struct dsl_bneck_desc {
+  const void* x; const void* w1; const void* w2; const void* w3; const void* idt;
+  const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3;
+  void* a1; void* a2; void* out;
+  int32_t n, hin, win, h, w;
+  int32_t planes, cin, ldx, stride, ldi, ldo;
+} dsl_bneck_desc;
+int dsl_bottleneck_fwd_supported(const dsl_bneck_desc* d);      /* 1 if dsl_bottleneck_fwd takes this shape */
+int dsl_bottleneck_fwd(const dsl_bneck_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GPU data path
@@ -524,6 +544,7 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_FP8_COMB = 24,   /* dsl_fp8_comb(p[0] = winv, p[1] = comb, i[0] = n, p[2] = partials, i[2] = n_partials) */
        DSL_OP_QUANT_FP8_W = 23, /* dsl_quant_fp8_weights(p[0] = w, p[1] = w8, p[2] = comb, p[3] = bn_scale, i[0] = cout, i[1] = cout_pad, i[2] = k,
                                 * inv_act_scale = the float whose bits are l[1]) */
+       DSL_OP_BNECK = 26,      /* desc = dsl_bneck_desc -> dsl_bottleneck_fwd */
        DSL_OP_STEM_POOL = 25,  /* dsl_stem_pool(p[0] = img, p[1] = w_groups, l[0] / l[1] = scale / bias pointers, p[2] = out, i[0] = ld_out,
                                 * i[1..3] = n, h, w, i[4] = half_last: dsl_stem_pool_half) */
        DSL_OP_PROF = 21 };     /* phase mark (dsl_prof_enable(3) only, else a no-op): i[0] = class >= 4, i[1] = 0 begin | 1 end, l[0] / l[1] =
@@ -548,6 +569,11 @@ int dsl_stream_record_slot(int slot, void* stream);
 /* The library's side stream `id` (1..3: 1 carries the weight gradients) of the current device as a hipStream_t, for work the
  * caller must queue in order with it (the optimizer step of a bucket whose last weight gradients run there). */
 int dsl_side_stream(int id, void** stream_out);
+/* Create the library's streams of the current device now and pick them so that the three that carry concurrent work (weight gradients,
+ * second chain, frozen prefix) sit on hardware queues of their own, none of them `caller_stream`'s - measured with a 300 us spin kernel,
+ * whatever other streams the process has created (api.hip side_init).  Optional (the first dsl_run_ops does it).  *distinct_out: how
+ * many of the three were found (3 = all, -1 = option "stream_probe" is 0). */
+int dsl_streams_init(void* caller_stream, int* distinct_out);
 
 /* ------------------------------------------------------------------------------------------
  * Live kernel timing with HIP events (bench.py roofline): when enabled, each launch of the MFMA

@@ -158,3 +158,33 @@ def test_fcos_step_with_fp8_towers_vs_bf16_step():
     cos = float((g16 * g8).sum() / (g16.norm() * g8.norm()))
     print('gradient norms', float(g16.norm()), float(g8.norm()), 'cosine', cos)
     assert cos > 0.9, cos          # (two bf16 runs of this net at different summation orders: ~0.97)
+
+
+def test_full_size_fp8_towers_step_vs_fp32_oracle():
+    """BASELINE.json configs[4]'s slice against the ORACLE, not against the bf16 step (round-4 review item 6): the benchmark's own batch
+    (2 x 3 x 800 x 1344, 44 800 locations) through FCOS(fp8=dict(layers='towers')) - e4m3 tower forward convolutions, dynamic
+    per-tensor activation scales, per-channel weight scales - against the fp32 CPU restatement of the reference step on the same
+    inputs.  Stated tolerance: every loss within 5e-3 relative of fp32 (the all-bf16 step is held to 1e-3 in
+    tests/test_step_gpu.py::test_full_size_losses_and_assignment_vs_oracle; e4m3 carries 3 mantissa bits on 8 of the ~70
+    convolutions between the image and the losses; measured values are printed), and bit-identical target assignment."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import fcos_oracle as O
+    model = _build(**dict(fp8=dict(layers='towers')))
+    b = bench.synth_batch(0, 2)
+    losses = model.forward_train(b['img'], b['img_metas'], b['gt_bboxes'], b['gt_labels'])
+    torch.cuda.synchronize()
+    plan = next(iter(model._engine.plans.values()))
+    assert 'feats.f8' in plan.bufs                      # the fp8 path is the one that ran
+    l32, _, aux = O.train_step(O.synth_state_dict(0), b['img'].cpu(), b['gt_bboxes'], b['gt_labels'], None, emulate_bf16=False, want_grads=False)
+    got = {k: float(v.detach()) for k, v in losses.items()}
+    print('fp8 towers', got, 'fp32 oracle', {k: l32[k] for k in got}, 'relative', {k: abs(got[k] - l32[k]) / abs(l32[k]) for k in got})
+    for k, v in got.items():
+        assert v == pytest.approx(l32[k], rel=5e-3), (k, v, l32[k])
+    with torch.no_grad():
+        _, raux = O.fcos_loss([t.detach() for t in aux['cls']], [t.detach() for t in aux['reg']], [t.detach() for t in aux['ctr']],
+                              b['gt_bboxes'], b['gt_labels'], None, return_aux=True)
+    assert torch.equal(plan.lossplan.assign_idx.cpu().long(), raux['assign_idx'])
+    assert torch.equal(plan.lossplan.labels.cpu(), raux['labels'])

@@ -802,8 +802,8 @@ def test_bf16_rounding_bit_patterns(K):
 @pytest.mark.parametrize('flavour', ['bn_relu', 'bias', 'plain', 'mask_last'])
 def test_conv_in_register_epilogue_equals_staged_epilogue(K, force, flavour):
     """Launches without an addend take conv_tile_epilogue's in-register path (scale / bias / ReLU / rounding in the accumulator
-    registers, one bf16 staging round, a last-applied ReLU mask as an AND on the staged words).  The same launch with an addend of
-    zeros takes the staged fp32 path.  Both must produce the same BITS (x + 0 is x, except for the sign of an exact zero), and
+    registers, one bf16 staging round, a last-applied ReLU mask as an AND on the staged words).  The same launch with the test hook
+    CONV_EPI_STAGED takes the general staged fp32 path.  Both must produce the same BITS (the sign of an exact zero aside), and
     both must equal the fp32 reference rounded to bf16 to within one bf16 step."""
     L, ops = K
     N, Ci, Co, H, W, k = 2, 128, 256, 24, 40, 3
@@ -828,9 +828,9 @@ def test_conv_in_register_epilogue_equals_staged_epilogue(K, force, flavour):
     outs = []
     for staged in (False, True):
         y = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device='cuda')
-        extra = dict(addend=torch.zeros(N, H, W, Co, dtype=torch.bfloat16, device='cuda'), lda=Co) if staged else {}
+        kw2 = dict(kw, flags=kw['flags'] | (L.CONV_EPI_STAGED if staged else 0))
         ops.conv2d(nhwc(x), pack_w(w, Co), y, n=N, grid=[(H, W)], src_hw=[(H, W)], dst_hw=[(H, W)], cs=Ci, cd=Co, cd_pad=Co, ldd=Co,
-                   kh=k, kw=k, stride=1, pad=1, **kw, **extra)
+                   kh=k, kw=k, stride=1, pad=1, **kw2)
         sync()
         outs.append(y.cpu())
     a, b = outs[0].view(torch.int16), outs[1].view(torch.int16)
@@ -838,6 +838,114 @@ def test_conv_in_register_epilogue_equals_staged_epilogue(K, force, flavour):
     assert bool(same.all()), int((~same).sum())
     got = from_nhwc(outs[0].cuda())
     assert (got - bf(ref)).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+@pytest.mark.parametrize('force', [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('flavour', ['add', 'bn_add_relu', 'add_mask_last', 'add_wide_rows', 'add_upsample'])
+def test_conv_addend_epilogue_equals_staged_epilogue(K, force, flavour):
+    """Launches WITH an addend on the destination's own pixel grid (the bottlenecks' residual adds forward and backward, the FPN's and
+    the head's gradient sums) take conv_tile_epilogue's addend path: the addend tile is DMA'd into LDS (swizzled dense bf16 rows), added
+    in the accumulator registers (scale, bias, + addend, ReLU, one rounding) and the rounded tile leaves as 16-byte stores; a ReLU
+    mask applied last is an AND on the rounded words.  Same operations in the same order as the staged fp32 path (test hook
+    CONV_EPI_STAGED) => the same BITS, the sign of an exact zero aside; ragged pixel tiles, a padded channel tail (80 of 128 weight
+    rows) and row strides wider than the channel count included."""
+    L, ops = K
+    N, Ci, H, W, k = 2, 128, 23, 37, 3                     # 1 702 pixels: ragged for every pixel tile
+    if flavour == 'add_upsample':                          # the FPN lateral's epilogue: the addend lives on the half-size grid (fpn.py:163-172)
+        H, W = 24, 38
+    Co, cd_pad = (80, 128) if flavour == 'add_wide_rows' else (256, 256)
+    bco = {1: 256, 2: 256, 3: 128, 4: 128, 5: 64, 6: 128, 7: 64, 8: 64}.get(force)
+    if bco and cd_pad % bco:
+        pytest.skip('tile does not divide Cout')
+    ldd, lda, ldm = (Co, Co, Co) if flavour != 'add_wide_rows' else (96, 128, 88)
+    g = torch.Generator().manual_seed(23 + force)
+    x, w = rnd(N, Ci, H, W, g=g), rnd(Co, Ci, k, k, g=g, scale=1 / math.sqrt(Ci * k * k))
+    scale, bias = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    msk, add = rnd(N, Co, H, W, g=g), rnd(N, Co, H, W, g=g)
+
+    def rows(t, ld):          # NCHW fp32 -> [N][H][W][ld] bf16 on the device, the columns beyond the channels poisoned
+        o = torch.full((N, H, W, ld), 777.0, dtype=torch.bfloat16, device='cuda')
+        o[..., :t.shape[1]] = nhwc(t)
+        return o
+    ref = F.conv2d(x, w, None, 1, 1)
+    kw = dict(flags=force << 8, addend=rows(add, lda), lda=lda)
+    if flavour == 'add_upsample':
+        small = rnd(N, Co, H // 2, W // 2, g=g)
+        ref = ref + bias[None, :, None, None] + F.interpolate(small, size=(H, W), mode='nearest')
+        kw = dict(flags=L.CONV_ADD_UPSAMPLE | (force << 8), addend=nhwc(small), lda=Co, add_hw=[(H // 2, W // 2)], bias=bias.cuda())
+    elif flavour == 'bn_add_relu':
+        ref = F.relu(ref * scale[None, :, None, None] + bias[None, :, None, None] + add)
+        kw.update(flags=L.CONV_RELU_OUT | (force << 8), scale=scale.cuda(), bias=bias.cuda())
+    elif flavour in ('add_mask_last', 'add_wide_rows'):
+        ref = (ref + add) * (msk > 0)
+        kw.update(flags=L.CONV_MASK_LAST | (force << 8), mask=rows(msk, ldm), ldm=ldm)
+    else:
+        ref = ref + add
+    outs = []
+    for staged in (False, True):
+        y = torch.full((N, H, W, ldd), 512.0, dtype=torch.bfloat16, device='cuda')
+        kw2 = dict(kw, flags=kw['flags'] | (L.CONV_EPI_STAGED if staged else 0))
+        ops.conv2d(nhwc(x), pack_w(w, cd_pad), y, n=N, grid=[(H, W)], src_hw=[(H, W)], dst_hw=[(H, W)], cs=Ci, cd=Co, cd_pad=cd_pad,
+                   ldd=ldd, kh=k, kw=k, stride=1, pad=1, **kw2)
+        sync()
+        assert ldd == Co or float(y[..., Co:].float().sub(512.0).abs().max()) == 0.0         # columns beyond the channels untouched
+        outs.append(y[..., :Co].contiguous().cpu())
+    a, b = outs[0].view(torch.int16), outs[1].view(torch.int16)
+    same = (a == b) | (((a & 0x7fff) == 0) & ((b & 0x7fff) == 0))          # +0 / -0 aside
+    assert bool(same.all()), int((~same).sum())
+    got = from_nhwc(outs[0].cuda())
+    assert (got - bf(ref)).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+@pytest.mark.parametrize('planes,stride,shape', [(128, 1, (2, 13, 19)), (128, 1, (1, 25, 42)), (128, 2, (2, 14, 18)), (256, 1, (2, 7, 15)),
+                                                 (256, 1, (1, 11, 25)), (256, 2, (2, 6, 13))])
+def test_bottleneck_forward_fused(K, planes, stride, shape):
+    """dsl_bottleneck_fwd (csrc/bneck.hip): a trained bottleneck - conv1 1x1 [/ stride] -> BN -> ReLU -> conv2 3x3 -> BN -> ReLU -> conv3 1x1
+    -> BN -> + identity -> ReLU (resnet.py:262-301) - as ONE launch, against (a) the three dsl_conv2d launches it replaces: a1, a2 and out
+    expected bit for bit (same K order per MFMA chain, same rounding points), and (b) fp32 torch with the intermediates rounded to bf16
+    where the launches store them.  Ragged tiles (sizes that are no multiple of the 12 x 16 / 5 x 12 pixel tiles), both identity kinds
+    (x itself; a separate tensor beside a stride-2 conv1 - a stage's first block)."""
+    L, ops = K
+    N, H, W = shape
+    P, C4 = planes, 4 * planes
+    cin = C4 if stride == 1 else 2 * planes
+    hin, win = (H, W) if stride == 1 else (2 * H, 2 * W - 1)
+    g = torch.Generator().manual_seed(3 * planes + stride + H)
+    x = rnd(N, cin, hin, win, g=g)
+    w1, w2, w3 = rnd(P, cin, 1, 1, g=g, scale=1 / math.sqrt(cin)), rnd(P, P, 3, 3, g=g, scale=1 / math.sqrt(9 * P)), rnd(C4, P, 1, 1, g=g, scale=1 / math.sqrt(P))
+    bns = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3) for c in (P, P, C4)]
+    idt = x if stride == 1 else rnd(N, C4, H, W, g=g)
+    xd, idd = nhwc(x), (None if stride == 1 else nhwc(idt))
+    if stride == 1:
+        idd = xd
+    p1, p2, p3 = pack_w(w1, P), pack_w(w2, P), pack_w(w3, C4)
+    dev = [(s_.cuda(), b_.cuda()) for s_, b_ in bns]
+    # (a) the three launches
+    a1 = torch.empty(N, H, W, P, dtype=torch.bfloat16, device='cuda')
+    a2, out = torch.empty_like(a1), torch.empty(N, H, W, C4, dtype=torch.bfloat16, device='cuda')
+    ops.conv2d(xd, p1, a1, n=N, grid=[(H, W)], src_hw=[(hin, win)], dst_hw=[(H, W)], cs=cin, cd=P, cd_pad=P, ldd=P, kh=1, kw=1, stride=stride, pad=0,
+               flags=L.CONV_RELU_OUT, scale=dev[0][0], bias=dev[0][1])
+    ops.conv2d(a1, p2, a2, n=N, grid=[(H, W)], src_hw=[(H, W)], dst_hw=[(H, W)], cs=P, cd=P, cd_pad=P, ldd=P, kh=3, kw=3, stride=1, pad=1,
+               flags=L.CONV_RELU_OUT, scale=dev[1][0], bias=dev[1][1])
+    ops.conv2d(a2, p3, out, n=N, grid=[(H, W)], src_hw=[(H, W)], dst_hw=[(H, W)], cs=P, cd=C4, cd_pad=C4, ldd=C4, kh=1, kw=1, stride=1, pad=0,
+               flags=L.CONV_RELU_OUT, scale=dev[2][0], bias=dev[2][1], addend=idd, lda=C4)
+    # (b) one launch (poisoned outputs: every element must be written)
+    f1 = torch.full_like(a1, 7.0)
+    f2, fo = torch.full_like(a2, 7.0), torch.full_like(out, 7.0)
+    ops.bottleneck_fwd(xd, p1, p2, p3, idd, (dev[0][0].data_ptr(), dev[0][1].data_ptr()), (dev[1][0].data_ptr(), dev[1][1].data_ptr()),
+                       (dev[2][0].data_ptr(), dev[2][1].data_ptr()), f1, f2, fo, n=N, hin=hin, win=win, h=H, w=W, planes=P, cin=cin, stride=stride)
+    sync()
+    for name, got, want in (('a1', f1, a1), ('a2', f2, a2), ('out', fo, out)):
+        ga, wa = got.cpu().view(torch.int16), want.cpu().view(torch.int16)
+        same = (ga == wa) | (((ga & 0x7fff) == 0) & ((wa & 0x7fff) == 0))
+        assert bool(same.all()), (name, int((~same).sum()), float((got.float() - want.float()).abs().max()))
+    # fp32 reference, intermediates rounded where they are stored
+    bnf = lambda t, k_: t * bns[k_][0][None, :, None, None] + bns[k_][1][None, :, None, None]
+    r1 = bf(F.relu(bnf(F.conv2d(x, w1, None, stride, 0), 0)))
+    r2 = bf(F.relu(bnf(F.conv2d(r1, w2, None, 1, 1), 1)))
+    ro = F.relu(bnf(F.conv2d(r2, w3, None, 1, 0), 2) + idt)
+    go = from_nhwc(fo)
+    assert (go - bf(ro)).abs().max() <= 2 ** -6 * ro.abs().max()
 
 
 # ------------------------------------------------------------------------------------------------
