@@ -49,9 +49,17 @@ struct BnK {
 };
 
 // P: planes (128 = layer2, 256 = layer3); TY x TX: output pixels per workgroup.  512 threads = 8 waves: 4 cout groups x 2 pixel groups.
+//
+// LDS map (160 KB; NS = 3 ring stages everywhere: two K tiles in flight beside the one being multiplied - with one in flight the
+// profile showed 51 - 56 % of the wave cycles parked at the tile-top wait, profiles/r05_bneck_pmc_v2.txt):
+//   phase A      ring of 3 stages [weights P x 128 B | x HPR x 128 B] from offset 0;  P1 (the a1 patch, [HPR][P] bf16) is written at
+//                offset 96 K only in the phase's epilogue, over the then dead third stage
+//   phases B, C  ONE weight ring of 3 stages [P x 128 B] from offset 0 that runs through conv2's 9 P / 64 tiles and on through
+//                conv3's 4 x P / 64 tiles without a bubble;  P2 (the a2 tile, [TPR][P]) between the ring and P1 (layer2) or over the
+//                dead P1 (layer3), written in phase B's epilogue;  S (identity / output staging of a cout block) over the dead P1
 template <int P, int TY, int TX>
 struct Cfg {
-  static constexpr int T = 512, WCO = 4, WPX = 2;
+  static constexpr int T = 512, WCO = 4, WPX = 2, NS = 3;
   static constexpr int C = 4 * P;
   static constexpr int CT = P / (32 * WCO);                  // 32-cout MFMA tiles per wave (1 or 2)
   static constexpr int TP = TY * TX;                         // tile pixels
@@ -65,35 +73,45 @@ struct Cfg {
   static constexpr int ROW = P * 2;                          // bytes per staged row (P1, P2, S)
   static constexpr int WST = P * 128;                        // bytes of one weight stage: [P rows][64 K]
   static constexpr int XST = HPR * 128;                      // ... of one x stage
-  static constexpr int OFF_P1 = 0;
-  static constexpr int OFF_W = HPR * ROW;                    // weight ring (2 stages)
-  static constexpr int OFF_X = OFF_W + 2 * WST;              // x ring (2 stages); P2 lives here after phase A
-  static constexpr int OFF_P2 = OFF_X;
-  static constexpr int OFF_S = OFF_P1;                       // identity / output staging of phase C (P1 is dead by then)
-  static constexpr int LDS = OFF_X + 2 * XST;
-  static_assert(TPR * ROW <= 2 * XST, "P2 fits in the x ring");
-  static_assert(TPR * ROW <= HPR * ROW, "the phase-C staging fits in P1");
-  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static constexpr int AST = WST + XST;                      // phase A stage
+  static constexpr int OFF_P1 = 96 * 1024;
+  static constexpr int OFF_P2 = (NS * WST + TPR * ROW <= OFF_P1) ? NS * WST : OFF_P1;
+  static constexpr int OFF_S = (OFF_P2 == OFF_P1) ? OFF_P1 + TPR * ROW : OFF_P1;
+  static constexpr int LDS = 160 * 1024;
+  static_assert(NS * AST <= LDS && OFF_P1 + HPR * ROW <= LDS, "phase A ring and P1");
+  static_assert(NS * WST <= OFF_P2 || OFF_P2 == OFF_P1, "weight ring below P2");
+  static_assert(NS * WST <= OFF_P1 && OFF_S + TPR * ROW <= LDS && OFF_P2 + TPR * ROW <= (OFF_P2 == OFF_P1 ? OFF_S : OFF_P1), "P2 / S placement");
   static_assert(P % 64 == 0 && (TX == 16 || TX == 12), "patch swizzles are fitted to these widths");
-  // conflict-free patch swizzle for the 3x3's shifted 16-byte fragment reads (tools/variants search: every ds_read_b128 lane group
-  // meets 16 distinct bank quads for all nine taps): slot = chunk ^ f(patch row R, patch column cx)
+  // conflict-free patch swizzle for the 3x3's shifted 16-byte fragment reads (every ds_read_b128 lane group meets 16 distinct bank
+  // quads for all nine taps): slot = chunk ^ f(patch row R, patch column cx)
   __device__ static __forceinline__ int f1(int R, int cx) { return TX == 16 ? (cx & 15) : ((4 * R + 3 * cx) & 15); }
 };
 
-// NMF x { 1 MFMA [, 1 DS read for the first NDS] }: the fragment reads of K step kk + 1 go out between the MFMAs of step kk
-template <int NMF, int NDS>
+// NMF x { 1 MFMA [, 1 DS read for the first NDS] [, 1 VMEM for the first NVM] }: the fragment reads of K step kk + 1 and the DMA pieces
+// of the tile being fetched go out between the MFMAs of step kk
+template <int NMF, int NDS, int NVM>
 __device__ __forceinline__ void sched_mix() {
 #pragma unroll
   for (int i = 0; i < NMF; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if (i < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
   }
+}
+
+// s_waitcnt vmcnt(n) for the handful of counts the tile loops need (an immediate operand)
+template <int A, int B, int C_>
+__device__ __forceinline__ void wait_vm(int n) {
+  if (n >= A + B + C_) wait_vmcnt<A + B + C_>();
+  else if (n >= A + B) wait_vmcnt<A + B>();
+  else if (n >= A) wait_vmcnt<A>();
+  else wait_vmcnt<0>();
 }
 
 template <int P, int TY, int TX>
 __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem) {
   using K = Cfg<P, TY, TX>;
-  constexpr int CT = K::CT, PTA = K::PTA, PTB = K::PTB, PW = K::PW, ROW = K::ROW, NCH = K::NCH, T = K::T;
+  constexpr int CT = K::CT, PTA = K::PTA, PTB = K::PTB, PW = K::PW, ROW = K::ROW, NCH = K::NCH, T = K::T, NS = K::NS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_co = wave >> 1, wave_px = wave & 1;
@@ -107,8 +125,6 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
   const int ty0 = (trem / p.tiles_x) * TY, tx0 = (trem % p.tiles_x) * TX;
 
   unsigned char* const P1 = smem + K::OFF_P1;
-  unsigned char* const WR = smem + K::OFF_W;
-  unsigned char* const XR = smem + K::OFF_X;
   unsigned char* const P2 = smem + K::OFF_P2;
   unsigned char* const S = smem + K::OFF_S;
 
@@ -129,13 +145,10 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
   const int lrow = tid >> 3;
   const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
   constexpr int WPASS = P / 64, XPASS = K::HPR / 64;
-  // weight stage: rows [row0, row0 + P) of a [rows][wrow] bf16 matrix, K tile kt
-  auto dma_w = [&](const __amdgpu_buffer_rsrc_t& rs, int wrow_bytes, int row0, int kt, int slot) {
-#pragma unroll
-    for (int i = 0; i < WPASS; ++i) {
-      const unsigned v = (unsigned)((row0 + i * 64 + lrow) * wrow_bytes + chunk * 16);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(WR + slot * K::WST + (i * 64 + wave * 8) * 128), 16, v, (unsigned)(kt * 128), 0, 0);
-    }
+  // one 64-row piece of a weight stage: rows [row0 + i * 64, + 64) of a [rows][wrow] bf16 matrix, K tile kt -> LDS at `dst`
+  auto dma_w_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int wrow_bytes, int row0, int kt, unsigned char* dst, int i) {
+    const unsigned v = (unsigned)((row0 + i * 64 + lrow) * wrow_bytes + chunk * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + (i * 64 + wave * 8) * 128), 16, v, (unsigned)(kt * 128), 0, 0);
   };
   // x stage: halo pixel j = pass * 64 + lrow -> source pixel (out of the image / beyond the patch: zeros)
   unsigned xoff[XPASS];
@@ -148,10 +161,8 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
     const int pix = (img * p.hin + y * p.stride) * p.win + x * p.stride;
     xoff[i] = ok ? (unsigned)(pix * p.ldx + chunk * 8) * 2u : 0x80000000u;
   }
-  auto dma_x = [&](int kt, int slot) {
-#pragma unroll
-    for (int i = 0; i < XPASS; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(XR + slot * K::XST + (i * 64 + wave * 8) * 128), 16, xoff[i], (unsigned)(kt * 128), 0, 0);
+  auto dma_x_piece = [&](int kt, unsigned char* dst, int i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(dst + (i * 64 + wave * 8) * 128), 16, xoff[i], (unsigned)(kt * 128), 0, 0);
   };
   // The tile's own pixels as 16-byte store items: item id -> (tile pixel t, chunk c); every thread issues the SAME number of store
   // instructions (out-of-range offsets drop the surplus), so the vmcnt bookkeeping around the stores is a compile-time constant
@@ -169,14 +180,22 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
     sto_c[i] = c;
     sto_pix[i] = ok ? (unsigned)((img * p.h + y) * p.w + x) : 0x80000000u;
   }
+  u32x4 sto_r[NSTO];                               // staged rows on their way to memory: read from LDS at the end of a phase, stored at the
+                                                   // next tile top (a clean point of the vmcnt ledger, see the tile loops)
+  auto store_rows = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned ld, unsigned col0) {
+#pragma unroll
+    for (int i = 0; i < NSTO; ++i) {
+      const unsigned v = sto_pix[i] == 0x80000000u ? 0x80000000u : (sto_pix[i] * ld + col0 + (unsigned)sto_c[i] * 8u) * 2u;
+      __builtin_amdgcn_raw_buffer_store_b128(sto_r[i], rs, v, 0, 0);
+    }
+  };
 
   // ---- fragment helpers (two register sets: the reads of K step kk + 1 fly during the MFMAs of step kk)
   bf16x8 fa[2][CT];
-  auto read_a = [&](int slot, int kk, int f) {
+  auto read_a = [&](const unsigned char* wst, int kk, int f) {
     const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-      fa[f][ct] = *reinterpret_cast<const bf16x8*>(WR + slot * K::WST + (wave_co * (32 * CT) + ct * 32 + frow) * 128 + coff);
+    for (int ct = 0; ct < CT; ++ct) fa[f][ct] = *reinterpret_cast<const bf16x8*>(wst + (wave_co * (32 * CT) + ct * 32 + frow) * 128 + coff);
   };
 
   // =================================================================================================================
@@ -192,43 +211,57 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
         for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
     const int KT = p.cin >> 6;
     const int wrow = p.cin * 2;
+    constexpr int LPT = WPASS + XPASS;
     bf16x8 fb[2][PTA];
-    auto read_b = [&](int slot, int kk, int f) {
-      const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
-#pragma unroll
-      for (int pt = 0; pt < PTA; ++pt)
-        fb[f][pt] = *reinterpret_cast<const bf16x8*>(XR + slot * K::XST + ((wave_px * PTA + pt) * 32 + frow) * 128 + coff);
+    auto piece = [&](int kt, int i) {               // piece i of tile kt's stage (weights first)
+      unsigned char* st = smem + (kt % NS) * K::AST;
+      if (i < WPASS) dma_w_piece(rs_w1, wrow, 0, kt, st, i);
+      else dma_x_piece(kt, st + K::WST, i - WPASS);
     };
-    dma_w(rs_w1, wrow, 0, 0, 0);
-    dma_x(0, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-      const int slot = kt & 1;
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();               // tile kt has landed for every wave; everyone is done reading the other slot
-      if (kt + 1 < KT) {
-        dma_w(rs_w1, wrow, 0, kt + 1, slot ^ 1);
-        dma_x(kt + 1, slot ^ 1);
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+      if (s_ < KT) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) piece(s_, i);
       }
-      read_a(slot, 0, 0);
-      read_b(slot, 0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+      const unsigned char* st = smem + (kt % NS) * K::AST;
+      // tile kt has landed; up to NS - 2 later tiles may stay in flight
+      wait_vm<LPT, 0, 0>(min(NS - 2, KT - 1 - kt) * LPT);
+      __builtin_amdgcn_s_barrier();               // ... for every wave; everyone is done reading the stage tile kt + NS - 1 goes to
+      const bool more = kt + NS - 1 < KT;
+      auto rd = [&](int kk, int f) {
+        read_a(st, kk, f);
+        const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
+#pragma unroll
+        for (int pt = 0; pt < PTA; ++pt)
+          fb[f][pt] = *reinterpret_cast<const bf16x8*>(st + K::WST + ((wave_px * PTA + pt) * 32 + frow) * 128 + coff);
+      };
+      rd(0, 0);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int f = kk & 1;
-        if (kk < 3) {
-          read_a(slot, kk + 1, f ^ 1);
-          read_b(slot, kk + 1, f ^ 1);
+        if (kk < 3) rd(kk + 1, f ^ 1);
+        // the fetched tile's DMA pieces, two per K step
+        constexpr int PPK = (LPT + 2) / 3;
+        if (more && kk < 3) {
+#pragma unroll
+          for (int i = kk * PPK; i < (kk + 1) * PPK && i < LPT; ++i) piece(kt + NS - 1, i);
         }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int pt = 0; pt < PTA; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
-        if (kk < 3) sched_mix<CT * PTA, CT + PTA>();
+        if (kk < 3) sched_mix<CT * PTA, CT + PTA, PPK>();
       }
     }
-    lds_barrier();                                 // every wave is through its last fragments: both weight slots are free
-    // conv2's first two weight tiles fly during the epilogue and the a1 stores
-    dma_w(rs_w2, 9 * P * 2, 0, 0, 0);
-    dma_w(rs_w2, 9 * P * 2, 0, 1, 1);
+    wait_vmcnt<0>();
+    lds_barrier();                                 // every wave is through its last fragments: the ring is free, P1 may be written
+    // conv2's first two weight tiles fly during the epilogue
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+#pragma unroll
+      for (int i = 0; i < WPASS; ++i) dma_w_piece(rs_w2, 9 * P * 2, 0, s_, smem + s_ * K::WST, i);
     // epilogue A: scale, bias, ReLU, round -> P1[halo row][cout] (zero outside the image: conv2's padding)
 #pragma unroll
     for (int pt = 0; pt < PTA; ++pt) {
@@ -255,20 +288,37 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
         }
     }
     lds_barrier();
-    // a1 (the tile's own pixels) -> global, 16 bytes per item
+    // a1 (the tile's own pixels): rows into registers now, to memory at phase B's first tile top
 #pragma unroll
     for (int i = 0; i < NSTO; ++i) {
       const int t = sto_t[i], c = sto_c[i];
       const int py = t / TX, px = t - py * TX;
-      const u32x4 r = *reinterpret_cast<const u32x4*>(P1 + ((py + 1) * PW + px + 1) * ROW + ((c ^ K::f1(py + 1, px + 1)) << 4));
-      const unsigned v = sto_pix[i] == 0x80000000u ? 0x80000000u : (sto_pix[i] * (unsigned)P + (unsigned)c * 8u) * 2u;
-      __builtin_amdgcn_raw_buffer_store_b128(r, rs_a1, v, 0, 0);
+      sto_r[i] = *reinterpret_cast<const u32x4*>(P1 + ((py + 1) * PW + px + 1) * ROW + ((c ^ K::f1(py + 1, px + 1)) << 4));
     }
   }
 
   // =================================================================================================================
-  // Phase B: a2 = relu(bn2(W2 * a1)), nine taps out of P1; GEMM [P couts] x [TPR tile pixels] x [9 P]
+  // Phases B and C share ONE weight-tile stream: q = 0 .. QB - 1 conv2's tiles (tap-major, then channel blocks), then conv3's
+  // (cout block, K tile).  Tile q sits in ring stage q % NS; at tile q's top tile q + NS - 1 is issued (one 64-row piece per K step).
+  // vmcnt ledger: besides the weight tiles a thread issues its row stores (NSTO) and the identity DMA (SDMA) - always at a tile top,
+  // right behind the wait and the barrier, in front of the fetched tile's pieces: the NEXT tile top then waits for a tile that is
+  // older than them and allows them to be outstanding (+ X), every later one waits for a tile that is younger (they are done).
   // =================================================================================================================
+  constexpr int KCB = P / 64;                      // K tiles per tap (conv2) and per cout block (conv3)
+  constexpr int QB = 9 * KCB, QC = 4 * KCB, QT = QB + QC;
+  constexpr int SDMA = K::TPR * ROW / (T * 16);    // identity DMA instructions per wave and cout block
+  static_assert((K::TPR * ROW) % (T * 16) == 0, "whole DMA instructions per wave");
+  static_assert(WPASS <= 4, "one weight piece per K step");
+  auto wpiece = [&](int q, int i) {
+    unsigned char* st = smem + (q % NS) * K::WST;
+    if (q < QB) dma_w_piece(rs_w2, 9 * P * 2, 0, q, st, i);
+    else {
+      const int qq = q - QB, blk = qq / KCB;
+      dma_w_piece(rs_w3, P * 2, blk * P, qq - blk * KCB, st, i);
+    }
+  };
+  int xprev = 0;                                   // non-tile VMEM instructions issued at the previous tile top
+  // one weight tile's K steps: B fragments through `rdb(kk, f)`, accumulating into acc
   int tpy[PTB], tpx[PTB];                          // this lane's tile pixels (phases B, C): row / column inside the tile
 #pragma unroll
   for (int pt = 0; pt < PTB; ++pt) {
@@ -277,18 +327,23 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
     tpy[pt] = t / TX;
     tpx[pt] = t - tpy[pt] * TX;
   }
+  f32x16 acc[CT][PTB];
+  bf16x8 fb[2][PTB];
+  auto tile_top = [&](int q) {                     // wait for tile q, barrier; returns with the ledger clean
+    const int fly = min(NS - 2, QT - 1 - q) * WPASS;
+    wait_vm<WPASS, NSTO, SDMA>(fly + xprev);
+    lds_barrier();                                 // (lgkmcnt too: a thread's staged-row reads of S / P2 are complete before anyone's DMA refills S)
+    xprev = 0;
+  };
+  // ---------------- Phase B: a2 = relu(bn2(W2 * a1)), nine taps out of P1; GEMM [P couts] x [TPR tile pixels] x [9 P]
   {
-    f32x16 acc[CT][PTB];
 #pragma unroll
     for (int a = 0; a < CT; ++a)
 #pragma unroll
       for (int b = 0; b < PTB; ++b)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
-    constexpr int KC = P / 64;                     // K tiles per tap
-    constexpr int KT = 9 * KC;
-    bf16x8 fb[2][PTB];
-    int kt = 0;
+    int q = 0;
     for (int tap = 0; tap < 9; ++tap) {
       const int tap_r = tap / 3, tap_s = tap - tap_r * 3;
       unsigned pb[PTB], psw[PTB];                  // this tap's patch row base and swizzle of the lane's pixels
@@ -298,42 +353,35 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
         pb[pt] = (unsigned)((R * PW + cx) * ROW);
         psw[pt] = (unsigned)(K::f1(R, cx) << 4);
       }
-      for (int cb = 0; cb < KC; ++cb, ++kt) {
-        const int slot = kt & 1;
-        auto read_b = [&](int kk, int f) {
+      for (int cb = 0; cb < KCB; ++cb, ++q) {
+        const unsigned char* st = smem + (q % NS) * K::WST;
+        tile_top(q);
+        if (q == 0) {                              // a1 leaves for memory (rows read from P1 at the end of phase A)
+          store_rows(rs_a1, (unsigned)P, 0u);
+          xprev = NSTO;
+        }
+        const bool more = q + NS - 1 < QT;
+        auto rd = [&](int kk, int f) {
+          read_a(st, kk, f);
           const unsigned ch = (unsigned)((cb * 8 + 2 * kk + fhalf) << 4);
 #pragma unroll
           for (int pt = 0; pt < PTB; ++pt) fb[f][pt] = *reinterpret_cast<const bf16x8*>(P1 + pb[pt] + (ch ^ psw[pt]));
         };
-        // tile kt has landed: tiles 0, 1 were issued in front of the a1 stores (which may still be in flight: counted), every later
-        // tile behind them
-        if (kt == 0) wait_vmcnt<NSTO + WPASS>();
-        else if (kt == 1) wait_vmcnt<NSTO>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt >= 1 && kt + 1 < KT) dma_w(rs_w2, 9 * P * 2, 0, kt + 1, slot ^ 1);
-        read_a(slot, 0, 0);
-        read_b(0, 0);
+        rd(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int f = kk & 1;
-          if (kk < 3) {
-            read_a(slot, kk + 1, f ^ 1);
-            read_b(kk + 1, f ^ 1);
-          }
+          if (kk < 3) rd(kk + 1, f ^ 1);
+          if (more && kk < WPASS) wpiece(q + NS - 1, kk);
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int pt = 0; pt < PTB; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
-          if (kk < 3) sched_mix<CT * PTB, CT + PTB>();
+          if (kk < 3) sched_mix<CT * PTB, CT + PTB, 1>();
         }
       }
     }
-    lds_barrier();
-    // conv3's first two weight tiles (cout block 0) fly during the epilogue and the a2 stores
-    constexpr int KC3 = P / 64;
-    dma_w(rs_w3, P * 2, 0, 0, 0);
-    dma_w(rs_w3, P * 2, KC3 > 1 ? 0 : P, KC3 > 1 ? 1 : 0, 1);
+    lds_barrier();                                 // every wave is through P1: P2 (layer3: over P1) may be written
     // epilogue B -> P2[tile pixel][cout] (slot = chunk ^ (row & 15))
 #pragma unroll
     for (int pt = 0; pt < PTB; ++pt) {
@@ -356,20 +404,11 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
 #pragma unroll
     for (int i = 0; i < NSTO; ++i) {
       const int t = sto_t[i], c = sto_c[i];
-      const u32x4 r = *reinterpret_cast<const u32x4*>(P2 + t * ROW + ((c ^ (t & 15)) << 4));
-      const unsigned v = sto_pix[i] == 0x80000000u ? 0x80000000u : (sto_pix[i] * (unsigned)P + (unsigned)c * 8u) * 2u;
-      __builtin_amdgcn_raw_buffer_store_b128(r, rs_a2, v, 0, 0);
+      sto_r[i] = *reinterpret_cast<const u32x4*>(P2 + t * ROW + ((c ^ (t & 15)) << 4));
     }
   }
-
-  // =================================================================================================================
-  // Phase C: out = relu(bn3(W3 . a2) + identity), four cout blocks of P; GEMM [P couts] x [TPR] x [P] per block
-  // =================================================================================================================
+  // ---------------- Phase C: out = relu(bn3(W3 . a2) + identity), four cout blocks of P; GEMM [P couts] x [TPR] x [P] per block
   {
-    constexpr int KC = P / 64;                     // K tiles per cout block
-    constexpr int NB = 4;
-    constexpr int SDMA = K::TPR * ROW / (T * 16);   // identity DMA instructions per wave and block
-    static_assert((K::TPR * ROW) % (T * 16) == 0, "whole DMA instructions per wave");
     unsigned idoff[SDMA];                          // this lane's identity source offsets (without the cout block), or 0x80000000
 #pragma unroll
     for (int i = 0; i < SDMA; ++i) {
@@ -386,55 +425,50 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
       for (int i = 0; i < SDMA; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_id, (lptr_t)(S + (i * 8 + wave) * 1024), 16, idoff[i], (unsigned)(blk * P * 2), 0, 0);
     };
-    f32x16 acc[CT][PTB];
-    bf16x8 fb[2][PTB];
-    auto read_b = [&](int k, int kk, int f) {
-#pragma unroll
-      for (int pt = 0; pt < PTB; ++pt) {
-        const int row = (wave_px * PTB + pt) * 32 + frow;
-        fb[f][pt] = *reinterpret_cast<const bf16x8*>(P2 + row * ROW + (((k * 8 + 2 * kk + fhalf) ^ (row & 15)) << 4));
-      }
-    };
-    // vmcnt ledger (per thread, in issue order): ... w3 tile 0, w3 tile 1, a2 stores [NSTO]; then per block: identity [SDMA] at its first
-    // tile, weight tiles one ahead, out stores [NSTO] at its end.  `pend` = instructions issued after the weight tile being waited for.
-    for (int blk = 0; blk < NB; ++blk) {
+    for (int blk = 0; blk < 4; ++blk) {
 #pragma unroll
       for (int a = 0; a < CT; ++a)
 #pragma unroll
         for (int b = 0; b < PTB; ++b)
 #pragma unroll
           for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
-      for (int k = 0; k < KC; ++k) {
-        const int kt = blk * KC + k;
-        const int slot = kt & 1;
-        if (kt == 0) wait_vmcnt<NSTO + WPASS>();   // tile 0 landed (tile 1 and the a2 stores may still fly)
-        else if (kt == 1) wait_vmcnt<NSTO + SDMA>();   // tile 1 landed (issued before the a2 stores; block 0's identity DMA came later)
-        else if (k == 0) wait_vmcnt<NSTO>();        // a later block's first tile was issued in front of the previous block's out stores
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (k == 0) dma_idt(blk);                   // S is free: the previous block's store loop is behind this barrier (P1's last readers too)
-        if (kt >= 1 && kt + 1 < NB * KC) {
-          const int nb_ = (kt + 1) / KC, nk_ = (kt + 1) - nb_ * KC;
-          dma_w(rs_w3, P * 2, nb_ * P, nk_, slot ^ 1);
+      for (int k = 0; k < KCB; ++k) {
+        const int q = QB + blk * KCB + k;
+        const unsigned char* st = smem + (q % NS) * K::WST;
+        tile_top(q);
+        if (k == 0) {
+          // the previous phase's / block's rows leave for memory (they sit in registers: S is free for this block's identity - the
+          // barrier above is behind every thread's reads of it)
+          if (blk == 0) store_rows(rs_a2, (unsigned)P, 0u);
+          else store_rows(rs_out, (unsigned)p.ldo, (unsigned)((blk - 1) * P));
+          dma_idt(blk);
+          xprev = NSTO + SDMA;
         }
-        read_a(slot, 0, 0);
-        read_b(k, 0, 0);
+        const bool more = q + NS - 1 < QT;
+        auto rd = [&](int kk, int f) {
+          read_a(st, kk, f);
+#pragma unroll
+          for (int pt = 0; pt < PTB; ++pt) {
+            const int row = (wave_px * PTB + pt) * 32 + frow;
+            fb[f][pt] = *reinterpret_cast<const bf16x8*>(P2 + row * ROW + (((k * 8 + 2 * kk + fhalf) ^ (row & 15)) << 4));
+          }
+        };
+        rd(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int f = kk & 1;
-          if (kk < 3) {
-            read_a(slot, kk + 1, f ^ 1);
-            read_b(k, kk + 1, f ^ 1);
-          }
+          if (kk < 3) rd(kk + 1, f ^ 1);
+          if (more && kk < WPASS) wpiece(q + NS - 1, kk);
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int pt = 0; pt < PTB; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
-          if (kk < 3) sched_mix<CT * PTB, CT + PTB>();
+          if (kk < 3) sched_mix<CT * PTB, CT + PTB, 1>();
         }
       }
-      // epilogue C of this block: the identity tile must have landed in S; the next block's first weight tile (issued after it) may fly on
-      if (blk + 1 < NB) wait_vmcnt<WPASS>(); else wait_vmcnt<0>();
+      // epilogue C of this block: the identity tile must have landed in S.  It was issued at the block's first tile top, in front of
+      // that top's fetched tile: every weight tile still in flight is younger - at most NS - 1 of them (fewer at the very end)
+      wait_vm<WPASS, WPASS, 0>(min(NS - 1, QT - 1 - (QB + blk * KCB + KCB - 1)) * WPASS);
       lds_barrier();
 #pragma unroll
       for (int pt = 0; pt < PTB; ++pt) {
@@ -460,11 +494,10 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
 #pragma unroll
       for (int i = 0; i < NSTO; ++i) {
         const int t = sto_t[i], c = sto_c[i];
-        const u32x4 r = *reinterpret_cast<const u32x4*>(S + t * ROW + ((c ^ (t & 15)) << 4));
-        const unsigned v = sto_pix[i] == 0x80000000u ? 0x80000000u : (sto_pix[i] * (unsigned)p.ldo + (unsigned)(blk * P + c * 8)) * 2u;
-        __builtin_amdgcn_raw_buffer_store_b128(r, rs_out, v, 0, 0);
+        sto_r[i] = *reinterpret_cast<const u32x4*>(S + t * ROW + ((c ^ (t & 15)) << 4));
       }
     }
+    store_rows(rs_out, (unsigned)p.ldo, (unsigned)(3 * P));
   }
 }
 
