@@ -477,10 +477,11 @@ def main():
     roof = None
     # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is the
     # committed result of the separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
-    traffic = traffic_src = None
+    traffic = traffic_src = step_traffic = None
     tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic.json')
     if os.path.exists(tf):
         tj = json.load(open(tf))
+        step_traffic = tj.get('step')          # whole-step HBM bytes (sum over every kernel of the PMC passes) and the floor they imply
         hit = [k for k in tj.get('kernels', {}) if k.startswith(DOMINANT[:-1])]     # the symbol carries further template args
         if hit:
             traffic = tj['kernels'][hit[0]]['hbm_bytes_per_launch']
@@ -525,7 +526,10 @@ def main():
                         'tile: the backbone / predictor convolutions; largest share of the step)',
                         achieved=round(gbs if hbm else ach, 1), peak=PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS,
                         unit='GB/s' if hbm else 'TFLOP/s', frac=round(gbs / PEAK_HBM_GBS if hbm else ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, traffic_source=traffic_src, measured='HIP event pairs on the launch stream, second pass '
+                        traffic=traffic, traffic_source=traffic_src,
+                        hbm_bytes_per_step=(step_traffic or {}).get('hbm_bytes_per_step'),
+                        hbm_floor_ms=(step_traffic or {}).get('hbm_floor_ms_at_8TBs'),
+                        hbm_floor_ms_at_measured_6p3TBs=(step_traffic or {}).get('hbm_floor_ms_at_6p3TBs'), measured='HIP event pairs on the launch stream, second pass '
                         'of the same %d steps (%.3f ms/step while instrumented)' % (args.steps, dt_prof / args.steps * 1e3),
                         launches_per_step=launches[0] // args.steps,
                         avg_launch_us=round(ms[0] * 1e3 / launches[0], 2),

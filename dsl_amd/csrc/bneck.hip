@@ -46,6 +46,7 @@ struct BnK {
   int cin, ldx, stride;           // conv1 reads `cin` channels of rows of ldx elements at pixel stride `stride`
   int ldi, ldo;                   // row strides of identity / out (elements)
   int tiles_y, tiles_x, ntiles, xcd_chunk;
+  int dbg;                        // timing probe (option bneck_dbg; results are wrong): 1 = stop behind phase A, 2 = behind phase B
 };
 
 // P: planes (128 = layer2, 256 = layer3); TY x TX: output pixels per workgroup.  512 threads = 8 waves: 4 cout groups x 2 pixel groups.
@@ -167,31 +168,33 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
   // The tile's own pixels as 16-byte store items: item id -> (tile pixel t, chunk c); every thread issues the SAME number of store
   // instructions (out-of-range offsets drop the surplus), so the vmcnt bookkeeping around the stores is a compile-time constant
   constexpr int NSTO = (K::TP * NCH + T - 1) / T;
-  unsigned sto_pix[NSTO];                          // pixel index (img, y, x) of the item's row, or 0x80000000
-  int sto_t[NSTO], sto_c[NSTO];
-#pragma unroll
-  for (int i = 0; i < NSTO; ++i) {
+  // (item -> pixel decoded where it is used: a handful of integer operations per item and phase instead of 3 x NSTO registers held
+  // through the K loops)
+  auto sto_item = [&](int i, int& t, int& c, unsigned& pix) {
     const int id = tid + i * T;
-    const int t = id / NCH, c = id - t * NCH;
+    t = id / NCH;
+    c = id - t * NCH;
     const int py = t / TX, px = t - py * TX;
     const int y = ty0 + py, x = tx0 + px;
     const bool ok = id < K::TP * NCH && y < p.h && x < p.w;
-    sto_t[i] = ok ? t : 0;
-    sto_c[i] = c;
-    sto_pix[i] = ok ? (unsigned)((img * p.h + y) * p.w + x) : 0x80000000u;
-  }
+    pix = ok ? (unsigned)((img * p.h + y) * p.w + x) : 0x80000000u;
+    if (!ok) t = 0;
+  };
   u32x4 sto_r[NSTO];                               // staged rows on their way to memory: read from LDS at the end of a phase, stored at the
-                                                   // next tile top (a clean point of the vmcnt ledger, see the tile loops)
+                                                   // next sync point (a clean point of the vmcnt ledger, see the tile loops)
   auto store_rows = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned ld, unsigned col0) {
 #pragma unroll
     for (int i = 0; i < NSTO; ++i) {
-      const unsigned v = sto_pix[i] == 0x80000000u ? 0x80000000u : (sto_pix[i] * ld + col0 + (unsigned)sto_c[i] * 8u) * 2u;
+      int t, c;
+      unsigned pix;
+      sto_item(i, t, c, pix);
+      const unsigned v = pix == 0x80000000u ? 0x80000000u : (pix * ld + col0 + (unsigned)c * 8u) * 2u;
       __builtin_amdgcn_raw_buffer_store_b128(sto_r[i], rs, v, 0, 0);
     }
   };
 
   // ---- fragment helpers (two register sets: the reads of K step kk + 1 fly during the MFMAs of step kk)
-  bf16x8 fa[2][CT];
+  bf16x8 fa[4][CT];                                // one fragment set per K step of a tile: the reads run HALF A TILE ahead of the MFMAs
   auto read_a = [&](const unsigned char* wst, int kk, int f) {
     const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
 #pragma unroll
@@ -212,7 +215,7 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
     const int KT = p.cin >> 6;
     const int wrow = p.cin * 2;
     constexpr int LPT = WPASS + XPASS;
-    bf16x8 fb[2][PTA];
+    bf16x8 fb[4][PTA];
     auto piece = [&](int kt, int i) {               // piece i of tile kt's stage (weights first)
       unsigned char* st = smem + (kt % NS) * K::AST;
       if (i < WPASS) dma_w_piece(rs_w1, wrow, 0, kt, st, i);
@@ -224,36 +227,50 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
 #pragma unroll
         for (int i = 0; i < LPT; ++i) piece(s_, i);
       }
-    for (int kt = 0; kt < KT; ++kt) {
+    auto rd = [&](int kt, int kk, int f) {
       const unsigned char* st = smem + (kt % NS) * K::AST;
-      // tile kt has landed; up to NS - 2 later tiles may stay in flight
-      wait_vm<LPT, 0, 0>(min(NS - 2, KT - 1 - kt) * LPT);
-      __builtin_amdgcn_s_barrier();               // ... for every wave; everyone is done reading the stage tile kt + NS - 1 goes to
+      read_a(st, kk, f);
+      const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
+#pragma unroll
+      for (int pt = 0; pt < PTA; ++pt)
+        fb[f][pt] = *reinterpret_cast<const bf16x8*>(st + K::WST + ((wave_px * PTA + pt) * 32 + frow) * 128 + coff);
+    };
+    auto mma = [&](int f) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PTA; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
+    };
+    // Software pipeline (conv_pipe_kernel's): the tile's single barrier sits in front of its LAST K step's MFMAs, whose fragments are in
+    // registers by then; behind it the next tile has landed for every wave, its first fragments are requested at once and fly while
+    // those MFMAs run - the matrix pipe does not drain at the tile boundary.
+    // (a K step of this kernel is only CT x PT = 3 - 4 MFMAs per wave: with the reads ONE step ahead every step waited for its LDS
+    // latency - 1 700 - 1 900 cycles per tile against 770 - 1 020 of MFMA, profiles/r05_bneck_micro_v4.txt; half a tile ahead they are
+    // covered by 6 - 8 MFMAs of the wave and as many of its SIMD partner)
+    wait_vm<LPT, 0, 0>(min(NS - 2, KT - 1) * LPT);
+    lds_barrier();
+    rd(0, 0, 0);
+    rd(0, 1, 1);
+    for (int kt = 0; kt < KT; ++kt) {
       const bool more = kt + NS - 1 < KT;
-      auto rd = [&](int kk, int f) {
-        read_a(st, kk, f);
-        const int coff = ((2 * kk + fhalf) ^ fswz) << 4;
+      rd(kt, 2, 2);
+      rd(kt, 3, 3);
+      if (more) {                                  // the fetched tile's DMA pieces: all out before the wait below
 #pragma unroll
-        for (int pt = 0; pt < PTA; ++pt)
-          fb[f][pt] = *reinterpret_cast<const bf16x8*>(st + K::WST + ((wave_px * PTA + pt) * 32 + frow) * 128 + coff);
-      };
-      rd(0, 0);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int f = kk & 1;
-        if (kk < 3) rd(kk + 1, f ^ 1);
-        // the fetched tile's DMA pieces, two per K step
-        constexpr int PPK = (LPT + 2) / 3;
-        if (more && kk < 3) {
-#pragma unroll
-          for (int i = kk * PPK; i < (kk + 1) * PPK && i < LPT; ++i) piece(kt + NS - 1, i);
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-          for (int pt = 0; pt < PTA; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
-        if (kk < 3) sched_mix<CT * PTA, CT + PTA, PPK>();
+        for (int i = 0; i < LPT; ++i) piece(kt + NS - 1, i);
       }
+      mma(0);
+      mma(1);
+      sched_mix<2 * CT * PTA, 2 * (CT + PTA), LPT>();
+      if (kt + 1 < KT) {
+        wait_vm<LPT, 0, 0>(min(NS - 2, KT - 2 - kt) * LPT);      // tile kt + 1 has landed (this thread's pieces) ...
+        lds_barrier();                                           // ... everyone's; and everyone holds tile kt's last fragments: its stage is free
+        rd(kt + 1, 0, 0);
+        rd(kt + 1, 1, 1);
+      }
+      mma(2);
+      mma(3);
+      sched_mix<2 * CT * PTA, 2 * (CT + PTA), 0>();
     }
     wait_vmcnt<0>();
     lds_barrier();                                 // every wave is through its last fragments: the ring is free, P1 may be written
@@ -263,39 +280,49 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
 #pragma unroll
       for (int i = 0; i < WPASS; ++i) dma_w_piece(rs_w2, 9 * P * 2, 0, s_, smem + s_ * K::WST, i);
     // epilogue A: scale, bias, ReLU, round -> P1[halo row][cout] (zero outside the image: conv2's padding)
+    // (cout group outermost: a lane keeps ONE group's scale / bias at a time - all of them at once cost 64 registers at P = 256)
+    int jrow[PTA], jsw[PTA];
+    bool jok[PTA];
 #pragma unroll
     for (int pt = 0; pt < PTA; ++pt) {
       const int j = (wave_px * PTA + pt) * 32 + frow;
       const int hy = j / PW, hx = j - hy * PW;
       const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-      const bool ok = j < K::HP && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
-      const int sw = K::f1(hy, hx);
+      jrow[pt] = j;
+      jok[pt] = j < K::HP && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
+      jsw[pt] = K::f1(hy, hx);
+    }
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s1 + col);
-          const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b1 + col);
+      for (int g = 0; g < 4; ++g) {
+        const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s1 + col);
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b1 + col);
+#pragma unroll
+        for (int pt = 0; pt < PTA; ++pt) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[e] = fmaxf(add_nc(mul_nc(acc[ct][pt][4 * g + e], sc[e]), bi[e]), 0.f);
-            if (!ok) v[e] = 0.f;
+            if (!jok[pt]) v[e] = 0.f;
           }
           const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(P1 + j * ROW + ((((col >> 3) ^ sw) << 4) | (fhalf << 3))) = o;
+          *reinterpret_cast<u32x2*>(P1 + jrow[pt] * ROW + ((((col >> 3) ^ jsw[pt]) << 4) | (fhalf << 3))) = o;
         }
-    }
+      }
     lds_barrier();
     // a1 (the tile's own pixels): rows into registers now, to memory at phase B's first tile top
 #pragma unroll
     for (int i = 0; i < NSTO; ++i) {
-      const int t = sto_t[i], c = sto_c[i];
+      int t, c;
+      unsigned pix;
+      sto_item(i, t, c, pix);
       const int py = t / TX, px = t - py * TX;
       sto_r[i] = *reinterpret_cast<const u32x4*>(P1 + ((py + 1) * PW + px + 1) * ROW + ((c ^ K::f1(py + 1, px + 1)) << 4));
     }
   }
+  if (p.dbg == 1) { wait_vmcnt<0>(); return; }
 
   // =================================================================================================================
   // Phases B and C share ONE weight-tile stream: q = 0 .. QB - 1 conv2's tiles (tap-major, then channel blocks), then conv3's
@@ -317,8 +344,7 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
       dma_w_piece(rs_w3, P * 2, blk * P, qq - blk * KCB, st, i);
     }
   };
-  int xprev = 0;                                   // non-tile VMEM instructions issued at the previous tile top
-  // one weight tile's K steps: B fragments through `rdb(kk, f)`, accumulating into acc
+  int xprev = 0;                                   // non-tile VMEM instructions issued at the previous sync point
   int tpy[PTB], tpx[PTB];                          // this lane's tile pixels (phases B, C): row / column inside the tile
 #pragma unroll
   for (int pt = 0; pt < PTB; ++pt) {
@@ -328,84 +354,111 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
     tpx[pt] = t - tpy[pt] * TX;
   }
   f32x16 acc[CT][PTB];
-  bf16x8 fb[2][PTB];
-  auto tile_top = [&](int q) {                     // wait for tile q, barrier; returns with the ledger clean
-    const int fly = min(NS - 2, QT - 1 - q) * WPASS;
-    wait_vm<WPASS, NSTO, SDMA>(fly + xprev);
-    lds_barrier();                                 // (lgkmcnt too: a thread's staged-row reads of S / P2 are complete before anyone's DMA refills S)
-    xprev = 0;
-  };
-  // ---------------- Phase B: a2 = relu(bn2(W2 * a1)), nine taps out of P1; GEMM [P couts] x [TPR tile pixels] x [9 P]
-  {
+  bf16x8 fb[4][PTB];
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int a = 0; a < CT; ++a)
 #pragma unroll
       for (int b = 0; b < PTB; ++b)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
-    int q = 0;
-    for (int tap = 0; tap < 9; ++tap) {
-      const int tap_r = tap / 3, tap_s = tap - tap_r * 3;
-      unsigned pb[PTB], psw[PTB];                  // this tap's patch row base and swizzle of the lane's pixels
+  };
+  auto mma = [&](int f) {
 #pragma unroll
-      for (int pt = 0; pt < PTB; ++pt) {
-        const int R = tpy[pt] + tap_r, cx = tpx[pt] + tap_s;
-        pb[pt] = (unsigned)((R * PW + cx) * ROW);
-        psw[pt] = (unsigned)(K::f1(R, cx) << 4);
-      }
-      for (int cb = 0; cb < KCB; ++cb, ++q) {
-        const unsigned char* st = smem + (q % NS) * K::WST;
-        tile_top(q);
-        if (q == 0) {                              // a1 leaves for memory (rows read from P1 at the end of phase A)
-          store_rows(rs_a1, (unsigned)P, 0u);
-          xprev = NSTO;
-        }
-        const bool more = q + NS - 1 < QT;
-        auto rd = [&](int kk, int f) {
-          read_a(st, kk, f);
-          const unsigned ch = (unsigned)((cb * 8 + 2 * kk + fhalf) << 4);
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-          for (int pt = 0; pt < PTB; ++pt) fb[f][pt] = *reinterpret_cast<const bf16x8*>(P1 + pb[pt] + (ch ^ psw[pt]));
-        };
-        rd(0, 0);
+      for (int pt = 0; pt < PTB; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
+  };
+  // sync point in front of tile q: tile q has landed for every wave, every wave holds the previous tile's last fragments (its stage is
+  // free) and has finished whatever it read from P2 / S; the ledger is clean behind it
+  auto sync_for = [&](int q) {
+    const int fly = min(NS - 2, QT - 1 - q) * WPASS;
+    wait_vm<WPASS, NSTO, SDMA>(fly + xprev);
+    lds_barrier();
+    xprev = 0;
+  };
+  unsigned pb[PTB], psw[PTB];                      // conv2: patch row base and swizzle of the lane's pixels for the tap being READ
+  auto set_tap = [&](int tap) {
+    const int tap_r = tap / 3, tap_s = tap - tap_r * 3;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int f = kk & 1;
-          if (kk < 3) rd(kk + 1, f ^ 1);
-          if (more && kk < WPASS) wpiece(q + NS - 1, kk);
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < PTB; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
-          if (kk < 3) sched_mix<CT * PTB, CT + PTB, 1>();
-        }
-      }
+    for (int pt = 0; pt < PTB; ++pt) {
+      const int R = tpy[pt] + tap_r, cx = tpx[pt] + tap_s;
+      pb[pt] = (unsigned)((R * PW + cx) * ROW);
+      psw[pt] = (unsigned)(K::f1(R, cx) << 4);
     }
-    lds_barrier();                                 // every wave is through P1: P2 (layer3: over P1) may be written
-    // epilogue B -> P2[tile pixel][cout] (slot = chunk ^ (row & 15))
+  };
+  auto rd_b = [&](int q, int kk, int f) {          // conv2 tile q: weights from its stage, pixels from P1 at the current tap
+    read_a(smem + (q % NS) * K::WST, kk, f);
+    const unsigned ch = (unsigned)(((q % KCB) * 8 + 2 * kk + fhalf) << 4);
+#pragma unroll
+    for (int pt = 0; pt < PTB; ++pt) fb[f][pt] = *reinterpret_cast<const bf16x8*>(P1 + pb[pt] + (ch ^ psw[pt]));
+  };
+  auto rd_c = [&](int q, int kk, int f) {          // conv3 tile q (K tile k of its cout block): pixels from P2
+    read_a(smem + (q % NS) * K::WST, kk, f);
+    const int k = (q - QB) % KCB;
 #pragma unroll
     for (int pt = 0; pt < PTB; ++pt) {
       const int row = (wave_px * PTB + pt) * 32 + frow;
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s2 + col);
-          const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b2 + col);
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(add_nc(mul_nc(acc[ct][pt][4 * g + e], sc[e]), bi[e]), 0.f);
-          const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(P2 + row * ROW + ((((col >> 3) ^ (row & 15)) << 4) | (fhalf << 3))) = o;
-        }
+      fb[f][pt] = *reinterpret_cast<const bf16x8*>(P2 + row * ROW + (((k * 8 + 2 * kk + fhalf) ^ (row & 15)) << 4));
     }
-    lds_barrier();
+  };
+  auto fetch = [&](int q) {                        // DMA pieces of tile q + NS - 1 during tile q's first half: all out before its sync point
+    if (q + NS - 1 < QT) {
 #pragma unroll
-    for (int i = 0; i < NSTO; ++i) {
-      const int t = sto_t[i], c = sto_c[i];
-      sto_r[i] = *reinterpret_cast<const u32x4*>(P2 + t * ROW + ((c ^ (t & 15)) << 4));
+      for (int i = 0; i < WPASS; ++i) wpiece(q + NS - 1, i);
     }
+  };
+  // ---------------- Phase B: a2 = relu(bn2(W2 * a1)), nine taps out of P1; GEMM [P couts] x [TPR tile pixels] x [9 P]
+  zero_acc();
+  sync_for(0);
+  store_rows(rs_a1, (unsigned)P, 0u);              // a1 leaves for memory (rows read from P1 at the end of phase A)
+  xprev = NSTO;
+  set_tap(0);
+  rd_b(0, 0, 0);
+  rd_b(0, 1, 1);
+  for (int q = 0; q < QB; ++q) {
+    rd_b(q, 2, 2);
+    rd_b(q, 3, 3);
+    fetch(q);
+    mma(0);
+    mma(1);
+    sched_mix<2 * CT * PTB, 2 * (CT + PTB), WPASS>();
+    if (q + 1 < QB) {                              // (the phase's last tile drains: conv3's pixels do not exist yet)
+      sync_for(q + 1);
+      if ((q + 1) % KCB == 0) set_tap((q + 1) / KCB);
+      rd_b(q + 1, 0, 0);
+      rd_b(q + 1, 1, 1);
+    }
+    mma(2);
+    mma(3);
+    sched_mix<2 * CT * PTB, 2 * (CT + PTB), 0>();
+  }
+  lds_barrier();                                   // every wave is through P1: P2 (layer3: over P1) may be written
+  // epilogue B -> P2[tile pixel][cout] (slot = chunk ^ (row & 15))
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s2 + col);
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b2 + col);
+#pragma unroll
+      for (int pt = 0; pt < PTB; ++pt) {
+        const int row = (wave_px * PTB + pt) * 32 + frow;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(add_nc(mul_nc(acc[ct][pt][4 * g + e], sc[e]), bi[e]), 0.f);
+        const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(P2 + row * ROW + ((((col >> 3) ^ (row & 15)) << 4) | (fhalf << 3))) = o;
+      }
+    }
+  lds_barrier();
+#pragma unroll
+  for (int i = 0; i < NSTO; ++i) {
+    int t, c;
+    unsigned pix;
+    sto_item(i, t, c, pix);
+    sto_r[i] = *reinterpret_cast<const u32x4*>(P2 + t * ROW + ((c ^ (t & 15)) << 4));
   }
   // ---------------- Phase C: out = relu(bn3(W3 . a2) + identity), four cout blocks of P; GEMM [P couts] x [TPR] x [P] per block
   {
@@ -425,61 +478,59 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
       for (int i = 0; i < SDMA; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_id, (lptr_t)(S + (i * 8 + wave) * 1024), 16, idoff[i], (unsigned)(blk * P * 2), 0, 0);
     };
+    // the staged rows of the previous phase / block leave for memory and this block's identity is requested: at a sync point (clean ledger;
+    // S is free - every thread's row reads of it are behind the sync's barrier)
+    auto block_start = [&](int blk) {
+      if (blk == 0) store_rows(rs_a2, (unsigned)P, 0u);
+      else store_rows(rs_out, (unsigned)p.ldo, (unsigned)((blk - 1) * P));
+      dma_idt(blk);
+      xprev = NSTO + SDMA;
+    };
+    sync_for(QB);
+    block_start(0);
+    rd_c(QB, 0, 0);
+    rd_c(QB, 1, 1);
+    if (p.dbg == 2) { wait_vmcnt<0>(); return; }
     for (int blk = 0; blk < 4; ++blk) {
-#pragma unroll
-      for (int a = 0; a < CT; ++a)
-#pragma unroll
-        for (int b = 0; b < PTB; ++b)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+      zero_acc();
       for (int k = 0; k < KCB; ++k) {
         const int q = QB + blk * KCB + k;
-        const unsigned char* st = smem + (q % NS) * K::WST;
-        tile_top(q);
-        if (k == 0) {
-          // the previous phase's / block's rows leave for memory (they sit in registers: S is free for this block's identity - the
-          // barrier above is behind every thread's reads of it)
-          if (blk == 0) store_rows(rs_a2, (unsigned)P, 0u);
-          else store_rows(rs_out, (unsigned)p.ldo, (unsigned)((blk - 1) * P));
-          dma_idt(blk);
-          xprev = NSTO + SDMA;
+        rd_c(q, 2, 2);
+        rd_c(q, 3, 3);
+        fetch(q);
+        mma(0);
+        mma(1);
+        sched_mix<2 * CT * PTB, 2 * (CT + PTB), WPASS>();
+        if (q + 1 < QT) {
+          sync_for(q + 1);
+          // (a block's identity is requested one tile into the block - behind the previous block's epilogue, which still owns S at the
+          // block boundary's own sync point)
+          if (k == 0 && blk > 0) block_start(blk);
+          rd_c(q + 1, 0, 0);
+          rd_c(q + 1, 1, 1);
         }
-        const bool more = q + NS - 1 < QT;
-        auto rd = [&](int kk, int f) {
-          read_a(st, kk, f);
+        mma(2);
+        mma(3);
+        sched_mix<2 * CT * PTB, 2 * (CT + PTB), 0>();
+      }
+      // epilogue C of this block: the identity tile must have landed in S.  The sync point behind this block's last tile has already waited
+      // for the next tile; what can still be in flight are the NS - 2 tiles after that one - all issued behind the identity request
+      // (which went out one tile into the block at the latest): allow exactly those
+      {
+        const int qlast = QB + blk * KCB + KCB - 1;
+        wait_vm<WPASS, 0, 0>(min(NS - 2, QT - 2 - qlast) * WPASS);
+      }
+      lds_barrier();
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s3 + blk * P + col);
+          const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b3 + blk * P + col);
 #pragma unroll
           for (int pt = 0; pt < PTB; ++pt) {
             const int row = (wave_px * PTB + pt) * 32 + frow;
-            fb[f][pt] = *reinterpret_cast<const bf16x8*>(P2 + row * ROW + (((k * 8 + 2 * kk + fhalf) ^ (row & 15)) << 4));
-          }
-        };
-        rd(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int f = kk & 1;
-          if (kk < 3) rd(kk + 1, f ^ 1);
-          if (more && kk < WPASS) wpiece(q + NS - 1, kk);
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < PTB; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f][ct], fb[f][pt], acc[ct][pt], 0, 0, 0);
-          if (kk < 3) sched_mix<CT * PTB, CT + PTB, 1>();
-        }
-      }
-      // epilogue C of this block: the identity tile must have landed in S.  It was issued at the block's first tile top, in front of
-      // that top's fetched tile: every weight tile still in flight is younger - at most NS - 1 of them (fewer at the very end)
-      wait_vm<WPASS, WPASS, 0>(min(NS - 1, QT - 1 - (QB + blk * KCB + KCB - 1)) * WPASS);
-      lds_barrier();
-#pragma unroll
-      for (int pt = 0; pt < PTB; ++pt) {
-        const int row = (wave_px * PTB + pt) * 32 + frow;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int col = wave_co * (32 * CT) + ct * 32 + 8 * g + 4 * fhalf;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.s3 + blk * P + col);
-            const f32x4 bi = *reinterpret_cast<const f32x4*>(p.b3 + blk * P + col);
             unsigned char* cell = S + row * ROW + ((((col >> 3) ^ (row & 15)) << 4) | (fhalf << 3));
             const u32x2 aa = *reinterpret_cast<const u32x2*>(cell);
             const float ad[4] = {bflo(aa[0]), bfhi(aa[0]), bflo(aa[1]), bfhi(aa[1])};
@@ -489,11 +540,13 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
             const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
             *reinterpret_cast<u32x2*>(cell) = o;
           }
-      }
+        }
       lds_barrier();
 #pragma unroll
       for (int i = 0; i < NSTO; ++i) {
-        const int t = sto_t[i], c = sto_c[i];
+        int t, c;
+        unsigned pix;
+        sto_item(i, t, c, pix);
         sto_r[i] = *reinterpret_cast<const u32x4*>(S + t * ROW + ((c ^ (t & 15)) << 4));
       }
     }
@@ -533,6 +586,7 @@ extern "C" int dsl_bottleneck_fwd(const dsl_bneck_desc* d, void* stream) {
   k.a1 = (uint16_t*)d->a1; k.a2 = (uint16_t*)d->a2; k.out = (uint16_t*)d->out;
   k.n = d->n; k.hin = d->hin; k.win = d->win; k.h = d->h; k.w = d->w;
   k.cin = d->cin; k.ldx = d->ldx; k.stride = d->stride; k.ldi = d->ldi; k.ldo = d->ldo;
+  k.dbg = dsl_option("bneck_dbg");
   hipStream_t st = (hipStream_t)stream;
   const double px = (double)d->n * d->h * d->w, P = d->planes;
   int prof = -1;

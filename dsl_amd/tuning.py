@@ -12,7 +12,8 @@ DEFAULTS = {
     'side': '1',               # library side streams (weight gradients, second tower, image-split chains); 0 = everything on the caller's stream
     'pipe_prefix': '1',        # the next step's frozen prefix (stem + layer1) on its own stream beside the backward tail
     'img_split': '234',        # forward stages (layer numbers) that run as two half-batch chains
-    'bneck_fwd': '23',         # forward stages whose bottlenecks run as one launch each (dsl_bottleneck_fwd; these stages are not image-split)
+    'bneck_fwd': '2',          # forward stages whose bottlenecks run as one launch each (dsl_bottleneck_fwd; not image-split then): layer2 + 1.5 %;
+                               # '23' adds layer3, where the fused kernel only ties the two half-batch chains (- 0.7 %, profiles/r05_bneck_ab_v4.txt)
     'img_split_bwd': '23',     # backward stages whose data-gradient chains do
     'tower_slots': '72',       # workgroup budget of the towers' x8 weight-gradient group
     'tail_slots': '192',       # ... of the last segment's (layer2) weight gradients
@@ -26,6 +27,7 @@ DEFAULTS = {
     'check_backward_grad': '0',    # 1: verify the gradient handed to loss.backward() on every step (default: the first steps only)
     'skip': '',                # timing-only ablation: '+'-separated items - region tags (fwd.l2 ... bwd.l2), 'sgd', 'prefix'
     # ---- C library options (dsl_set_option)
+    'lib.bneck_dbg': '0',      # timing probe of the fused bottleneck kernel (phase cut-offs; results are wrong)
     'lib.conv_addfast': '1',   # (A/B of round 5's in-register addend epilogue; 0 = the staged fp32 epilogue)
     'lib.wgrad_slots': '128',
     'lib.stream_probe': '1',   # 0: the library takes its streams as the runtime deals them (no hardware-queue probe)

@@ -293,6 +293,45 @@ def test_pipelined_prefix_equals_inline_forward(golden):
     assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
 
 
+def test_fused_bottleneck_stages_train_to_the_same_bits(golden, monkeypatch):
+    """Tuning key bneck_fwd: layer2 / layer3's bottlenecks as ONE launch each (dsl_bottleneck_fwd, csrc/bneck.hip) instead of three launches
+    per block and image-split chain.  Same K order per MFMA chain and the same rounding points => the step's losses, every gradient and
+    the updated weights are bit-identical whichever stages are fused, over steps with changing images (a stage's first block runs the
+    stride-2 conv1 + separate-identity form of the kernel)."""
+    from dsl_amd import tuning
+    from dsl_amd.optim import FlatSGD
+    d = golden('net_tiny.npz')
+    B = int(d['B'])
+    gtb, gtl = [T(d[f'gt{i}']) for i in range(B)], [T(d[f'gl{i}']) for i in range(B)]
+    g = torch.Generator().manual_seed(9)
+    imgs = [(T(d['img']) + 0.5 * k * torch.randn(T(d['img']).shape, generator=g)).cuda() for k in range(3)]
+    metas = [dict(img_shape=tuple(imgs[0].shape[2:]) + (3,), pad_shape=tuple(imgs[0].shape[2:]) + (3,), scale_factor=1.0)] * B
+    tuning.tune('side')                                    # (DSL_TUNE parsed before the overrides below)
+    finals = []
+    for fused in ('', '2', '23'):
+        monkeypatch.setitem(tuning._values, 'bneck_fwd', fused)
+        model = build()
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+        losses = []
+        for img in imgs:
+            out = model.train_step(dict(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl), opt)
+            out['loss'].backward()
+            opt.step()
+            losses.append(out['loss'].detach().clone())
+        torch.cuda.synchronize()
+        plan = [p for p in model._engine.plans.values() if p.training][0]
+        n_fused = sum(1 for o in plan.fwd.items if o.kind == L_OP_BNECK())
+        assert n_fused == {'': 0, '2': 4, '23': 10}[fused], n_fused
+        finals.append((torch.stack(losses).cpu(), model.store.grad.clone().cpu(), model.store.train.clone().cpu()))
+    for other in finals[1:]:
+        assert torch.equal(finals[0][0], other[0]) and torch.equal(finals[0][1], other[1]) and torch.equal(finals[0][2], other[2])
+
+
+def L_OP_BNECK():
+    from dsl_amd import _lib as L
+    return L.OP_BNECK
+
+
 def test_deferred_head_update_trains_to_the_same_bits(golden, monkeypatch):
     """Deferred head update (engine.Plan.defer, FlatSGD without clipping): the towers' weight gradients and the head + FPN bucket's
     optimizer step run under the NEXT step's backbone forward, which waits for them in front of the FPN (SLOT_HEADW).  Same kernels

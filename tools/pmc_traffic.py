@@ -56,8 +56,15 @@ if wg and algo.get('wgrad (all launches, average)'):
                                                 algorithmic_bytes_per_launch=algo['wgrad (all launches, average)'],
                                                 measured_over_algorithmic=round(tot / max(nl, 1) / algo['wgrad (all launches, average)'], 2),
                                                 note='main + reduce kernels of the weight gradients per main launch')
-json.dump(dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 3 '
+# whole-step HBM traffic: every kernel's bytes x launches over the profiled run, per training step (the run is --steps 3 --warmup 2: five
+# steps; the few one-off initialisation kernels of the process are in the sum - an upper bound by < 1 %)
+STEPS = 5
+total = sum(v['launches'] * v['hbm_bytes_per_launch'] for k, v in out.items() if not k.startswith('wgrad (all'))
+step_total = dict(hbm_bytes_per_step=round(total / STEPS), steps_profiled=STEPS,
+                  hbm_floor_ms_at_8TBs=round(total / STEPS / 8e12 * 1e3, 3), hbm_floor_ms_at_6p3TBs=round(total / STEPS / 6.3e12 * 1e3, 3))
+json.dump(dict(step=step_total, source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 3 '
                       '--warmup 2 --no-prof --no-dsl`; read bytes = 2 x FETCH_SIZE (gfx950 correction), KiB units',
                kernels=out), open(sys.argv[3], 'w'), indent=1)
+print('whole step:', step_total)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:8]:
     print(k, v)
