@@ -25,8 +25,6 @@ extern "C" int dsl_version(void) { return 100; }
 namespace {
 struct Option { const char* name; int value; };
 Option g_options[] = {
-    {"bneck_dbg", 0},        // (timing probe of dsl_bottleneck_fwd, results are wrong) 1 = stop behind conv1, 2 = behind conv2
-    {"conv_addfast", 1},     // (A/B) 0: convolutions with an addend take the staged fp32 epilogue instead of the in-register addend path
     {"wgrad_slots", 128},    // workgroup budget of a weight-gradient launch that runs beside the caller's chain (dsl_wgrad_desc.slots = 0)
     {"stream_probe", 1},     // 0: the library takes its streams as the runtime deals them instead of probing for distinct hardware queues
     {"debug_sync", 0},       // 1: drain the device after every op of dsl_run_ops and name it on stderr

@@ -46,7 +46,7 @@ struct BnK {
   int cin, ldx, stride;           // conv1 reads `cin` channels of rows of ldx elements at pixel stride `stride`
   int ldi, ldo;                   // row strides of identity / out (elements)
   int tiles_y, tiles_x, ntiles, xcd_chunk;
-  int dbg;                        // timing probe (option bneck_dbg; results are wrong): 1 = stop behind phase A, 2 = behind phase B
+  int dbg;                        // timing probe of the ablation build (tools/build_ablate.sh, DSL_BNECK_DBG; results are wrong): 1 = stop behind phase A, 2 = behind phase B
 };
 
 // P: planes (128 = layer2, 256 = layer3); TY x TX: output pixels per workgroup.  512 threads = 8 waves: 4 cout groups x 2 pixel groups.
@@ -322,7 +322,9 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
       sto_r[i] = *reinterpret_cast<const u32x4*>(P1 + ((py + 1) * PW + px + 1) * ROW + ((c ^ K::f1(py + 1, px + 1)) << 4));
     }
   }
+#ifdef DSL_ABLATE_BUILD
   if (p.dbg == 1) { wait_vmcnt<0>(); return; }
+#endif
 
   // =================================================================================================================
   // Phases B and C share ONE weight-tile stream: q = 0 .. QB - 1 conv2's tiles (tap-major, then channel blocks), then conv3's
@@ -490,7 +492,9 @@ __device__ __forceinline__ void bneck_fwd_body(const BnK& p, unsigned char* smem
     block_start(0);
     rd_c(QB, 0, 0);
     rd_c(QB, 1, 1);
+#ifdef DSL_ABLATE_BUILD
     if (p.dbg == 2) { wait_vmcnt<0>(); return; }
+#endif
     for (int blk = 0; blk < 4; ++blk) {
       zero_acc();
       for (int k = 0; k < KCB; ++k) {
@@ -586,7 +590,10 @@ extern "C" int dsl_bottleneck_fwd(const dsl_bneck_desc* d, void* stream) {
   k.a1 = (uint16_t*)d->a1; k.a2 = (uint16_t*)d->a2; k.out = (uint16_t*)d->out;
   k.n = d->n; k.hin = d->hin; k.win = d->win; k.h = d->h; k.w = d->w;
   k.cin = d->cin; k.ldx = d->ldx; k.stride = d->stride; k.ldi = d->ldi; k.ldo = d->ldo;
-  k.dbg = dsl_option("bneck_dbg");
+  k.dbg = 0;
+#ifdef DSL_ABLATE_BUILD
+  { const char* e = getenv("DSL_BNECK_DBG"); k.dbg = e ? atoi(e) : 0; }
+#endif
   hipStream_t st = (hipStream_t)stream;
   const double px = (double)d->n * d->h * d->w, P = d->planes;
   int prof = -1;

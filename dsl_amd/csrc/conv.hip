@@ -2041,7 +2041,7 @@ extern "C" int dsl_conv2d(const dsl_conv_desc* d, void* stream) {
   bool identd = d->os == 1;               // destination pixel == compute-grid pixel (whatever the addend's grid is)
   for (int s = 0; s < d->nseg; ++s)
     if (d->gh[s] != d->dh[s] || d->gw[s] != d->dw[s]) identd = false;
-  k.addfast = (d->addend && identd && dsl_option("conv_addfast") != 0 && !(d->flags & DSL_CONV_EPI_STAGED) && d->lda % 8 == 0 && d->ldd % 8 == 0 &&
+  k.addfast = (d->addend && identd && !(d->flags & DSL_CONV_EPI_STAGED) && d->lda % 8 == 0 && d->ldd % 8 == 0 &&
                (!d->mask || d->ldm % 8 == 0) && ((uintptr_t)d->addend & 15) == 0 && ((uintptr_t)d->dst & 15) == 0 &&
                (dof > ao ? dof : ao) * (long long)d->lda * 2 < 0x7fff0000LL) ? ((d->flags & DSL_CONV_ADD_UPSAMPLE) ? 2 : 1) : 0;
   k.lds = d->lds > 0 ? d->lds : d->cs;

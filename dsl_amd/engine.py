@@ -19,6 +19,8 @@ from .head_loss import FcosLossPlan
 from .params import STAGE_BLOCKS, STAGE_PLANES
 from .tuning import skip_items, tune, tune_int
 
+DEFER_SLOTS = 144      # workgroup budget of the towers' weight-gradient group when the head update is deferred (FlatSGD(defer_head_update=True))
+
 BF = torch.bfloat16
 
 
@@ -707,7 +709,7 @@ class Plan:
                 gd.conv_stats = 1 if (tower, i) in gn_from_conv else 0
                 ol.gn_bwd(gd, side=sd)
                 tower_group.append(self._wgrad(ol, lay['spec'], g_pre[tower], lay['xin'], N, ls, ls, side=SIDE, emit=False, no_db=True,
-                                               slots=tune_int('defer_slots') if self.defer else tune_int('tower_slots')))     # measured: tools/experiments_r2.txt (exp_r2z) (48-128: 5.84 ms, 160-192: 5.89); round 3: 72 / 96 / 128: 5.435 / 5.461 / 5.456
+                                               slots=DEFER_SLOTS if self.defer else tune_int('tower_slots')))     # measured: tools/experiments_r2.txt (exp_r2z) (48-128: 5.84 ms, 160-192: 5.89); round 3: 72 / 96 / 128: 5.435 / 5.461 / 5.456
             if i == 0:
                 if BT and SIDE:
                     ol.fork(1, other=BT)       # the weight-gradient stream also waits for the regression tower's stream

@@ -183,7 +183,7 @@ def build_backward(plan, buckets, SIDE):
         rec_items = []
         # the last stage's weight gradients go out behind the whole data-gradient chain, with nothing left to run beside them (0.8 ms
         # of the iteration, profiles/r03_rla_sequence.txt): they take the chip instead of the weight-gradient stream's usual budget
-        tsl = tune_int('rla_tail_slots') if s_ == 1 else 0
+        tsl = tune_int('tail_slots') if s_ == 1 else 0
         if bsplit:
             ol.fork(BB)
 

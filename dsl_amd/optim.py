@@ -11,15 +11,15 @@ from . import _lib as L
 from .registry import OPTIMIZERS
 
 
-from .tuning import skip_items, tune
+from .tuning import skip_items
 
-_BUCKET_SGD = tune('bucket_sgd') != '0'    # per-bucket optimizer steps beside the backward pass (no clipping only)
 _PACK_SIDE = True                          # data-gradient weight packs off the caller's stream (measured: tools/experiments_r2.txt (exp_r2l))
 
 
 @OPTIMIZERS.register_module(name='SGD')
 class FlatSGD:
-    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=0.0, paramwise_cfg=None, grad_clip=None, **kw):
+    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=0.0, paramwise_cfg=None, grad_clip=None,
+                 defer_head_update=False, **kw):
         assert not kw.get('nesterov', False) and kw.get('dampening', 0) == 0
         self.model = model
         self.store = model.store
@@ -37,13 +37,14 @@ class FlatSGD:
         self.momentum_buf = None
         self.gnorm_sq = None
         self.steps = 0
+        self.defer_head_update = bool(defer_head_update)      # opt-in (measured slower on one GPU, LAB_NOTES: deferred head update)
         self._sync_defer()
 
     def _sync_defer(self):
         """Deferred head update (engine.Plan.defer): possible when the update is element-wise per bucket - no gradient
         clipping (a global norm needs every gradient first), per-bucket steps on, packs on the side stream.  The flag lives on
-        the parameter store because it shapes the op lists; opt-in (tuning key defer_head=1)."""
-        want = (self.max_norm is None and _BUCKET_SGD and _PACK_SIDE and tune('defer_head') != '0'
+        the parameter store because it shapes the op lists; opt-in (constructor argument defer_head_update)."""
+        want = (self.max_norm is None and _PACK_SIDE and self.defer_head_update
                 and self.store.backbone != 'rla')
         if bool(getattr(self.store, 'defer_head', False)) != want:
             self.store.wait_pending() if self.store.train.is_cuda else None
@@ -107,7 +108,7 @@ class FlatSGD:
         self._sync_defer()          # (OptimizerHook may set max_norm after construction)
         infos = getattr(self.model, '_last_bwd_infos', None)
         infos = [i for i in infos if i['bucket'] is not None] if infos else infos      # completion order; a deferred bucket comes last
-        if self.max_norm is None and _BUCKET_SGD and infos and st.grad.is_cuda and all(i['bucket'][0] % 4 == 0 for i in infos):
+        if self.max_norm is None and infos and st.grad.is_cuda and all(i['bucket'][0] % 4 == 0 for i in infos):
             # No gradient clipping (the supervised config): the update is element-wise, so each gradient bucket - head + FPN,
             # layer4, layer3, layer2, in the order the backward pass completes them - is updated on the optimizer's own stream
             # as soon as its weight gradients (data parallel: its all-reduce) are done, beside the rest of the backward pass,

@@ -16,19 +16,13 @@ DEFAULTS = {
                                # '23' adds layer3, where the fused kernel only ties the two half-batch chains (- 0.7 %, profiles/r05_bneck_ab_v4.txt)
     'img_split_bwd': '23',     # backward stages whose data-gradient chains do
     'tower_slots': '72',       # workgroup budget of the towers' x8 weight-gradient group
-    'tail_slots': '192',       # ... of the last segment's (layer2) weight gradients
-    'defer_head': '0',         # deferred head + FPN update (FlatSGD without clipping; measured slower, kept for data-parallel experiments)
-    'defer_slots': '144',      # workgroup budget of the deferred towers' group
-    'bucket_sgd': '1',         # per-bucket optimizer steps beside the backward pass (no-clipping configs)
+    'tail_slots': '192',       # ... of the last segment's weight gradients (layer2; the RLA backbone's stage 1)
     # ---- RLA_ResNet engine
     'rla_split': '123',        # forward stages of the RLA backbone that run as two chains
-    'rla_tail_slots': '192',
     # ---- checks / measurement
     'check_backward_grad': '0',    # 1: verify the gradient handed to loss.backward() on every step (default: the first steps only)
     'skip': '',                # timing-only ablation: '+'-separated items - region tags (fwd.l2 ... bwd.l2), 'sgd', 'prefix'
     # ---- C library options (dsl_set_option)
-    'lib.bneck_dbg': '0',      # timing probe of the fused bottleneck kernel (phase cut-offs; results are wrong)
-    'lib.conv_addfast': '1',   # (A/B of round 5's in-register addend epilogue; 0 = the staged fp32 epilogue)
     'lib.wgrad_slots': '128',
     'lib.stream_probe': '1',   # 0: the library takes its streams as the runtime deals them (no hardware-queue probe)
     'lib.debug_sync': '0',

@@ -31,8 +31,7 @@ int dsl_version(void);
 const char* dsl_last_error(void);
 /* Library options - the library reads no environment variable.  Names: "wgrad_slots" (default 128: workgroup budget of a
  * weight-gradient launch whose descriptor leaves `slots` 0), "stream_probe" (1; 0 = the library takes its streams as the runtime deals
- * them instead of probing for hardware queues of their own, dsl_streams_init), "conv_addfast" (1; 0 = convolutions with an addend take
- * the staged fp32 epilogue - A/B of the in-register addend path), "debug_sync" (0; 1 = dsl_run_ops drains the device after every op and
+ * them instead of probing for hardware queues of their own, dsl_streams_init), "debug_sync" (0; 1 = dsl_run_ops drains the device after every op and
  * names it on stderr), "skip_kinds" (0; timing-only ablation: bit mask of op kinds dsl_run_ops skips).  Unknown name: -1. */
 int dsl_set_option(const char* name, int value);
 int dsl_get_option(const char* name, int* value);

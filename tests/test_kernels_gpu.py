@@ -596,7 +596,7 @@ def test_groupnorm_relu_fwd_bwd(K):
     (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 4),       # 128 x 128 tile (two cout tiles write one record)
     (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 7),       # 64 x 64 tile
     (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 3),       # 128 x 256 tile
-    (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 9),       # 256 x 256 tile (its staged tile lies beyond the K loop's ring)
+    (2, [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)], 0),  # the benchmark's head: 88 tiles per row of the first level
 ])
 def test_groupnorm_statistics_from_the_conv_epilogue(K, N, sizes, force):
     """conv -> GN -> ReLU (ConvModule, anchor_free_head.py:104-133) with the statistics left by the convolution's epilogue
@@ -650,6 +650,7 @@ def test_groupnorm_statistics_from_the_conv_epilogue(K, N, sizes, force):
     (3, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 1),       # 256 x 192: the reduction scratch takes two rounds
     (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 4),       # 128 x 128: not instantiated, the launch refuses
     (2, [(40, 52), (20, 26), (10, 13), (5, 7), (3, 4)], 2),       # 256 x 128
+    (2, [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)], 0),  # the benchmark's head
 ])
 def test_groupnorm_backward_records_from_the_data_gradient_epilogue(K, N, sizes, force):
     """dY of a tower layer's GroupNorm + ReLU comes out of the next layer's data gradient: with dsl_conv_desc.gn_x that launch also

@@ -333,7 +333,7 @@ def L_OP_BNECK():
 def test_deferred_head_update_trains_to_the_same_bits(golden, monkeypatch):
     """Deferred head update (engine.Plan.defer, FlatSGD without clipping): the towers' weight gradients and the head + FPN bucket's
     optimizer step run under the NEXT step's backbone forward, which waits for them in front of the FPN (SLOT_HEADW).  Same kernels
-    and summation order (tuning key defer_slots = the inline budget) => bit-identical losses and weights over steps with changing images;
+    and summation order (engine.DEFER_SLOTS = the inline budget) => bit-identical losses and weights over steps with changing images;
     a state_dict() read right behind opt.step() already sees the finished update (ParamStore.wait_pending)."""
     from dsl_amd.optim import FlatSGD
     d = golden('net_tiny.npz')
@@ -344,13 +344,14 @@ def test_deferred_head_update_trains_to_the_same_bits(golden, monkeypatch):
     metas = [dict(img_shape=tuple(imgs[0].shape[2:]) + (3,), pad_shape=tuple(imgs[0].shape[2:]) + (3,), scale_factor=1.0)] * B
     from dsl_amd import tuning
     tuning.tune('side')                                    # (DSL_TUNE parsed before the overrides below)
-    monkeypatch.setitem(tuning._values, 'defer_slots', '72')
+    from dsl_amd import engine
+    monkeypatch.setattr(engine, 'DEFER_SLOTS', 72)
     monkeypatch.setitem(tuning._values, 'tower_slots', '72')
     finals = []
     for defer in ('0', '1'):
-        monkeypatch.setitem(tuning._values, 'defer_head', defer)
         model = build()
-        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
+                      defer_head_update=defer == '1')
         assert bool(getattr(model.store, 'defer_head', False)) == (defer == '1')
         losses = []
         for img in imgs:
@@ -381,13 +382,13 @@ def test_deferred_plan_with_a_clipping_optimizer_still_sees_every_gradient(golde
     metas = [dict(img_shape=tuple(img.shape[2:]) + (3,), pad_shape=tuple(img.shape[2:]) + (3,), scale_factor=1.0)] * B
     from dsl_amd import tuning
     tuning.tune('side')
-    monkeypatch.setitem(tuning._values, 'defer_slots', '72')
-    monkeypatch.setitem(tuning._values, 'defer_head', '1')
+    from dsl_amd import engine
+    monkeypatch.setattr(engine, 'DEFER_SLOTS', 72)
     res = []
     for late_clip in (False, True):
         model = build()
         opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.),
-                      grad_clip=None if late_clip else dict(max_norm=1.0, norm_type=2))
+                      grad_clip=None if late_clip else dict(max_norm=1.0, norm_type=2), defer_head_update=True)
         for it in range(2):
             out = model.train_step(dict(img=img, img_metas=metas, gt_bboxes=gtb, gt_labels=gtl), opt)
             if late_clip and it == 0:

@@ -65,19 +65,12 @@ for name, P, H, W, NBLK in (('layer2', 128, 100, 168, 3), ('layer3', 256, 50, 84
     tf = timeit(fused) / NBLK
     tf1 = timeit(lambda: L.check(L.lib.dsl_bottleneck_fwd(C.byref(bd), L.stream_ptr())))
     flops = 2.0 * N * H * W * (P * C4 + 9 * P * P + C4 * P)
-    import ctypes
-    ph = []
-    for dbg in (1, 2):          # timing probe: the fused kernel cut off behind conv1 / behind conv2 (option bneck_dbg)
-        L.check(L.lib.dsl_set_option(b'bneck_dbg', dbg))
-        ph.append(timeit(lambda: L.check(L.lib.dsl_bottleneck_fwd(C.byref(bd), L.stream_ptr()))))
-    L.check(L.lib.dsl_set_option(b'bneck_dbg', 0))
-    ab = None          # (fine-grained ablation bits: a round-5 experiment build only, LAB_NOTES.md)
-    for nm, dbg in (() if ab is None else (('no MFMA', 4), ('no tile DMA', 8), ('no fragment reads', 16), ('no MFMA, no reads', 20), ('DMA only', 20), ('neither DMA nor MFMA nor reads', 28))):
-        L.check(L.lib.dsl_set_option(b'bneck_dbg', dbg))
-        ab[nm] = timeit(lambda: L.check(L.lib.dsl_bottleneck_fwd(C.byref(bd), L.stream_ptr())))
-    L.check(L.lib.dsl_set_option(b'bneck_dbg', 0))
-    if ab:
-        print(f'{name}: fused kernel ablation (timing only): ' + ', '.join(f'{k} {v:5.1f}' for k, v in ab.items()) + f' | whole {tf1:5.1f} us')
-    print(f'{name}: fused kernel by phase (cut-off probe): conv1 + halo {ph[0]:5.1f} us, + conv2 {ph[1]:5.1f} us, whole {tf1:5.1f} us')
+    if os.environ.get('DSL_BNECK_DBG_PROBE'):          # ablation build only (tools/build_ablate.sh): the kernel cut off behind conv1 / conv2
+        ph = []
+        for dbg in (1, 2):
+            os.environ['DSL_BNECK_DBG'] = str(dbg)
+            ph.append(timeit(lambda: L.check(L.lib.dsl_bottleneck_fwd(C.byref(bd), L.stream_ptr()))))
+        os.environ['DSL_BNECK_DBG'] = '0'
+        print(f'{name}: fused kernel by phase (cut-off probe): conv1 + halo {ph[0]:5.1f} us, + conv2 {ph[1]:5.1f} us, whole {tf1:5.1f} us')
     print(f'{name}: conv1 {t[0]:6.1f}  conv2 {t[1]:6.1f}  conv3 {t[2]:6.1f}  per block of a {NBLK}-block chain: three launches {t3:6.1f} us ({flops / t3 / 1e6:5.0f} TF)'
           f'   fused {tf:6.1f} us ({flops / tf / 1e6:5.0f} TF)   [one block replayed: fused {tf1:6.1f} us]')
