@@ -80,7 +80,8 @@ struct GnK {
                                  // a row's records indexed by pixel tile relative to the tile that holds the row's first pixel
 };
 
-constexpr int GN_PPB = 128;   // pixels per block
+constexpr int GN_PPB = 128;   // pixels per block (round 5, profiles/r05_gn_ppa_ab.txt: apply passes with 64 / 128 / 256 pixels per block tie,
+                              // 512: - 4 %, 1024: - 7 % on the step - the passes live in the gaps the convolutions' workgroups leave)
 
 // Where the block records of one (segment, image) row are and how many there are: the pass's own (one per GN_PPB pixels) or the
 // ones a convolution's epilogue left (conv_nbk > 0: one per pixel tile of that launch that meets the row).

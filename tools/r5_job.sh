@@ -1,3 +1,4 @@
 mkdir -p gpurun_out
-bash tools/exp_env.sh "-" "-" 2>&1 | tee gpurun_out/r05_sanity.txt
-(timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -8) | tee gpurun_out/r05_gpu_tests.log
+for rep in 1 2 3; do
+bash tools/exp_env.sh "-" "DSL_HIP_LIB=$PWD/dsl_amd/lib_ta128/libdsl_hip.so"
+done 2>&1 | tee gpurun_out/r05_gn_ta128_ab.txt
