@@ -273,7 +273,7 @@ def cpu_baseline(batch, seed=0, warmup=1, steps=2):
                        + ', '.join(f'{t:.1f}' for t in times) + ' s'), losses
 
 
-def dsl_iteration_timing(steps=12, warm=6, variants=None):
+def dsl_iteration_timing(steps=12, warm=6, variants=None, extra_hook=None, raw=False):
     """BASELINE.json configs[2] beside the headline line: the semi-supervised iteration - labeled + unlabeled image and the
     half-scale copy (N = 3 through the student), ignore boxes, loss_weight 3, sisoft, clip, SGD, EMA teacher update every
     iteration - without and with the teacher's pseudo-label refresh of the upcoming unlabeled image (self-scheduled
@@ -325,6 +325,8 @@ def dsl_iteration_timing(steps=12, warm=6, variants=None):
                     e.record()
                     evs.append(e)
         runner.register_hook(Clock(), priority=90)
+        if extra_hook is not None:           # (tools/dsl_outlier_probe.py: host-side bookkeeping per iteration)
+            runner.register_hook(extra_hook, priority=95)
         runner.run([loader], max_epochs=1)
         torch.cuda.synchronize()
         # median of the per-iteration intervals: a one-off stall inside the window (first use of a new shape, an allocator
@@ -335,6 +337,8 @@ def dsl_iteration_timing(steps=12, warm=6, variants=None):
         key = ('ms_per_iter' if not refresh else 'ms_per_iter_with_teacher_refresh' + ('_async' if asyn else '')) + ('_rla_backbone' if rla else '')
         out[key] = round(dt * 1e3, 3)
         out['spread'][key] = [round(gaps[0], 3), round(gaps[-1], 3)]           # min / max interval, ms
+        if raw:
+            out.setdefault('raw', {})[key] = [round(a.elapsed_time(b), 3) for a, b in zip(evs[:-1], evs[1:])]
         del student, teacher, runner, opt, loader
         torch.cuda.empty_cache()
     out['imgs_per_iter'] = 2
@@ -423,6 +427,9 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.freeze()          # what dsl_amd.runner does a few iterations into a run (_gc_settle): no generation-2 walk over the op lists
     if 'after' in args.foreign_streams:
         foreign_streams()
         for _ in range(3):

@@ -10,6 +10,7 @@ What changes w.r.t. the reference: the scale-invariant thir
 GPU; EMA is one fused lerp over the flat parameter buffer (no deepcopy, no barriers); the pseudo-label
 refresh runs the teacher and its post-processing on the GPU and keeps the labels in an in-memory
 bank (the reference's per-image JSON layout is kept as an optional export)."""
+import gc
 import json
 import os
 import time
@@ -195,12 +196,27 @@ class SemiEpochBasedRunner:
             self.run_iter(data_batch, train_mode=True, **kw)
             self.call_hook('after_train_iter')
             self._iter += 1
+            self._gc_settle()
         self.call_hook('after_train_epoch')
         self._epoch += 1
+
+    GC_FREEZE_AFTER = 8        # training iterations of a run after which the long-lived heap is frozen (see _gc_settle)
+
+    def _gc_settle(self):
+        """The engine's op lists, descriptors, plans and the modules are some 10^5 long-lived Python objects.  A generation-2
+        collection that walks them stalls the host for tens of milliseconds - longer than its 2 - 3 ms lead over the GPU, so the GPU
+        idles (the 19 / 55 ms intervals of `extra.dsl_iteration.spread` in rounds 4 / 5).  Once everything is built - a few
+        iterations into the run - they move to the permanent generation; run() undoes it."""
+        self._gc_iters = getattr(self, '_gc_iters', 0) + 1
+        if self._gc_iters == self.GC_FREEZE_AFTER and not getattr(self, '_gc_frozen', False):
+            gc.collect()
+            gc.freeze()
+            self._gc_frozen = True
 
     def run(self, data_loaders, workflow=(('train', 1),), max_epochs=None, **kw):
         if max_epochs is not None:
             self._max_epochs = max_epochs
+        self._gc_iters = 0
         self.call_hook('before_run')
         while self._epoch < self._max_epochs:
             for (mode, epochs), loader in zip(workflow, data_loaders):
@@ -209,6 +225,9 @@ class SemiEpochBasedRunner:
                     if self._epoch >= self._max_epochs:
                         break
                     self.train(loader, **kw)
+        if getattr(self, '_gc_frozen', False):
+            gc.unfreeze()
+            self._gc_frozen = False
         self.call_hook('after_run')
 
     @torch.no_grad()

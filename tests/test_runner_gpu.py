@@ -383,7 +383,7 @@ def test_bench_loop_and_train_detector_enqueue_the_same_step(tmp_path):
     assert runner.iter == n_it
     for flag in ('lazy_log', 'eager_backward', 'pipeline_prefix'):
         assert getattr(a, flag) == getattr(det, flag) is True, flag
-    assert a.store.defer_head == det.store.defer_head                # (the deferred head update is opt-in: tuning key defer_head=1)
+    assert a.store.defer_head == det.store.defer_head                # (the deferred head update is opt-in: FlatSGD(defer_head_update=True))
     la, lb = lists(a), lists(det)
     assert la.keys() == lb.keys()
     for k in la:
