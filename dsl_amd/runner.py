@@ -200,13 +200,14 @@ class SemiEpochBasedRunner:
         self.call_hook('after_train_epoch')
         self._epoch += 1
 
-    GC_FREEZE_AFTER = 8        # training iterations of a run after which the long-lived heap is frozen (see _gc_settle)
+    GC_FREEZE_AFTER = 5        # training iterations of a run after which the long-lived heap is frozen (see _gc_settle)
 
     def _gc_settle(self):
         """The engine's op lists, descriptors, plans and the modules are some 10^5 long-lived Python objects.  A generation-2
         collection that walks them stalls the host for tens of milliseconds - longer than its 2 - 3 ms lead over the GPU, so the GPU
-        idles (the 19 / 55 ms intervals of `extra.dsl_iteration.spread` in rounds 4 / 5).  Once everything is built - a few
-        iterations into the run - they move to the permanent generation; run() undoes it."""
+        idles (the 19 / 55 ms intervals of `extra.dsl_iteration.spread` in rounds 4 / 5; the collection below itself takes 40 - 100 ms
+        on this heap: profiles/r05_bench_full_gcfreeze_in_window.log, where it fell into bench.py's timed window).  Once everything
+        is built - the plans are through by iteration 4 - they move to the permanent generation; run() undoes it."""
         self._gc_iters = getattr(self, '_gc_iters', 0) + 1
         if self._gc_iters == self.GC_FREEZE_AFTER and not getattr(self, '_gc_frozen', False):
             gc.collect()
