@@ -760,11 +760,6 @@ class Plan:
             if BB:
                 cd_.workspace, cd_.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
             return cd_
-        self._wgrad(ol, fc[4], gseg[4], p6r, N, [hw7], [hw6], side=SIDE)
-        self._wgrad(ol, fc[3], g_p6, self.feat_seg[2], N, [hw6], [hw5], side=SIDE)
-        self._wgrad(ol, fc[2], g_p5, lat[2], N, [hw5], [hw5], side=SIDE)
-        self._wgrad(ol, fc[1], gseg[1], lat[1], N, [hw4], [hw4], side=SIDE)
-        self._wgrad(ol, fc[0], gseg[0], lat[0], N, [hw3], [hw3], side=SIDE)
         if BB:
             ol.fork(BB)
         # P3, P4 = fpn_i(lat_i); the top-down path's nearest upsampling is a 2x2 sum in the backward direction
@@ -783,6 +778,14 @@ class Plan:
             ol.join(BB)
         ol.conv(self._dgrad(fc[2].name, g_p5, g_lat[2], N, [hw5], [hw5], cs=256, cd=256, k=3, stride=1, pad=1,
                             addend=s1))
+        # the output convolutions' weight gradients: behind the data gradients that produce g_p6 / g_p5 (with side streams they
+        # are collected for the segment's multi launch anyway; on one stream - tuning side=0 - they run right here, and in front of
+        # those data gradients they read buffers nobody had written: found by the side=0 leg of test_train_step_vs_reference_and_oracle)
+        self._wgrad(ol, fc[4], gseg[4], p6r, N, [hw7], [hw6], side=SIDE)
+        self._wgrad(ol, fc[3], g_p6, self.feat_seg[2], N, [hw6], [hw5], side=SIDE)
+        self._wgrad(ol, fc[2], g_p5, lat[2], N, [hw5], [hw5], side=SIDE)
+        self._wgrad(ol, fc[1], gseg[1], lat[1], N, [hw4], [hw4], side=SIDE)
+        self._wgrad(ol, fc[0], gseg[0], lat[0], N, [hw3], [hw3], side=SIDE)
         # laterals -> gradients w.r.t. C3, C4, C5 (masked by the ReLU that produced them)
         self.g_stage = {}
         self._br_pending = False        # side-stream-3 work the next segment must join before it touches g_stage[1], g_stage[2]

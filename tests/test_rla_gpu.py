@@ -111,13 +111,18 @@ def build(**head):
     return model.cuda()
 
 
-def test_rla_train_step_vs_oracle():
-    """FCOS + RLA_ResNet, forward + loss + hand-written backward on the GPU vs the oracle: losses within 3e-3 of the
+@pytest.mark.parametrize('side', ['1', '0'])
+def test_rla_train_step_vs_oracle(monkeypatch, side):
+    """(side = '0': every launch on the caller's stream, tuning key side=0.)
+    FCOS + RLA_ResNet, forward + loss + hand-written backward on the GPU vs the oracle: losses within 3e-3 of the
     bf16-emulating oracle and 1e-3 of fp32, identical assignment, and every parameter gradient (trainable eval-mode BN
     affine terms, shared recurrent / conv_out weights, zero-padded conv1 rows included) no farther from the fp32 gradient than
     1.6 x the bf16-emulating oracle's own distance."""
     from oracle import fcos_oracle as O
     from oracle import rla_oracle as RO
+    from dsl_amd import tuning
+    tuning.tune('side')                                    # (DSL_TUNE parsed before the override below)
+    monkeypatch.setitem(tuning._values, 'side', side)
     model = build()
     assert len(model.state_dict()) == 465
     rng = np.random.RandomState(1)

@@ -20,9 +20,14 @@ def build(**head):
     return model.cuda()
 
 
-@pytest.mark.parametrize('name', ['net_tiny', 'net_small_dsl'])
-def test_train_step_vs_reference_and_oracle(golden, name):
+@pytest.mark.parametrize('name,side', [('net_tiny', '1'), ('net_small_dsl', '1'), ('net_tiny', '0'), ('net_small_dsl', '0')])
+def test_train_step_vs_reference_and_oracle(golden, monkeypatch, name, side):
+    """side = '0': the same step with every launch on the caller's stream (tuning key side=0; ADVICE round 4 asked for a gradient
+    check of the single-stream schedule - both towers' GroupNorm records then meet in one stream order)."""
     from oracle import fcos_oracle as O
+    from dsl_amd import tuning
+    tuning.tune('side')                                    # (DSL_TUNE parsed before the override below)
+    monkeypatch.setitem(tuning._values, 'side', side)
     d = golden(name + '.npz')
     B, dsl = int(d['B']), bool(int(d['dsl']))
     head = dict(loss_weight=3.0, soft_weight=1.0, soft_warm_up=0) if dsl else {}
@@ -50,6 +55,7 @@ def test_train_step_vs_reference_and_oracle(golden, name):
     for k in got:
         assert got[k] == pytest.approx(ol[k], rel=3e-3), (k, got[k], ol[k])
     plan = next(iter(model._engine.plans.values()))
+    assert bool(plan.BR) == (side == '1')
     cls = plan.bufs['cls_logits'].cpu()
     ref_cls = levels_to_flat([c.detach() for c in aux['cls']])
     assert rel_l2(cls, ref_cls) < 5e-3

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-python bench.py > gpurun_out/r05_bench_full.log 2>gpurun_out/r05_bench_full.err; tail -c 1200 gpurun_out/r05_bench_full.log
+(timeout 1500 python -m pytest tests/test_rla_gpu.py -q --tb=short -k "train_step_vs_oracle" 2>&1 | tail -25) | tee gpurun_out/r05_tests_rla_side.log
