@@ -20,14 +20,22 @@ def build(**head):
     return model.cuda()
 
 
-@pytest.mark.parametrize('name,side', [('net_tiny', '1'), ('net_small_dsl', '1'), ('net_tiny', '0'), ('net_small_dsl', '0')])
-def test_train_step_vs_reference_and_oracle(golden, monkeypatch, name, side):
-    """side = '0': the same step with every launch on the caller's stream (tuning key side=0; ADVICE round 4 asked for a gradient
-    check of the single-stream schedule - both towers' GroupNorm records then meet in one stream order)."""
+_KNOBS = [('net_tiny', {}), ('net_small_dsl', {}), ('net_tiny', dict(side='0')), ('net_small_dsl', dict(side='0')),
+          ('net_tiny', dict(img_split='', img_split_bwd='')), ('net_tiny', dict(bneck_fwd='')), ('net_tiny', dict(bneck_fwd='23')),
+          ('net_tiny', dict(pipe_prefix='0')), ('net_small_dsl', dict(tower_slots='128', tail_slots='128'))]
+
+
+@pytest.mark.parametrize('name,knobs', _KNOBS, ids=[n + ''.join(f'-{k}={v}' for k, v in kn.items()) for n, kn in _KNOBS])
+def test_train_step_vs_reference_and_oracle(golden, monkeypatch, name, knobs):
+    """Also under every schedule knob of dsl_amd/tuning.py set away from its default (side=0: every launch on the caller's stream -
+    ADVICE round 4 asked for a gradient check of the single-stream schedule; no image-split chains; unfused / all fused bottleneck
+    stages; inline prefix; other weight-gradient budgets): the same checks against the reference's vectors."""
     from oracle import fcos_oracle as O
     from dsl_amd import tuning
-    tuning.tune('side')                                    # (DSL_TUNE parsed before the override below)
-    monkeypatch.setitem(tuning._values, 'side', side)
+    tuning.tune('side')                                    # (DSL_TUNE parsed before the overrides below)
+    for k_, v_ in knobs.items():
+        monkeypatch.setitem(tuning._values, k_, v_)
+    side = knobs.get('side', '1')
     d = golden(name + '.npz')
     B, dsl = int(d['B']), bool(int(d['dsl']))
     head = dict(loss_weight=3.0, soft_weight=1.0, soft_warm_up=0) if dsl else {}
