@@ -110,6 +110,42 @@ def test_losses_within_1e3_of_fp32_oracle_256x320():
     assert torch.equal(plan.lossplan.assign_idx.cpu().long(), raux['assign_idx'])      # identical indices
 
 
+@pytest.mark.parametrize('B,H,W', [(1, 128, 192), (3, 160, 224), (4, 96, 160), (2, 224, 160)])
+def test_train_step_vs_oracle_other_batch_sizes_and_shapes(B, H, W):
+    """Batch sizes other than the benchmark's 2 (1: no image-split chains; 3 and 4: uneven / even halves) and image sizes whose level
+    grids leave ragged tiles: losses within 3e-3 of the bf16-emulating oracle, identical assignment, every parameter gradient no
+    farther from the fp32 gradient than 1.6 x the bf16-emulating oracle's own distance (the golden test's noise model)."""
+    from oracle import fcos_oracle as O
+    model = build()
+    rng = np.random.RandomState(10 + B)
+    g = torch.Generator().manual_seed(7 + B)
+    img = (torch.randn(B, 3, H, W, generator=g) * 40).bfloat16().float()
+    gtb = [T(O.synth_boxes(rng, 3, H=H, W=W, lo=8, hi=min(H, W))) for _ in range(B)]
+    gtl = [T(rng.randint(0, 80, len(b)).astype('int64')) for b in gtb]
+    losses = model.forward_train(img.cuda(), [dict()] * B, gtb, gtl)
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    got = {k: float(v.detach()) for k, v in losses.items()}
+    sd = O.synth_state_dict(0)
+    ol, og, aux = O.train_step(sd, img, gtb, gtl, None, emulate_bf16=True)
+    for k in got:
+        assert got[k] == pytest.approx(ol[k], rel=3e-3), (k, got[k], ol[k])
+    plan = next(iter(model._engine.plans.values()))
+    _, raux = O.fcos_loss(aux['cls'], aux['reg'], aux['ctr'], gtb, gtl, None, return_aux=True)
+    assert torch.equal(plan.lossplan.labels.cpu(), raux['labels'])
+    assert torch.equal(plan.lossplan.assign_idx.cpu().long(), raux['assign_idx'])
+    _, g32, _ = O.train_step(sd, img, gtb, gtl, None, emulate_bf16=False)
+    named = dict(model.named_parameters())
+    bad = []
+    for k, gref in g32.items():
+        if k not in named or named[k].grad is None or float(gref.norm()) == 0:
+            continue
+        e_hip, e_emu = rel_l2(named[k].grad.cpu(), gref), rel_l2(og[k], gref)
+        if e_hip > 1.6 * e_emu + 5e-3:
+            bad.append((k, float(e_hip), float(e_emu)))
+    assert not bad, bad[:10]
+
+
 def test_sgd_step_and_ema_on_flat_store():
     from dsl_amd.optim import FlatSGD
     from oracle import fcos_oracle as O
