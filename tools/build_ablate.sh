@@ -6,7 +6,10 @@ set -e
 cd "$(dirname "$0")/.."
 python -c "from dsl_amd.build import build_lib; build_lib(verbose=False)" 2>/dev/null
 mkdir -p dsl_amd/lib/ablate
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DDSL_ABLATE_BUILD -Iinclude -c dsl_amd/csrc/conv.hip -o dsl_amd/lib/ablate/conv.o 2>/dev/null
-objs=$(ls dsl_amd/lib/*.o | grep -v "/conv.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs dsl_amd/lib/ablate/conv.o -o dsl_amd/lib/libdsl_hip_ablate.so
+for f in conv wgrad bneck; do      # the three sources that carry ablation knobs (bneck: DSL_BNECK_DBG = 1 / 2, phase cut-offs)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DDSL_ABLATE_BUILD -Iinclude -c dsl_amd/csrc/$f.hip -o dsl_amd/lib/ablate/$f.o 2>/dev/null &
+done
+wait
+objs=$(ls dsl_amd/lib/*.o | grep -v "/conv.o\|/wgrad.o\|/bneck.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs dsl_amd/lib/ablate/conv.o dsl_amd/lib/ablate/wgrad.o dsl_amd/lib/ablate/bneck.o -ldl -o dsl_amd/lib/libdsl_hip_ablate.so
 echo built dsl_amd/lib/libdsl_hip_ablate.so
