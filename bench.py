@@ -614,6 +614,7 @@ def main():
                            'streams are created AND picked by the C library (csrc/api.hip side_init: a spin-kernel probe finds three on hardware queues of their own); tests/test_stream_layout_gpu.py runs '
                            'the before / after variants in fresh processes')
         foreign.clear()
+    gc.unfreeze()        # (the extras below build and drop models of their own; their runs freeze and unfreeze by themselves)
     if rank == 0 and world == 1 and not args.no_dsl:
         del opt
         # (train_detector last: every model instance creates streams, and stream creation order decides which streams share one of
