@@ -133,6 +133,73 @@ def fp8_step_timing(batch, steps=20, warm=5):
                      'v_mfma_scale_f32_32x32x64_f8f6f4, everything else (and the whole backward pass) bf16; off by default in the product')
 
 
+def comm_proxy_timing(batch, steps=20, warm=5, rounds=3, wgs=32, passes=2, carriers=('lib', 'torch')):
+    """Multi-GPU first contact de-risked on ONE GPU (the reference's DDP: mmdet/apis/train.py:92-96): the
+    headline's step in its data-parallel schedule - named bucket events, communication stream, per-bucket optimizer steps behind each
+    bucket's exchange - with dsl_comm_proxy in place of the all-reduce: `wgs` workgroups making `passes` read-modify-write passes
+    over the bucket (RCCL's ring: one workgroup per channel; reduce-scatter + all-gather each read and write the bucket once), on
+    (lib) the library's PLACED communication stream - the C-ABI carrier's, comm='rccl' - and (torch) a stream from torch's pool, as
+    ProcessGroupNCCL runs its kernels on one of its own.  No xGMI, no peer latency: what is measured is what the collectives' device
+    footprint and their stream cost the backward pass.  Alternated `rounds` times on one model; medians."""
+    import statistics
+    from dsl_amd import _lib as L
+    from dsl_amd.data import mark_ready
+    from dsl_amd.optim import FlatSGD
+    from dsl_amd.registry import build_detector
+    _release_earlier_models()
+    model = build_detector(model_cfg()).cuda()
+    opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+    ev = torch.cuda.Event()
+    ev.record()
+
+    def step():
+        mark_ready(batch['img'], event=ev)
+        out = model.train_step(batch, opt)
+        out['loss'].backward()
+        opt.step()
+        return out
+
+    def run(mode):
+        model.comm_proxy = None if mode == 'none' else dict(carrier=mode, wgs=wgs, passes=passes)
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    modes = ('none',) + tuple(carriers)
+    res = {m: [] for m in modes}
+    for _ in range(rounds):
+        for m in modes:
+            res[m].append(run(m))
+    model.comm_proxy = None
+    # the proxy alone: what each bucket's stand-in costs on an idle chip (its own "bus bandwidth")
+    st = model.store
+    alone = []
+    for lo, hi in st.grad_buckets():
+        g = st.grad[lo:hi]
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        L.check(L.lib.dsl_comm_proxy(L.ptr(g), (hi - lo) // 4 * 4, wgs, passes, L.stream_ptr()), 'dsl_comm_proxy')
+        a.record()
+        L.check(L.lib.dsl_comm_proxy(L.ptr(g), (hi - lo) // 4 * 4, wgs, passes, L.stream_ptr()), 'dsl_comm_proxy')
+        b.record()
+        torch.cuda.synchronize()
+        alone.append(dict(mb=round((hi - lo) * 4 / 1e6, 1), ms=round(a.elapsed_time(b), 3)))
+    med = {m: statistics.median(v) for m, v in res.items()}
+    out = dict(ms_per_step={m: round(v, 3) for m, v in med.items()}, runs={m: [round(x, 3) for x in v] for m, v in res.items()},
+               cost_frac={m: round(med[m] / med['none'] - 1.0, 4) for m in modes if m != 'none'},
+               comm_stream_queue=int(L.lib.dsl_comm_stream_queue()), proxy=dict(workgroups=wgs, passes=passes, buckets_alone=alone),
+               note='one GPU, no peer: dsl_comm_proxy (value-preserving passes over each gradient bucket) stands in for the all-reduce '
+                    'behind the same bucket events; lib = the library\'s communication stream, placed on the hardware queue '
+                    'comm_stream_queue names (1 weight gradients, 2 second chain, 3 frozen prefix, 4 caller, 0 = as the runtime dealt it), '
+                    'torch = a torch-pool stream as ProcessGroupNCCL uses; cost_frac = median step time / median without proxy - 1')
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 class _ResidentLoader:
     """A loader (dsl_amd/data.py contract: __iter__ / __len__ yielding batch dicts) that yields ONE HBM-resident batch n times and
     stamps the wall clock (device drained) in front of batch `warm` and behind the last one."""
@@ -621,6 +688,7 @@ def main():
         # the four hardware queues - DESIGN 3.2i; the semi-supervised variants keep the order their round-3 numbers were taken in)
         extra = dict(dsl_iteration=dsl_iteration_timing(), fp8_towers=fp8_step_timing(batch), datapath=datapath_timing())
         extra['train_detector'] = train_detector_timing(batch, steps=60, warm=10)
+        extra['comm_proxy'] = comm_proxy_timing(batch)
         extra['stream_layout_check'] = layout
         if roof is not None:        # BASELINE.json configs[2] beside the headline, also where a record that keeps `roofline` keeps it
             roof['configs2_dsl_iteration_ms'] = {k: v for k, v in extra['dsl_iteration'].items() if k.startswith('ms_per_iter')}
@@ -635,7 +703,8 @@ def main():
                                    f'{args.imgs_per_gpu} x (3,800,1344) per GPU, synthetic COCO-shaped boxes, '
                                    'random-init weights', 'global_batch': args.imgs_per_gpu * world,
                        'parallelism': f'dp{world}', 'optimizer': 'SGD momentum 0.9 wd 1e-4'},
-            'roofline': roof, 'cpu_baseline': cpu, 'extra': extra, 'final_losses': log}))
+            'roofline': roof, 'cpu_baseline': cpu, 'extra': extra, 'final_losses': log,
+            'streams_on_own_queues': _streams_probe(), 'comm_stream_queue': int(L.lib.dsl_comm_stream_queue())}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -65,7 +65,8 @@ class WgradDesc(C.Structure):
                 ('splits', C.c_int32),
                 ('dy', C.c_void_p), ('x', C.c_void_p), ('scale', C.c_void_p), ('dw', C.c_void_p),
                 ('db', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
-                ('ldx', C.c_int32), ('shared', C.c_int32), ('slots', C.c_int32), ('pad_', C.c_int32)]
+                ('ldx', C.c_int32), ('shared', C.c_int32), ('slots', C.c_int32), ('pad_', C.c_int32),
+                ('pixtab', C.c_void_p), ('pixtab_bytes', C.c_size_t)]
 
 
 class GnDesc(C.Structure):
@@ -156,6 +157,8 @@ class Op(C.Structure):
 
 lib.dsl_last_error.restype = C.c_char_p
 lib.dsl_wgrad_workspace_bytes.restype = C.c_size_t
+if hasattr(lib, 'dsl_wgrad_pixtab_bytes'):
+    lib.dsl_wgrad_pixtab_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_wgrad_group_workspace_bytes'):
     lib.dsl_wgrad_group_workspace_bytes.restype = C.c_size_t
 lib.dsl_conv2d_workspace_bytes.restype = C.c_size_t
@@ -173,7 +176,7 @@ if hasattr(lib, 'dsl_detect_workspace_bytes'):
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
     'dsl_conv2d': [_vp, _vp], 'dsl_conv2d_workspace_bytes': [_vp], 'dsl_conv2d_gn_fusable': [_vp], 'dsl_conv2d_wgrad': [_vp, _vp], 'dsl_wgrad_splits': [_vp],
-    'dsl_wgrad_workspace_bytes': [_vp], 'dsl_wgrad_group_workspace_bytes': [_vp, _i], 'dsl_conv2d_wgrad_group': [_vp, _i, _vp],
+    'dsl_wgrad_workspace_bytes': [_vp], 'dsl_wgrad_pixtab_bytes': [_vp], 'dsl_wgrad_pixtab_fill': [_vp, _vp, C.c_size_t, _vp], 'dsl_wgrad_group_workspace_bytes': [_vp, _i], 'dsl_conv2d_wgrad_group': [_vp, _i, _vp],
     'dsl_wgrad_multi_config': [_vp], 'dsl_wgrad_multi_table_bytes': [], 'dsl_wgrad_multi_workspace_bytes': [_vp, _vp, _i],
     'dsl_wgrad_multi_build': [_vp, _vp, _i, _vp, C.c_size_t, _vp, C.c_size_t], 'dsl_conv2d_wgrad_multi': [_vp, _vp, _vp], 'dsl_wgrad_multi_info': [_vp, _vp, _vp, _vp, _vp, _vp],
     'dsl_wgrad_plan_probe': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
@@ -210,7 +213,7 @@ _SIGS = {
     'dsl_pseudo_label_fuse_history': [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
     'dsl_bottleneck_fwd': [_vp, _vp], 'dsl_bottleneck_fwd_supported': [_vp],
     'dsl_set_option': [C.c_char_p, _i], 'dsl_get_option': [C.c_char_p, _vp],
-    'dsl_run_ops': [_vp, _i, _vp], 'dsl_stream_wait_slot': [_i, _vp], 'dsl_stream_record_slot': [_i, _vp], 'dsl_side_stream': [_i, _vp], 'dsl_streams_init': [_vp, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_prof_read2': [_vp, _vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
+    'dsl_run_ops': [_vp, _i, _vp], 'dsl_stream_wait_slot': [_i, _vp], 'dsl_stream_record_slot': [_i, _vp], 'dsl_side_stream': [_i, _vp], 'dsl_streams_init': [_vp, _vp], 'dsl_comm_stream_queue': [], 'dsl_comm_proxy': [_vp, C.c_longlong, _i, _i, _vp], 'dsl_prof_enable': [_i], 'dsl_prof_reset': [], 'dsl_prof_read': [_vp, _vp, _vp], 'dsl_prof_read2': [_vp, _vp, _vp, _vp], 'dsl_probe_tr16': [_vp, _vp, _vp, _vp], 'dsl_probe_xcc': [_vp, _vp, _i, _vp], 'dsl_probe_cu_mask': [_vp, _i, _vp, _i],
 }
 MISSING = []
 for _name, _args in _SIGS.items():

@@ -29,6 +29,10 @@ Option g_options[] = {
     {"stream_probe", 1},     // 0: the library takes its streams as the runtime deals them instead of probing for distinct hardware queues
     {"debug_sync", 0},       // 1: drain the device after every op of dsl_run_ops and name it on stderr
     {"skip_kinds", 0},       // step-level ablation (tools/step_ablation.sh): bit mask of op kinds dsl_run_ops does not launch - timing only
+    {"comm_queue", 3},       // which hardware queue the communication stream (dsl_side_stream(5)) is PLACED on (round 6; read at side_init):
+                             // 0 = any unused candidate (rounds 3 - 5), 1 = the weight-gradient stream's queue, 2 = the second chain's,
+                             // 3 = the frozen prefix's, 4 = the caller's.  A fifth busy queue collapses the step, so the
+                             // collectives must share one of the four; default and measurement: DESIGN section 6
 };
 }  // namespace
 int dsl_option(const char* name) {
@@ -72,6 +76,7 @@ hipEvent_t g_ev[16][kEvRing] = {};
 int g_evpos[16] = {};
 bool g_init[16] = {};
 int g_probe_result[16] = {};            // distinct-queue streams found by the probe (3 = all), -1 = probe off
+int g_comm_queue[16] = {};              // where the communication stream was placed (option comm_queue's value; 0 = as the runtime dealt it)
 hipEvent_t g_named[16][16] = {};        // DSL_OP_RECORD / DSL_OP_WAIT slots
 bool g_named_set[16][16] = {};
 
@@ -112,6 +117,9 @@ void side_init(int dev, hipStream_t caller) {
       if (ok) { chosen[n++] = cand[i]; used[i] = true; }
     }
     g_probe_result[dev] = n;
+    if (n < kNeed)       // (say so - the layout then is whatever the runtime dealt, worth up to 20 % of a step)
+      fprintf(stderr, "[libdsl_hip] stream probe: only %d of %d side streams found a hardware queue of their own (device %d); "
+                      "dsl_streams_init reports the count\n", n, kNeed, dev);
   } else {
     g_probe_result[dev] = -1;
   }
@@ -125,7 +133,19 @@ void side_init(int dev, hipStream_t caller) {
   g_side[dev][1] = chosen[1];                    // second tower ...
   g_side[dev][2] = chosen[1];                    // ... and second image chain: one stream
   g_side[dev][3] = chosen[2];                    // frozen prefix
-  g_side[dev][4] = take();                       // communication
+  // Communication stream: on a hardware queue the library CHOOSES (option comm_queue) - a candidate that does NOT run concurrently
+  // with that queue's owner.  With four queues taken by the caller and the three streams above, every further stream shares one of
+  // them; which one the runtime's round-robin deals was left to chance until round 6
+  hipStream_t comm = nullptr;
+  g_comm_queue[dev] = 0;
+  const int want = dsl_option("comm_queue");
+  if (g_probe_result[dev] == kNeed && want >= 1 && want <= 4) {
+    hipEvent_t ea = g_ev[dev][kEvRing - 1], eb = g_ev[dev][kEvRing - 2];
+    hipStream_t owner = want == 4 ? caller : chosen[want - 1];
+    for (int i = 0; i < kCand && !comm; ++i)
+      if (!used[i] && !streams_concurrent(owner, cand[i], ea, eb)) { comm = cand[i]; used[i] = true; g_comm_queue[dev] = want; }
+  }
+  g_side[dev][4] = comm ? comm : take();         // communication
   g_side[dev][5] = take();                       // teacher sweep
   for (int i = 0; i < kCand; ++i)
     if (!used[i]) hipStreamDestroy(cand[i]);
@@ -304,6 +324,42 @@ extern "C" int dsl_streams_init(void* caller_stream, int* distinct_out) {
   DSL_CHECK(dev >= 0 && dev < 16, "dsl_streams_init: device index %d out of range", dev);
   side_init(dev, (hipStream_t)caller_stream);
   if (distinct_out) *distinct_out = g_probe_result[dev];
+  return 0;
+}
+
+// Where the communication stream sits: 1 = the weight-gradient stream's hardware queue, 2 = the second chain's, 3 = the frozen prefix's,
+// 4 = the caller's, 0 = not placed (probe off / no candidate found: as the runtime dealt it).
+extern "C" int dsl_comm_stream_queue(void) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !g_init[dev]) return -1;
+  return g_comm_queue[dev];
+}
+
+// ---- communication proxy (bench.py extra.comm_proxy, tests/test_comm_proxy_gpu.py) -------------------------------------------------
+// What a ring all-reduce of `n` floats costs the DEVICE beside the backward pass, without a second GPU: `wgs` workgroups (RCCL: one
+// per channel) make `passes` read-modify-write passes over the bucket (x *= 1.0f: the gradients keep their bits), i.e. the HBM
+// traffic of reduce-scatter + all-gather and the CUs RCCL's kernels hold while they run.  No xGMI traffic, no peer latency.
+namespace {
+__global__ __launch_bounds__(512) void comm_proxy_kernel(float* __restrict__ g, long long n4, int passes, float one) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4* p = reinterpret_cast<f4*>(g);
+  for (int r = 0; r < passes; ++r) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+      f4 v = __builtin_nontemporal_load(p + i);
+      v *= one;          // (a run-time 1.0f: not folded away, and every bit pattern - signed zeros too - survives)
+      __builtin_nontemporal_store(v, p + i);
+    }
+    __threadfence();
+  }
+}
+}  // namespace
+extern "C" int dsl_comm_proxy(float* buf, long long n, int wgs, int passes, void* stream) {
+  DSL_CHECK(buf != nullptr && n >= 0 && ((uintptr_t)buf & 15) == 0 && wgs >= 1 && wgs <= 1024 && passes >= 1,
+            "dsl_comm_proxy: bad arguments (n %lld wgs %d passes %d)", n, wgs, passes);
+  if (n < 4) return 0;
+  hipLaunchKernelGGL(comm_proxy_kernel, dim3(wgs), dim3(512), 0, (hipStream_t)stream, buf, n / 4, passes, 1.0f);
+  DSL_LAUNCH_CHECK("comm_proxy_kernel");
   return 0;
 }
 

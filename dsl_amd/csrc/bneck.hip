@@ -573,6 +573,12 @@ extern "C" int dsl_bottleneck_fwd_supported(const dsl_bneck_desc* d) {
   if (d->stride != 1 && d->stride != 2) return 0;
   if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->hin < (d->h - 1) * d->stride + 1 || d->win < (d->w - 1) * d->stride + 1) return 0;
   if ((long long)d->n * d->hin * d->win * d->ldx * 2 >= 0x7fff0000LL || (long long)d->n * d->h * d->w * d->ldi * 2 >= 0x7fff0000LL) return 0;
+  // a1 / a2 / out leave through 32-bit buffer offsets in 16-byte chunks as well: an `out` extent past 2 GiB (ldo > ldi)
+  // would be dropped silently by the out-of-range rule, a pointer off a 16-byte boundary would fault
+  if ((long long)d->n * d->h * d->w * d->ldo * 2 >= 0x7fff0000LL) return 0;
+  const void* ptrs[] = {d->x, d->idt, d->a1, d->a2, d->out, d->w1, d->w2, d->w3};
+  for (const void* q : ptrs)
+    if (q && ((uintptr_t)q & 15)) return 0;
   return 1;
 }
 

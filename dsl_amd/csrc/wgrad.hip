@@ -1206,18 +1206,38 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, const RedK r, 
 
 }  // namespace
 
-// ---- v3 weight gradient: per-geometry pixel descriptor tables (PixDesc), built on the host once per geometry and kept
-// in device memory for the life of the process (a few hundred KB per geometry; a training run has ~20 geometries)
+// ---- v3 weight gradient: per-geometry pixel descriptor tables (PixDesc).  The table lives in CALLER-OWNED device memory
+// (dsl_wgrad_desc.pixtab, >= dsl_wgrad_pixtab_bytes): dsl_wgrad_pixtab_fill writes it with a kernel on the caller's stream, once per
+// geometry; the library allocates nothing and copies nothing (until round 6 it kept a process-lifetime hipMalloc'd cache here)
 namespace {
 constexpr int kWgV3KS = 32, kWgV3DR = 16;
-struct PixTabEntry {
-  int dev, nseg, n, stride, pad, kh, kw;
+struct PixGeo {
+  int nseg, n, stride, pad, kh, kw;
   int gh[DSL_MAX_SEG], gw[DSL_MAX_SEG], sh[DSL_MAX_SEG], sw[DSL_MAX_SEG];
-  void* ptr;
-  unsigned bytes;
+  int pxstart[DSL_MAX_SEG + 1];
+  long long xoff[DSL_MAX_SEG];
 };
-std::mutex g_pixtab_mu;
-std::vector<PixTabEntry> g_pixtabs;
+__global__ void pixtab_fill_kernel(PixDesc* __restrict__ out, PixGeo g) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.pxstart[g.nseg]) return;
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < DSL_MAX_SEG; ++t)
+    if (t < g.nseg && i >= g.pxstart[t]) s = t;
+  const int gh = g.gh[s], gw = g.gw[s], sh = g.sh[s], sw = g.sw[s];
+  int r = i - g.pxstart[s];
+  const int img = r / (gh * gw);
+  r -= img * gh * gw;
+  const int y = r / gw, x = r - y * gw;
+  const int y0 = y * g.stride - g.pad, x0 = x * g.stride - g.pad;
+  unsigned ym = 0, xm = 0;
+  for (int a = 0; a < g.kh; ++a) if ((unsigned)(y0 + a) < (unsigned)sh) ym |= 1u << a;
+  for (int c = 0; c < g.kw; ++c) if ((unsigned)(x0 + c) < (unsigned)sw) xm |= 1u << c;
+  PixDesc e;
+  e.base = (int32_t)(g.xoff[s] + ((long long)img * sh + y0) * sw + x0);
+  e.info = ((unsigned)sw << 16) | (xm << 8) | ym;
+  out[i] = e;
+}
 
 int wgrad_slots();
 bool wgrad_persist() {
@@ -1240,54 +1260,13 @@ bool wgrad_v3_ok(const dsl_wgrad_desc* d, int cfg) {
   const long long ldx = d->ldx > 0 ? d->ldx : d->cs;
   return px * d->cy * 2 < 0x7fff0000LL && xo * ldx * 2 < 0x7fff0000LL && px < (1 << 20);
 }
-// returns the device table of d's geometry (building it on first use), or nullptr on failure
-const void* wgrad_pixtab(const dsl_wgrad_desc* d, unsigned* bytes) {
-  int dev = 0;
-  hipGetDevice(&dev);
-  std::lock_guard<std::mutex> lk(g_pixtab_mu);
-  for (const PixTabEntry& e : g_pixtabs) {
-    if (e.dev != dev || e.nseg != d->nseg || e.n != d->n || e.stride != d->stride || e.pad != d->pad || e.kh != d->kh || e.kw != d->kw) continue;
-    bool same = true;
-    for (int s = 0; s < d->nseg; ++s)
-      same = same && e.gh[s] == d->gh[s] && e.gw[s] == d->gw[s] && e.sh[s] == d->sh[s] && e.sw[s] == d->sw[s];
-    if (same) { *bytes = e.bytes; return e.ptr; }
-  }
-  long long px = 0;
-  for (int s = 0; s < d->nseg; ++s) px += (long long)d->n * d->gh[s] * d->gw[s];
-  std::vector<PixDesc> h((size_t)px);
-  long long xoff = 0;
-  size_t i = 0;
-  for (int s = 0; s < d->nseg; ++s) {
-    const int sh = d->sh[s], sw = d->sw[s];
-    for (int img = 0; img < d->n; ++img)
-      for (int y = 0; y < d->gh[s]; ++y)
-        for (int x = 0; x < d->gw[s]; ++x) {
-          const int y0 = y * d->stride - d->pad, x0 = x * d->stride - d->pad;
-          unsigned ym = 0, xm = 0;
-          for (int r = 0; r < d->kh; ++r) if ((unsigned)(y0 + r) < (unsigned)sh) ym |= 1u << r;
-          for (int c = 0; c < d->kw; ++c) if ((unsigned)(x0 + c) < (unsigned)sw) xm |= 1u << c;
-          h[i].base = (int32_t)(xoff + ((long long)img * sh + y0) * sw + x0);
-          h[i].info = ((unsigned)sw << 16) | (xm << 8) | ym;
-          ++i;
-        }
-    xoff += (long long)d->n * sh * sw;
-  }
-  PixTabEntry e;
-  memset(&e, 0, sizeof(e));
-  e.dev = dev; e.nseg = d->nseg; e.n = d->n; e.stride = d->stride; e.pad = d->pad; e.kh = d->kh; e.kw = d->kw;
-  for (int s = 0; s < d->nseg; ++s) { e.gh[s] = d->gh[s]; e.gw[s] = d->gw[s]; e.sh[s] = d->sh[s]; e.sw[s] = d->sw[s]; }
-  e.bytes = (unsigned)(px * sizeof(PixDesc));
-  if (hipMalloc(&e.ptr, e.bytes + 256) != hipSuccess) return nullptr;
-  if (hipMemcpy(e.ptr, h.data(), e.bytes, hipMemcpyHostToDevice) != hipSuccess) { hipFree(e.ptr); return nullptr; }
-  g_pixtabs.push_back(e);
-  *bytes = e.bytes;
-  return e.ptr;
-}
 int wgrad_v3_fill(const dsl_wgrad_desc* d, WgK& k, long long px) {
-  unsigned tb = 0;
-  k.pixtab = wgrad_pixtab(d, &tb);
-  DSL_CHECK(k.pixtab != nullptr, "dsl_conv2d_wgrad: could not build the pixel descriptor table");
-  k.pixtab_bytes = tb;
+  const size_t need = (size_t)px * sizeof(PixDesc);
+  DSL_CHECK(d->pixtab != nullptr && d->pixtab_bytes >= need,
+            "dsl_conv2d_wgrad: this geometry runs the pipelined kernel and needs dsl_wgrad_desc.pixtab (%zu bytes given, %zu needed: "
+            "dsl_wgrad_pixtab_bytes / dsl_wgrad_pixtab_fill)", d->pixtab ? d->pixtab_bytes : (size_t)0, need);
+  k.pixtab = d->pixtab;
+  k.pixtab_bytes = (unsigned)need;
   k.ybytes = (unsigned)(px * d->cy * 2);
   return 0;
 }
@@ -1360,6 +1339,38 @@ static int wgrad_splits_for(const dsl_wgrad_desc* d, int count) {
 }
 
 extern "C" int dsl_wgrad_splits(const dsl_wgrad_desc* d) { return wgrad_splits_for(d, 1); }
+
+// Pixel descriptor table of d's geometry (the pipelined kernels' gather addresses): size and fill.  0 bytes: this geometry runs a
+// kernel that needs none.
+extern "C" size_t dsl_wgrad_pixtab_bytes(const dsl_wgrad_desc* d) {
+  if (d == nullptr || d->nseg < 1 || d->nseg > DSL_MAX_SEG) return 0;
+  if (!wgrad_v3_ok(d, wgrad_pick(d))) return 0;
+  long long px = 0;
+  for (int s = 0; s < d->nseg; ++s) px += (long long)d->n * d->gh[s] * d->gw[s];
+  return (size_t)px * sizeof(PixDesc);
+}
+extern "C" int dsl_wgrad_pixtab_fill(const dsl_wgrad_desc* d, void* table, size_t bytes, void* stream) {
+  DSL_CHECK(d != nullptr && d->nseg >= 1 && d->nseg <= DSL_MAX_SEG, "dsl_wgrad_pixtab_fill: bad descriptor");
+  const size_t need = dsl_wgrad_pixtab_bytes(d);
+  if (need == 0) return 0;
+  DSL_CHECK(table != nullptr && bytes >= need, "dsl_wgrad_pixtab_fill: table too small (%zu < %zu)", bytes, need);
+  PixGeo g;
+  memset(&g, 0, sizeof(g));
+  g.nseg = d->nseg; g.n = d->n; g.stride = d->stride; g.pad = d->pad; g.kh = d->kh; g.kw = d->kw;
+  int px = 0;
+  long long xo = 0;
+  for (int s = 0; s < d->nseg; ++s) {
+    g.gh[s] = d->gh[s]; g.gw[s] = d->gw[s]; g.sh[s] = d->sh[s]; g.sw[s] = d->sw[s];
+    g.pxstart[s] = px;
+    g.xoff[s] = xo;
+    px += d->n * d->gh[s] * d->gw[s];
+    xo += (long long)d->n * d->sh[s] * d->sw[s];
+  }
+  for (int s = d->nseg; s <= DSL_MAX_SEG; ++s) g.pxstart[s] = px;
+  hipLaunchKernelGGL(pixtab_fill_kernel, dim3((px + 255) / 256), dim3(256), 0, (hipStream_t)stream, (PixDesc*)table, g);
+  DSL_CHECK(hipGetLastError() == hipSuccess, "dsl_wgrad_pixtab_fill: launch failed");
+  return 0;
+}
 
 static size_t wgrad_cy_pad(const dsl_wgrad_desc* d) {       // rows of one partial tile set in the workspace
   int ktiles, tiles, bco;

@@ -238,15 +238,17 @@ def role_stream(role, device=None):
     return st
 
 
-def _check_grad_now(det):
+def _check_grad_now(det, who='total'):
     """Should this backward call verify its incoming gradient (one host sync)?  Always when the step syncs anyway or the tuning key
-    asks for it; otherwise on the detector's first three backward calls only."""
+    asks for it; otherwise on the first three backward calls of EACH autograd bridge (`who`: one backward pass goes through
+    _TotalFn and _TrainStepFn - a budget shared between them was spent within two passes)."""
     from .tuning import tune
     if not det.lazy_log or tune('check_backward_grad') != '0':
         return True
-    left = getattr(det, '_grad_checks_left', 3)
+    budget = det.__dict__.setdefault('_grad_checks_left', {})
+    left = budget.get(who, 3)
     if left > 0:
-        det._grad_checks_left = left - 1
+        budget[who] = left - 1
         return True
     return False
 
@@ -303,7 +305,7 @@ class _TrainStepFn(torch.autograd.Function):
         backward calls (a loop that scales its loss does so from the first step on) and on every step under the tuning key
         check_backward_grad=1; fold a constant factor into `FCOS.loss_scale` instead."""
         det = ctx.det
-        if _check_grad_now(det):
+        if _check_grad_now(det, 'train_step'):
             k = ctx.n_losses
             gh = g.tolist()       # d(total)/d(term) = 1 for every term: either through the terms or through the kernel's own sum
             if not (all(v == 1 for v in gh[:k]) and gh[k] == 0) and not (all(v == 0 for v in gh[:k]) and gh[k] == 1):
@@ -356,7 +358,7 @@ class FCOS(nn.Module):
         # log-variable ops) instead of when `loss.backward()` reaches the autograd bridge.  The gradient of the summed loss is 1
         # either way - the bridge ignores its incoming gradient - so only the launch order changes.  For loops that call
         # loss.backward() once per train_step, as mmcv's OptimizerHook does (mmdet/apis/train.py:126-176); a caller that scales the
-        # loss tensor instead of FCOS.loss_scale must set this False (DSL_CHECK_BACKWARD_GRAD=1 checks the incoming gradient).
+        # loss tensor instead of FCOS.loss_scale must set this False (tuning key check_backward_grad=1 checks the incoming gradient on every step; by default the first three are checked).
         # A direct forward_train() call (no train_step around it) stays lazy unless eager_backward == 'always'.
         self.eager_backward = True
         self._in_train_step, self._deferred_plan = False, None
@@ -374,6 +376,13 @@ class FCOS(nn.Module):
         # data-parallel options (set by HipDistributedDataParallel)
         self.grad_bf16 = False        # gradient buckets cross xGMI as bf16 copies (half the bytes); master gradient, norm, update stay fp32
         self.comm_off = False         # DSL_COMM=none / bench.py's attribution probe: every collective skipped (timing only - WRONG gradients)
+        # Communication proxy (one-GPU measurement of what the collectives cost the DEVICE; bench.py extra.comm_proxy):
+        # dict(carrier='lib' | 'torch', wgs=32, passes=2).  The step then runs its data-parallel schedule - bucket events, communication
+        # stream, per-bucket optimizer steps behind each bucket's "all-reduce" - with dsl_comm_proxy (value-preserving passes over the
+        # bucket on `wgs` workgroups) in place of RCCL; carrier 'lib' = the library's placed communication stream (what comm='rccl'
+        # uses), 'torch' = a stream from torch's pool, as ProcessGroupNCCL runs its kernels on one of its own
+        self.comm_proxy = None
+        self._proxy_stream = None
         self.clip_partials = None     # [buckets * SUMSQ_PARTS] floats: FlatSGD with grad_clip asks for the norm in pieces, per bucket
         self._partials_valid = False
         self._g16 = None
@@ -566,10 +575,13 @@ class FCOS(nn.Module):
         hooks do at mmdet/apis/train.py:92-96); only the last, smallest bucket (layer2, 5 MB) is exposed."""
         self._pending = []
         self._last_bwd_infos = [info for _, info in plan.bwd_segments]      # bucket ranges / event slots, for the optimizer
-        ddp = self.world_size > 1 and not self.comm_off
+        proxy = self.comm_proxy if (self.comm_proxy and self.world_size == 1 and self.store.grad.is_cuda) else None
+        ddp = (self.world_size > 1 and not self.comm_off) or proxy is not None
         on_gpu = self.store.grad.is_cuda
         if ddp and on_gpu and self._comm_stream is None:
             self._comm_stream = role_stream('comm', self.store.device)
+        if proxy is not None and proxy.get('carrier', 'lib') == 'torch' and self._proxy_stream is None:
+            self._proxy_stream = torch.cuda.Stream()
         self._partials_valid = False
         nb = 0
         for ol, info in plan.bwd_segments:
@@ -582,12 +594,19 @@ class FCOS(nn.Module):
                 continue
             from . import _lib as L
             from .parallel import StreamWork
-            cs = self._comm_stream
+            cs = self._proxy_stream if (proxy is not None and proxy.get('carrier', 'lib') == 'torch') else self._comm_stream
             csp = C_void(cs.cuda_stream)
             L.check(min(L.lib.dsl_stream_wait_slot(info['slot'], csp), 0), 'dsl_stream_wait_slot')
             if info['main']:
                 cs.wait_stream(torch.cuda.current_stream())
             g = self.store.grad[lo:hi]
+            if proxy is not None:
+                # the bucket's stand-in collective (no peer: the values stay): same stream, same event, same optimizer hand-over
+                L.check(L.lib.dsl_comm_proxy(L.ptr(g), (hi - lo) // 4 * 4, int(proxy.get('wgs', 32)), int(proxy.get('passes', 2)), csp),
+                        'dsl_comm_proxy')
+                self._pending.append(StreamWork(cs))
+                nb += 1
+                continue
             with torch.cuda.stream(cs):
                 if self.comm_trace:
                     es = torch.cuda.Event(enable_timing=True)

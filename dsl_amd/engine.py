@@ -400,7 +400,7 @@ class Plan:
         cv = st.convs
         self.blocks = []        # per block: dict(xin, a1, a2, out, idt, in_hw, out_hw, prefix, stride)
         self._pp = {}           # descriptors that touch layer1's output (pipelined prefix: two buffers, patched per step)
-        # Image-split stages (DSL_IMG_SPLIT; measured in round 3's first half: none 372.6, 3: 384.0, 34: 383.4, 4: 372.1, 23: -0.5 % vs 3; re-measured on
+        # Image-split stages (tuning key img_split; measured in round 3's first half: none 372.6, 3: 384.0, 34: 383.4, 4: 372.1, 23: -0.5 % vs 3; re-measured on
         # the final kernels, two boxes, both orders (profiles/r03_step_boundary.txt): 3: 416.8 / 432.1, 34: 420.3 / 435.1, 23: 420.0, 24: 420.9 (second
         # box), 234: 420.9 / 436.2 img/s -> default layer2 + layer3 + layer4, + 1 %;
         # profiles/r03b_* are the profiles of this setting, r03_* those of the layer3 split): their launches are 66-132 workgroups of 15-40 us - mostly
@@ -414,7 +414,7 @@ class Plan:
             d_.workspace, d_.workspace_bytes = L.ptr(self.conv_ws_br), self.conv_ws_br.numel()
             return d_
         for li, (planes, nb) in enumerate(zip(STAGE_PLANES, STAGE_BLOCKS)):
-            # Fused stages (tuning key bneck_fwd, default layer2 + layer3): every bottleneck's forward pass is ONE launch over the whole
+            # Fused stages (tuning key bneck_fwd, default layer2; '23' adds layer3): every bottleneck's forward pass is ONE launch over the whole
             # batch (dsl_bottleneck_fwd, csrc/bneck.hip) - the image-split chains of three launches per block and half are its predecessor
             fuse = str(li + 1) in tune('bneck_fwd') and planes in (128, 256)
             split = str(li + 1) in SPLIT and not fuse
@@ -839,7 +839,7 @@ class Plan:
             planes = blks[0]['planes']
             g_pre = self.g_stage[li]          # gradient w.r.t. the (pre-ReLU-masked) output of the stage's last block
             g3, g2, g1 = [], [], []           # same-geometry weight gradients of this stage's blocks
-            # image-split data-gradient chains (as in the forward pass, DSL_IMG_SPLIT_BWD): images [0, ceil(N/2)) on the caller's
+            # image-split data-gradient chains (as in the forward pass; tuning key img_split_bwd): images [0, ceil(N/2)) on the caller's
             # stream, the rest on stream 3; the stage's weight gradients (whole batch) go out behind the JOIN at its end
             grp_all = GROUP and (li > 1 or GROUP_LAST)
             bsplit = bool(BB) and N >= 2 and grp_all and str(li + 1) in BSPLIT

@@ -163,7 +163,7 @@ def build_backward(plan, buckets, SIDE):
     # '' 11.99 / 12.00 / 12.12 ms, '123' 12.17 / 12.16 / 12.15, '23' 12.07 / 12.13 / 12.01: unlike the forward chains and the
     # ResNet engine's backward, the caller's stream is full of kernel time here (10.7 of 12.1 ms busy, profiles/r03_rla_timeline.txt),
     # not of launch gaps, and the weight-gradient grids already hold the CUs a second chain would use.
-    BSPLIT = ''               # (image-split backward chains: built, same gradients, slower - LAB_NOTES.md; the group loops below stay general)
+    BSPLIT = tune('rla_split_bwd')        # default '': built, same gradients (test_rla_image_split_backward_chains_give_the_same_gradients), slower - LAB_NOTES.md
     S2_CLASSES = True         # stride-2 3x3 data gradients as four parity-class launches
     BB = plan.BR
 

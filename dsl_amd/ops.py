@@ -131,8 +131,38 @@ def wgrad_desc(dy, x, dw, *, n, grid, src_hw, cs, cy, cd, kh, kw, stride=1, pad=
         workspace = torch.empty(need, dtype=torch.uint8, device=dy.device)
     assert workspace.numel() * workspace.element_size() >= need, (workspace.numel(), need)
     d.workspace, d.workspace_bytes = L.ptr(workspace), workspace.numel() * workspace.element_size()
-    d._keep = (dy, x, dw, scale, db, workspace)
+    tab = pixtab(d, dy.device if hasattr(dy, 'device') else 'cuda')
+    d._keep = (dy, x, dw, scale, db, workspace, tab)
     return d
+
+
+_pixtabs = None
+
+
+def pixtab(d, device='cuda'):
+    """The pixel descriptor table of d's geometry (dsl_wgrad_desc.pixtab: caller-owned since round 6, the library allocates nothing):
+    one tensor per geometry and device, shared by every descriptor that has it, filled by dsl_wgrad_pixtab_fill and freed with the last
+    descriptor that holds it (weak cache).  Sets d.pixtab / d.pixtab_bytes; returns the tensor (None: this geometry needs no table)."""
+    global _pixtabs
+    import weakref
+    if _pixtabs is None:
+        _pixtabs = weakref.WeakValueDictionary()
+    need = lib.dsl_wgrad_pixtab_bytes(C.byref(d))
+    if need == 0:
+        d.pixtab, d.pixtab_bytes = None, 0
+        return None
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    key = (dev.index, d.nseg, d.n, d.kh, d.kw, d.stride, d.pad) + tuple(d.gh) + tuple(d.gw) + tuple(d.sh) + tuple(d.sw)
+    t = _pixtabs.get(key)
+    if t is None:
+        t = torch.empty(need, dtype=torch.uint8, device=dev)
+        L.check(lib.dsl_wgrad_pixtab_fill(C.byref(d), L.ptr(t), need, L.stream_ptr()), 'dsl_wgrad_pixtab_fill')
+        torch.cuda.current_stream().synchronize()       # once per geometry, at plan-build time: its readers run on other streams
+        _pixtabs[key] = t
+    d.pixtab, d.pixtab_bytes = L.ptr(t), t.numel()
+    return t
 
 
 def wgrad_workspace_bytes(*, n, grid, src_hw, cs, cy, cd, kh, kw, stride=1, pad=0):

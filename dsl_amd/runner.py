@@ -209,6 +209,8 @@ class SemiEpochBasedRunner:
         on this heap: profiles/r05_bench_full_gcfreeze_in_window.log, where it fell into bench.py's timed window).  Once everything
         is built - the plans are through by iteration 4 - they move to the permanent generation; run() undoes it."""
         self._gc_iters = getattr(self, '_gc_iters', 0) + 1
+        if self.GC_FREEZE_AFTER <= 0:          # (0 disables the freeze)
+            return
         if self._gc_iters == self.GC_FREEZE_AFTER and not getattr(self, '_gc_frozen', False):
             gc.collect()
             gc.freeze()
@@ -219,16 +221,19 @@ class SemiEpochBasedRunner:
             self._max_epochs = max_epochs
         self._gc_iters = 0
         self.call_hook('before_run')
-        while self._epoch < self._max_epochs:
-            for (mode, epochs), loader in zip(workflow, data_loaders):
-                assert mode == 'train'
-                for _ in range(epochs):
-                    if self._epoch >= self._max_epochs:
-                        break
-                    self.train(loader, **kw)
-        if getattr(self, '_gc_frozen', False):
-            gc.unfreeze()
-            self._gc_frozen = False
+        try:
+            while self._epoch < self._max_epochs:
+                for (mode, epochs), loader in zip(workflow, data_loaders):
+                    assert mode == 'train'
+                    for _ in range(epochs):
+                        if self._epoch >= self._max_epochs:
+                            break
+                        self.train(loader, **kw)
+        finally:
+            # also when train() or a hook raises: a heap left frozen would keep every later cycle of the process uncollected
+            if getattr(self, '_gc_frozen', False):
+                gc.unfreeze()
+                self._gc_frozen = False
         self.call_hook('after_run')
 
     @torch.no_grad()

@@ -19,12 +19,14 @@ DEFAULTS = {
     'tail_slots': '192',       # ... of the last segment's weight gradients (layer2; the RLA backbone's stage 1)
     # ---- RLA_ResNet engine
     'rla_split': '123',        # forward stages of the RLA backbone that run as two chains
+    'rla_split_bwd': '',       # backward stages whose data-gradient chains do (measured slower on the saturated N = 3 iteration: 12.0 -> 12.15 ms)
     # ---- checks / measurement
     'check_backward_grad': '0',    # 1: verify the gradient handed to loss.backward() on every step (default: the first steps only)
     'skip': '',                # timing-only ablation: '+'-separated items - region tags (fwd.l2 ... bwd.l2), 'sgd', 'prefix'
     # ---- C library options (dsl_set_option)
     'lib.wgrad_slots': '128',
     'lib.stream_probe': '1',   # 0: the library takes its streams as the runtime deals them (no hardware-queue probe)
+    'lib.comm_queue': '3',     # hardware queue the communication stream is placed on (1 weight gradients, 2 second chain, 3 prefix, 4 caller; 0 = as dealt)
     'lib.debug_sync': '0',
     'lib.skip_kinds': '0',
 }

@@ -6,8 +6,11 @@
  *
  * Conventions:
  *   - every function returns 0 on success, <0 on error; dsl_last_error() gives a thread-local text
- *   - the caller owns every buffer; the library never allocates device memory; workspace sizes
- *     are queried (dsl_*_workspace_bytes)
+ *   - the caller owns every buffer; the library never allocates device memory (workspace and table
+ *     sizes are queried: dsl_*_workspace_bytes, dsl_wgrad_pixtab_bytes).  What the library DOES own, per
+ *     device and for the life of the process: the HIP streams it schedules its op lists on (12 candidates
+ *     created at first use, dsl_streams_init), the named events of dsl_run_ops / dsl_stream_*_slot and the
+ *     event pairs of dsl_prof_*; tests/test_abi_gpu.py holds hipMemGetInfo still over multi-scale steps
  *   - kernels are enqueued on the given hipStream_t (passed as void*), no implicit device sync
  *   - activations are NHWC bf16; tensors that span the 5 FPN levels are stored level-major:
  *     [level][image][y][x][channel] ("segments"), which is exactly the flattened location order
@@ -32,7 +35,8 @@ const char* dsl_last_error(void);
 /* Library options - the library reads no environment variable.  Names: "wgrad_slots" (default 128: workgroup budget of a
  * weight-gradient launch whose descriptor leaves `slots` 0), "stream_probe" (1; 0 = the library takes its streams as the runtime deals
  * them instead of probing for hardware queues of their own, dsl_streams_init), "debug_sync" (0; 1 = dsl_run_ops drains the device after every op and
- * names it on stderr), "skip_kinds" (0; timing-only ablation: bit mask of op kinds dsl_run_ops skips).  Unknown name: -1. */
+ * names it on stderr), "skip_kinds" (0; timing-only ablation: bit mask of op kinds dsl_run_ops skips), "comm_queue" (3; which of the four
+ * hardware queues the communication stream is placed on, see dsl_comm_stream_queue; set it before the streams exist).  Unknown name: -1. */
 int dsl_set_option(const char* name, int value);
 int dsl_get_option(const char* name, int* value);
 
@@ -134,10 +138,21 @@ typedef struct dsl_wgrad_desc {
                                                       * is chosen for: launches that run beside the caller's stream leave it CUs, the
                                                       * ones at the very end of a pass can take the chip (group launches: descs[0]'s) */
   int32_t pad_;
+  const void* pixtab;                                /* the geometry's pixel descriptor table: caller-owned device memory of
+                                                      * >= dsl_wgrad_pixtab_bytes(d), written ONCE per geometry by dsl_wgrad_pixtab_fill
+                                                      * (any descriptor of the same nseg / n / grid / source sizes / kh / kw / stride /
+                                                      * pad may share it).  May be NULL when dsl_wgrad_pixtab_bytes(d) is 0 */
+  size_t pixtab_bytes;
 } dsl_wgrad_desc;
 
 int dsl_wgrad_splits(const dsl_wgrad_desc* d);
 size_t dsl_wgrad_workspace_bytes(const dsl_wgrad_desc* d);
+/* The pipelined weight-gradient kernels read their gather addresses (source pixel of tap (0, 0), tap validity bits) from a table of
+ * 8 bytes per output pixel.  It is the CALLER's memory like every other buffer: query the size (0 = this geometry's kernel needs
+ * none), fill it with one small kernel on `stream`, hand it over in dsl_wgrad_desc.pixtab.  The library keeps no device allocation
+ * of its own (until round 6 it cached these tables in hipMalloc'd memory for the life of the process). */
+size_t dsl_wgrad_pixtab_bytes(const dsl_wgrad_desc* d);
+int dsl_wgrad_pixtab_fill(const dsl_wgrad_desc* d, void* table, size_t bytes, void* stream);
 int dsl_conv2d_wgrad(const dsl_wgrad_desc* d, void* stream);
 /* The weight gradients of `count` (<= DSL_MAX_GROUP) convolutions that share one geometry - every descriptor
  * field except dy, x, scale, dw, db - as ONE launch: the workgroups that fill the chip come from `count` times
@@ -573,6 +588,15 @@ int dsl_side_stream(int id, void** stream_out);
  * whatever other streams the process has created (api.hip side_init).  Optional (the first dsl_run_ops does it).  *distinct_out: how
  * many of the three were found (3 = all, -1 = option "stream_probe" is 0). */
 int dsl_streams_init(void* caller_stream, int* distinct_out);
+/* Which hardware queue the communication stream (dsl_side_stream(5)) shares - it is PLACED, not dealt (option "comm_queue", default 3):
+ * 1 = the weight-gradient stream's, 2 = the second chain's, 3 = the frozen prefix's, 4 = the caller's; 0 = not placed (probe off or no
+ * candidate found), -1 = the streams do not exist yet.  Side ids 2 and 3 are ONE stream (they only add ordering). */
+int dsl_comm_stream_queue(void);
+/* Device-side stand-in for a ring all-reduce of buf[0, n) (fp32, 16-byte aligned) on `stream`: `wgs` workgroups (RCCL: one per
+ * channel) make `passes` value-preserving read-modify-write passes over the bucket - the HBM traffic and the CUs the collective's
+ * kernels hold beside the backward pass, on a box with one GPU (bench.py extra.comm_proxy: mmdet/apis/train.py:92-96's DDP
+ * all-reduce priced without a peer).  Not a collective: no data leaves the device. */
+int dsl_comm_proxy(float* buf, long long n, int wgs, int passes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Live kernel timing with HIP events (bench.py roofline): when enabled, each launch of the MFMA

@@ -266,6 +266,90 @@ def test_full_size_dsl_iteration_vs_oracle():
         assert torch.equal(plan.lossplan.cls_weight.cpu(), raux['cls_weight'].float())
 
 
+_FULL_ORACLE = {}
+
+
+def _full_size_oracle(kind):
+    """fp32 and bf16-emulating oracle gradients of the benchmark's own batch (kind 'sup': bench.synth_batch(0, 2); 'dsl': the N = 3
+    semi-supervised batch of test_full_size_dsl_iteration_vs_oracle), computed once per session (about 12 s per backward pass on the
+    GPU box's host) and shared by the schedule legs below."""
+    if kind in _FULL_ORACLE:
+        return _FULL_ORACLE[kind]
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import fcos_oracle as O
+    b = bench.synth_batch(0, 2)
+    sd = O.synth_state_dict(0)
+    if kind == 'sup':
+        img, gtb, gtl, ig, metas, kw = b['img'].cpu(), b['gt_bboxes'], b['gt_labels'], None, b['img_metas'], {}
+    else:
+        from dsl_amd.runner import append_half_scale
+        rng = np.random.RandomState(77)
+        ig0 = [torch.zeros(0, 4), T(bench.synth_boxes(rng, 3))]
+        img, gtb, gtl, ig = O.append_half_scale(b['img'].cpu(), b['gt_bboxes'], b['gt_labels'], ig0)
+        _, _, _, _, metas = append_half_scale(b['img'][:, :, :8, :8].cpu(), b['gt_bboxes'], b['gt_labels'], ig0, b['img_metas'])
+        kw = dict(loss_weight=3.0, soft_weight=1.0, soft_scale=1.0)
+    l32, g32, _ = O.train_step(sd, img, gtb, gtl, ig, emulate_bf16=False, **kw)
+    lem, gem, _ = O.train_step(sd, img, gtb, gtl, ig, emulate_bf16=True, **kw)
+    _FULL_ORACLE[kind] = dict(img=img, gtb=gtb, gtl=gtl, ig=ig, metas=metas, l32=l32, g32=g32, lem=lem, gem=gem)
+    return _FULL_ORACLE[kind]
+
+
+_FULL_LEGS = [('sup', {}), ('sup', dict(side='0')), ('dsl', dict(tower_slots='128'))]
+
+
+@pytest.mark.parametrize('kind,knobs', _FULL_LEGS, ids=[k + ''.join(f'-{a}={v}' for a, v in kn.items()) for k, kn in _FULL_LEGS])
+def test_full_size_gradients_vs_oracle(monkeypatch, kind, knobs):
+    """VERDICT round 5, "parity first" item 1: every whole-network gradient check ran at <= 256 x 320, where the launch planner picks
+    other tiles, split factors and weight-gradient schedules than at the benchmark's 2 x 3 x 800 x 1344.  Here the schedule that SHIPS
+    - FPN multi launch, layer3 / layer4 persistent `wgrad_pipe_multi_sched` tables, the x8 tower group on its 72-workgroup budget,
+    image-split chains, the fused layer2 blocks, the pipelined prefix off (one step) - is compared parameter by parameter with the
+    oracle's autograd backward (mmdet/models/detectors/base.py:210-243 + loss.backward()) under the golden tests' noise model:
+    the HIP gradient may be no farther from the fp32 gradient than 1.6 x the bf16-emulating oracle's own distance + 5e-3.  Legs:
+    the default schedule, everything on the caller's stream (side=0: the schedule in which two ordering bugs hid in rounds 4 and 5),
+    and the N = 3 semi-supervised batch (ignore boxes, loss_weight 3, sisoft) with the towers' group on 128 workgroups."""
+    from dsl_amd import tuning
+    tuning.tune('side')
+    for k_, v_ in knobs.items():
+        monkeypatch.setitem(tuning._values, k_, v_)
+    o = _full_size_oracle(kind)
+    head = dict(loss_weight=3.0, soft_weight=1.0, soft_warm_up=0) if kind == 'dsl' else {}
+    model = build(**head)
+    if kind == 'dsl':
+        model.bbox_head.cur_iter = 1
+    losses = model.forward_train(o['img'].cuda(), o['metas'], o['gtb'], o['gtl'], o['ig'])
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    plan = [p for p in model._engine.plans.values() if p.training][0]
+    assert (plan.N, plan.H, plan.W) == (3 if kind == 'dsl' else 2, 800, 1344)
+    assert bool(plan.BR) == (knobs.get('side', '1') == '1')
+    for k, v in losses.items():
+        tol = 3e-3 if k == 'loss_sisoft' else 1e-3          # (sisoft: DESIGN section 4, bf16 storage adds 2 s^2 to every squared difference)
+        assert float(v.detach()) == pytest.approx(o['l32'][k], rel=tol), (k, float(v.detach()), o['l32'][k])
+    named = dict(model.named_parameters())
+    bad, worst, n = [], [], 0
+    for k, gref in o['g32'].items():
+        if k not in named or named[k].grad is None or float(gref.norm()) == 0:
+            continue
+        n += 1
+        e_hip, e_emu = rel_l2(named[k].grad.cpu(), gref), rel_l2(o['gem'][k], gref)
+        worst.append((e_hip / (1.6 * e_emu + 5e-3), k, e_hip, e_emu))
+        if e_hip > 1.6 * e_emu + 5e-3:
+            bad.append((k, e_hip, e_emu))
+    worst.sort(reverse=True)
+    print(kind, knobs, 'parameters compared:', n, 'worst err_hip / bound:', [(round(r, 3), k, round(a, 4), round(b, 4)) for r, k, a, b in worst[:6]])
+    assert n >= 150, n            # every trainable tensor of backbone (layer2-4), FPN and head
+    assert not bad, bad[:10]
+    # the whole gradient vector (what clipping and the all-reduce see): norm within the emulated run's own deviation + 2 %
+    keys = [k for k in o['g32'] if k in named and named[k].grad is not None]
+    nh = float(torch.sqrt(sum(named[k].grad.double().pow(2).sum() for k in keys)).cpu())
+    n32 = float(torch.sqrt(sum(o['g32'][k].double().pow(2).sum() for k in keys)))
+    nem = float(torch.sqrt(sum(o['gem'][k].double().pow(2).sum() for k in keys)))
+    assert abs(nh - n32) <= 1.6 * abs(nem - n32) + 2e-2 * n32, (nh, n32, nem)
+
+
 def test_plan_cache_is_bounded_and_reuses_shapes():
     """Multi-scale training visits many padded shapes: plans are cached per shape, least recently used evicted."""
     model = build()

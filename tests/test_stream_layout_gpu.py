@@ -1,6 +1,6 @@
 """Stream-layout robustness (round-4 review item 4; DESIGN: which of the step's streams share one of the device's hardware queues
-is worth up to 20 % of the step).  The library creates every stream it uses itself, in one fixed order and priority class
-(csrc/api.hip side_init), so what ELSE the process creates - a DataLoader's copy stream, an evaluation hook's stream
+is worth up to 20 % of the step).  The library creates every stream it uses itself and PICKS them with a spin-kernel probe for
+hardware queues of their own (csrc/api.hip side_init), so what ELSE the process creates - a DataLoader's copy stream, an evaluation hook's stream
 (the reference's MultiDataLoader always brings its own: mmdet/datasets/builder.py:159-352) - must not move the step time."""
 import json
 import os
@@ -18,16 +18,22 @@ def _bench(foreign):
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{') and '"value"' in l][-1]
-    return json.loads(line)['ms_per_step']
+    j = json.loads(line)
+    return j['ms_per_step'], j['streams_on_own_queues']
 
 
 @pytest.mark.gpu
 def test_foreign_streams_before_and_after_model_construction_do_not_move_the_step_time():
     """bench.py's loop in fresh processes: clean, with three foreign torch streams created AND used before the model is built, and
     with three created after its first steps (each is used - a small op - in every timed step, as a loader's copy stream would be).
-    Round 4 measured -18 % for the 'after' case (a pool stream landed on a hardware queue of the step's own streams)."""
-    clean = _bench('none')
+    Round 4 measured -18 % for the 'after' case (a pool stream landed on a hardware queue of the step's own streams).
+    The asserted signal is the FUNCTIONAL one: in every variant the probe finds all three of the library's
+    concurrently used streams on hardware queues of their own.  The step-time ratio is printed and only held to 10 % - a layout
+    collision costs 18 - 45 % (profiles/r04_streams.txt, r05_stream_prio_collapse.txt), box and run noise is ~1 %."""
+    clean, q0 = _bench('none')
     res = {k: _bench(k) for k in ('before', 'after')}
-    print('ms/step: clean', clean, res)
-    for k, v in res.items():
-        assert abs(v / clean - 1.0) <= 0.03, (k, v, clean)
+    print('ms/step: clean', clean, {k: v[0] for k, v in res.items()}, 'ratios', {k: round(v[0] / clean, 4) for k, v in res.items()})
+    assert q0 == 3
+    for k, (v, q) in res.items():
+        assert q == 3, (k, q)
+        assert v / clean <= 1.10, (k, v, clean)
