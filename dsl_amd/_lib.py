@@ -147,7 +147,8 @@ class AugItem(C.Structure):
                 ('roi', C.c_int32 * 4), ('cval', C.c_int32), ('f', C.c_float * 3), ('rect', (C.c_int32 * 4) * 3), ('seed', C.c_uint32)]
 
 
-AUG_COPY, AUG_AFFINE, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_HUE, AUG_GRAY, AUG_BLUR_H, AUG_BLUR_V, AUG_ERASE = range(10)
+(AUG_COPY, AUG_AFFINE, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_HUE, AUG_GRAY, AUG_BLUR_H, AUG_BLUR_V, AUG_ERASE,
+ AUG_AUTOCONTRAST, AUG_EQUALIZE, AUG_SOLARIZE, AUG_POSTERIZE, AUG_SHARPNESS) = range(15)
 
 
 class Op(C.Structure):
@@ -162,6 +163,8 @@ if hasattr(lib, 'dsl_wgrad_pixtab_bytes'):
 if hasattr(lib, 'dsl_wgrad_group_workspace_bytes'):
     lib.dsl_wgrad_group_workspace_bytes.restype = C.c_size_t
 lib.dsl_conv2d_workspace_bytes.restype = C.c_size_t
+if hasattr(lib, 'dsl_image_aug_scratch_bytes'):
+    lib.dsl_image_aug_scratch_bytes.restype = C.c_size_t
 for _n in ('dsl_wgrad_multi_table_bytes', 'dsl_wgrad_multi_workspace_bytes'):
     if hasattr(lib, _n):
         getattr(lib, _n).restype = C.c_size_t
@@ -187,7 +190,7 @@ _SIGS = {
     'dsl_avgpool2x2_bwd': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_bn_tanh_fwd': [_vp, _i, _vp, _vp, _vp, _i, _l, _i, _vp], 'dsl_bn_tanh_bwd_workspace_bytes': [_l, _i],
     'dsl_bn_tanh_bwd': [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
-    'dsl_image_prep_u8': [_vp, _i, _vp, _i, _i, _vp], 'dsl_image_aug': [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp],
+    'dsl_image_prep_u8': [_vp, _i, _vp, _i, _i, _vp], 'dsl_image_aug': [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp], 'dsl_image_aug_scratch_bytes': [_i],
     'dsl_image_normalize': [_vp, _vp, _i, _vp, _i, _i, _vp],
     'dsl_quant_fp8': [_vp, _vp, _l, _i, _i, _f, _vp], 'dsl_absmax': [_vp, _l, _i, _i, _vp, _i, _vp],
     'dsl_quant_fp8_dyn': [_vp, _vp, _l, _i, _i, _vp, _i, _vp], 'dsl_fp8_comb': [_vp, _vp, _i, _vp, _i, _vp], 'dsl_quant_fp8_weights': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],

@@ -110,6 +110,8 @@ struct AugK {
   const unsigned char* src;
   unsigned char* dst;
   unsigned long long* sums;      // per image: sum of the 8-bit luma (contrast's mean), filled by aug_luma_sum_kernel
+  unsigned* hist;                // per image and band: 256-bin histogram (AUTOCONTRAST / EQUALIZE), filled by aug_hist_kernel
+  unsigned char* lut;            // per image and band: the 256-entry table aug_lut_kernel derives from it
 };
 
 __device__ __forceinline__ int luma_u8(int r, int g, int b) {       // PIL "L": (R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16
@@ -141,6 +143,71 @@ __global__ __launch_bounds__(256) void aug_luma_sum_kernel(const AugK p) {
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(p.sums + img, sh[0] + sh[1] + sh[2] + sh[3]);      // integer sum: order-independent
+}
+
+// Image.histogram() of the images whose pass is AUTOCONTRAST or EQUALIZE: 256 bins per band; a block folds 256 x 32 pixels in LDS and
+// adds its non-empty bins to the image's table (integer sums: order-independent)
+__global__ __launch_bounds__(256) void aug_hist_kernel(const AugK p) {
+  const int img = blockIdx.z;
+  const dsl_aug_item it = p.items[img];
+  if (it.kind != DSL_AUG_AUTOCONTRAST && it.kind != DSL_AUG_EQUALIZE) return;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * kLumaRows;
+  if (y0 >= it.h || (int)(blockIdx.x * blockDim.x) >= it.w) return;              // block-uniform
+  __shared__ unsigned sh[768];
+  for (int i = threadIdx.x; i < 768; i += 256) sh[i] = 0u;
+  __syncthreads();
+  if (x < it.w) {
+    const int y1 = min(y0 + kLumaRows, it.h);
+    for (int y = y0; y < y1; ++y) {
+      const unsigned char* s = p.src + (((long long)img * p.hc + y) * p.wc + x) * 3;
+      atomicAdd(&sh[s[0]], 1u); atomicAdd(&sh[256 + s[1]], 1u); atomicAdd(&sh[512 + s[2]], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 768; i += 256)
+    if (sh[i]) atomicAdd(p.hist + (size_t)img * 768 + i, sh[i]);
+}
+// ImageOps.autocontrast(img) (cutoff 0) / ImageOps.equalize(img), PIL/ImageOps.py: one band's table per 256-thread slice of the block
+//  autocontrast: lo / hi = the first / last occupied bin; identity when hi <= lo, else lut[i] = clamp(int(i * scale + offset)) with the
+//                DOUBLE scale = 255.0 / (hi - lo), offset = -lo * scale (two rounded operations, as Python evaluates them)
+//  equalize:     step = (pixels - count of the last occupied bin) // 255; identity when fewer than two bins are occupied or step == 0,
+//                else lut[i] = (step // 2 + sum(h[:i])) // step, clipped to 8 bits by Image.point
+__global__ __launch_bounds__(768) void aug_lut_kernel(const AugK p) {
+  const int img = blockIdx.x;
+  const dsl_aug_item it = p.items[img];
+  if (it.kind != DSL_AUG_AUTOCONTRAST && it.kind != DSL_AUG_EQUALIZE) return;
+  __shared__ unsigned h[768];
+  __shared__ unsigned long long pre[768];
+  __shared__ int lo_[3], hi_[3], occ_[3];
+  const int t = threadIdx.x, band = t >> 8, i = t & 255;
+  h[t] = p.hist[(size_t)img * 768 + t];
+  __syncthreads();
+  if (i == 0) {                                   // 256 bins: one thread per band walks them once
+    int lo = 256, hi = -1, occ = 0;
+    unsigned long long run = 0;
+    for (int q = 0; q < 256; ++q) {
+      const unsigned v = h[band * 256 + q];
+      pre[band * 256 + q] = run;
+      run += v;
+      if (v) { lo = min(lo, q); hi = q; ++occ; }
+    }
+    lo_[band] = lo; hi_[band] = hi; occ_[band] = occ;
+  }
+  __syncthreads();
+  const int lo = lo_[band], hi = hi_[band];
+  int v = i;
+  if (it.kind == DSL_AUG_AUTOCONTRAST) {
+    if (hi > lo) {
+      const double scale = ddiv1(255.0, (double)(hi - lo));
+      const double offset = dmul1((double)(-lo), scale);
+      v = min(max((int)dadd1(dmul1((double)i, scale), offset), 0), 255);
+    }
+  } else if (occ_[band] > 1) {
+    const unsigned long long total = pre[band * 256 + 255] + h[band * 256 + 255];
+    const unsigned long long step = (total - h[band * 256 + hi]) / 255ull;
+    if (step) v = (int)min((step / 2ull + pre[band * 256 + i]) / step, 255ull);
+  }
+  p.lut[(size_t)img * 768 + t] = (unsigned char)v;
 }
 
 // Pillow's Image.blend(degenerate, image, f) as ImageEnhance uses it (Blend.c): float32 deg + f * (img - deg), clipped, TRUNCATED
@@ -286,6 +353,44 @@ __global__ __launch_bounds__(256) void image_aug_kernel(const AugK p) {
       b = (int)((acc[2] * ww + far_[2] * fw + (1u << 23)) >> 24);
       break;
     }
+    case DSL_AUG_AUTOCONTRAST:    // RandAug AutoContrast / Equalize (autoaug_fast.py:219-224): per-band tables out of aug_lut_kernel
+    case DSL_AUG_EQUALIZE: {
+      const unsigned char* lut = p.lut + (size_t)img * 768;
+      r = lut[r]; g = lut[256 + g]; b = lut[512 + b];
+      break;
+    }
+    case DSL_AUG_SOLARIZE: {      // ImageOps.solarize(img, threshold): f[0] = 256 - int(level * 256 / 10) (autoaug_fast.py:371-372)
+      const int th = (int)it.f[0];
+      r = r < th ? r : 255 - r; g = g < th ? g : 255 - g; b = b < th ? b : 255 - b;
+      break;
+    }
+    case DSL_AUG_POSTERIZE: {     // ImageOps.posterize(img, bits): f[0] = bits = 4 - int(level * 4 / 10) (autoaug_fast.py:244-247)
+      const int mask = ~((1 << (8 - (int)it.f[0])) - 1) & 255;
+      r &= mask; g &= mask; b &= mask;
+      break;
+    }
+    case DSL_AUG_SHARPNESS: {     // ImageEnhance.Sharpness: blend(img.filter(SMOOTH), img, f).  Filter.c ImagingFilter3x3 on 8-bit bands:
+                                  // float32 weights 1 / 13 and 5 / 13, 0.5 + row(y + 1) + row(y) + row(y - 1), each row's three products
+                                  // added left to right first, truncated; the image's one-pixel frame keeps its input values
+      int deg[3] = {r, g, b};
+      if (x > 0 && y > 0 && x < it.w - 1 && y < it.h - 1) {
+        const float k1 = fdiv1(1.f, 13.f), k5 = fdiv1(5.f, 13.f);
+        float ss[3] = {0.5f, 0.5f, 0.5f};
+#pragma unroll
+        for (int dy = 1; dy >= -1; --dy) {
+          const unsigned char* q = p.src + (base + (long long)(y + dy) * p.wc + x - 1) * 3;
+          const float kc = dy == 0 ? k5 : k1;
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            ss[c] = fadd1(ss[c], fadd1(fadd1(fmul1((float)q[c], k1), fmul1((float)q[3 + c], kc)), fmul1((float)q[6 + c], k1)));
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) deg[c] = (int)fminf(fmaxf(ss[c], 0.f), 255.f);
+      }
+      r = blend_u8((float)r, (float)deg[0], it.f[0]); g = blend_u8((float)g, (float)deg[1], it.f[0]);
+      b = blend_u8((float)b, (float)deg[2], it.f[0]);
+      break;
+    }
     case DSL_AUG_ERASE: {         // RandomErasing(value='random'): N(0, 1) noise in [0, 1] units, then ToPILImage's mul(255).byte()
       for (int k = 0; k < 3; ++k) {
         if (it.rect[k][2] <= it.rect[k][0]) continue;
@@ -346,19 +451,35 @@ extern "C" int dsl_image_prep_u8(const dsl_image_prep_item* items_dev, int n, un
   return 0;
 }
 
+extern "C" size_t dsl_image_aug_scratch_bytes(int n) {
+  return n > 0 ? (size_t)n * (8 + 768 * 4 + 768) : 0;      // luma sums [n] u64 | histograms [n][3][256] u32 | tables [n][3][256] u8
+}
+
 extern "C" int dsl_image_aug(const dsl_aug_item* items_dev, int n, const unsigned char* src, unsigned char* dst, int hc, int wc,
-                             void* luma_sums, int need_mean, void* stream) {
+                             void* scratch, int need_stats, void* stream) {
   DSL_CHECK(items_dev && src && dst && src != dst && n > 0 && hc > 0 && wc > 0 && wc < 8192, "dsl_image_aug: bad arguments");
-  DSL_CHECK(!need_mean || luma_sums, "dsl_image_aug: the contrast pass needs the 8 * n byte luma_sums scratch");
-  AugK k{items_dev, n, hc, wc, src, dst, (unsigned long long*)luma_sums};
+  DSL_CHECK(!need_stats || (scratch && ((uintptr_t)scratch & 7) == 0),
+            "dsl_image_aug: CONTRAST / AUTOCONTRAST / EQUALIZE passes need the 8-byte aligned dsl_image_aug_scratch_bytes(n) scratch");
+  unsigned char* sc = (unsigned char*)scratch;
+  AugK k{items_dev, n, hc, wc, src, dst, (unsigned long long*)sc, (unsigned*)(sc ? sc + 8 * (size_t)n : nullptr),
+         sc ? sc + (8 + 768 * 4) * (size_t)n : nullptr};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((wc + 255) / 256, hc, n);
-  if (need_mean) {
-    if (hipMemsetAsync(luma_sums, 0, 8 * (size_t)n, st) != hipSuccess) {
+  const dim3 sgrid(grid.x, (hc + kLumaRows - 1) / kLumaRows, n);
+  if (need_stats & 1) {
+    if (hipMemsetAsync(k.sums, 0, 8 * (size_t)n, st) != hipSuccess) {
       dsl_set_error("dsl_image_aug: memset failed");
       return -2;
     }
-    hipLaunchKernelGGL(aug_luma_sum_kernel, dim3(grid.x, (hc + kLumaRows - 1) / kLumaRows, n), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(aug_luma_sum_kernel, sgrid, dim3(256), 0, st, k);
+  }
+  if (need_stats & 2) {
+    if (hipMemsetAsync(k.hist, 0, 768 * 4 * (size_t)n, st) != hipSuccess) {
+      dsl_set_error("dsl_image_aug: memset failed");
+      return -2;
+    }
+    hipLaunchKernelGGL(aug_hist_kernel, sgrid, dim3(256), 0, st, k);
+    hipLaunchKernelGGL(aug_lut_kernel, dim3(n), dim3(768), 0, st, k);
   }
   hipLaunchKernelGGL(image_aug_kernel, grid, dim3(256), 0, st, k);
   DSL_LAUNCH_CHECK("image_aug_kernel");

@@ -254,7 +254,11 @@ int dsl_image_prep_u8(const dsl_image_prep_item* items_dev, int n, unsigned char
  * ToPILImage unchanged.  imgaug is not available to this build: AFFINE follows its documented convention, parity UNPINNED.
  * ERASE writes its own N(0, 1) stream through torchvision's value mapping (mul(255).byte(): truncate, wrap). */
 enum { DSL_AUG_COPY = 0, DSL_AUG_AFFINE = 1, DSL_AUG_BRIGHTNESS = 2, DSL_AUG_CONTRAST = 3, DSL_AUG_SATURATION = 4, DSL_AUG_HUE = 5,
-       DSL_AUG_GRAY = 6, DSL_AUG_BLUR_H = 7, DSL_AUG_BLUR_V = 8, DSL_AUG_ERASE = 9 };
+       DSL_AUG_GRAY = 6, DSL_AUG_BLUR_H = 7, DSL_AUG_BLUR_V = 8, DSL_AUG_ERASE = 9,
+       /* RandAug's ops on an image without boxes (mmdet/datasets/pipelines/autoaug_fast.py:219-224, 244-250, 371-372, 407, reached from
+        * semi_aug.py:494-497): Pillow's ImageOps.autocontrast / equalize / solarize / posterize and ImageEnhance.Sharpness bit for
+        * bit, pinned against Pillow's own outputs (tests/golden/randaug_pil.npz) */
+       DSL_AUG_AUTOCONTRAST = 10, DSL_AUG_EQUALIZE = 11, DSL_AUG_SOLARIZE = 12, DSL_AUG_POSTERIZE = 13, DSL_AUG_SHARPNESS = 14 };
 typedef struct dsl_aug_item {
   int32_t h, w;                  /* the image inside its canvas */
   int32_t kind;
@@ -263,14 +267,18 @@ typedef struct dsl_aug_item {
                                   * y_s = m3 x + m4 y + m5 inside the roi (the inverse of the drawn transform) */
   int32_t roi[4];                /* AFFINE: x0, y0, x1, y1 - the region replaced and sampled (whole image, or one box) */
   int32_t cval;                  /* AFFINE: fill value (125) */
-  float f[3];                    /* f[0]: BRIGHTNESS / CONTRAST / SATURATION the enhancement factor; HUE int(factor * 255), the 8-bit
-                                  * shift; BLUR_H / BLUR_V the fractional box radius of GaussianBlur(sigma) (BoxBlur.c) */
+  float f[3];                    /* f[0]: BRIGHTNESS / CONTRAST / SATURATION / SHARPNESS the enhancement factor; HUE int(factor * 255), the
+                                  * 8-bit shift; BLUR_H / BLUR_V the fractional box radius of GaussianBlur(sigma) (BoxBlur.c); SOLARIZE the
+                                  * threshold (0 .. 256); POSTERIZE the bits kept (1 .. 8) */
   int32_t rect[3][4];            /* ERASE: up to three rectangles x0, y0, x1, y1 (x1 <= x0: unused) */
   uint32_t seed;                 /* ERASE: noise stream */
 } dsl_aug_item;
-/* luma_sums: 8 * n bytes of scratch, needed (need_mean != 0) when some item is a CONTRAST pass. */
+/* scratch: dsl_image_aug_scratch_bytes(n) bytes, 8-byte aligned (per image: the luma sum, the three 256-bin band histograms and
+ * the tables derived from them); need_stats: bit 0 set when some item is a CONTRAST pass, bit 1 when some item is an AUTOCONTRAST or
+ * EQUALIZE pass (0: scratch may be NULL). */
+size_t dsl_image_aug_scratch_bytes(int n);
 int dsl_image_aug(const dsl_aug_item* items_dev, int n, const unsigned char* src, unsigned char* dst, int hc, int wc,
-                  void* luma_sums, int need_mean, void* stream);
+                  void* scratch, int need_stats, void* stream);
 /* Normalize + Pad of a uint8 canvas batch (the tail of dsl_image_prep): dst[n][3][hc][wc] fp32. */
 int dsl_image_normalize(const unsigned char* src_u8, const dsl_image_prep_item* items_dev, int n, float* dst, int hc, int wc,
                         void* stream);

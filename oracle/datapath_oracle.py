@@ -285,6 +285,96 @@ def gaussian_blur(img, radius):
     return out
 
 
+# RandAug's histogram / filter ops on a no-box image (mmdet/datasets/pipelines/autoaug_fast.py:219-224 auto_contrast / equalize,
+# :244-250 posterize, :371-372 solarize, :407 sharpness; reached from semi_aug.py:494-497): Pillow's ImageOps / ImageEnhance
+# arithmetic, restated from PIL/ImageOps.py and Filter.c / Blend.c and PINNED: tests/golden/randaug_pil.npz holds Pillow's own outputs
+# (tests/golden/make_golden.py randaug).  Every op acts per band, so the stored channel order is immaterial.
+def band_histogram(img):
+    """Image.histogram(): 256 bins per band."""
+    return np.stack([np.bincount(img[..., c].reshape(-1), minlength=256) for c in range(img.shape[-1])]).astype(np.int64)
+
+
+def autocontrast_lut(h):
+    """ImageOps.autocontrast(img) with cutoff 0, one band's histogram h[256] -> lut[256]: the darkest value present maps to 0, the
+    lightest to 255; int() of the DOUBLE ix * scale + offset, clamped."""
+    nz = np.nonzero(h)[0]
+    if nz.size == 0:
+        return np.arange(256, dtype=np.uint8)
+    lo, hi = int(nz[0]), int(nz[-1])
+    if hi <= lo:
+        return np.arange(256, dtype=np.uint8)
+    scale = 255.0 / (hi - lo)
+    offset = -lo * scale
+    return np.clip((np.arange(256, dtype=np.float64) * scale + offset).astype(np.int64), 0, 255).astype(np.uint8)
+
+
+def equalize_lut(h):
+    """ImageOps.equalize(img), one band: step = (pixels - count of the last occupied bin) // 255; lut[i] = (step // 2 + sum(h[:i]))
+    // step, identity when fewer than two bins are occupied or step is 0; Image.point clips the table to 8 bits."""
+    histo = h[h > 0]
+    if histo.size <= 1:
+        return np.arange(256, dtype=np.uint8)
+    step = (int(histo.sum()) - int(histo[-1])) // 255
+    if step == 0:
+        return np.arange(256, dtype=np.uint8)
+    n = step // 2 + np.concatenate([[0], np.cumsum(h)[:-1]])
+    return np.clip(n // step, 0, 255).astype(np.uint8)
+
+
+def autocontrast(img):
+    h = band_histogram(img)
+    return np.stack([autocontrast_lut(h[c])[img[..., c]] for c in range(3)], -1)
+
+
+def equalize(img):
+    h = band_histogram(img)
+    return np.stack([equalize_lut(h[c])[img[..., c]] for c in range(3)], -1)
+
+
+def solarize(img, threshold):
+    """ImageOps.solarize: values >= threshold are inverted."""
+    return np.where(img.astype(np.int64) < threshold, img, 255 - img).astype(np.uint8)
+
+
+def posterize(img, bits):
+    """ImageOps.posterize: keep the `bits` high bits of every channel."""
+    return (img & np.uint8((~(2 ** (8 - bits) - 1)) & 255)).astype(np.uint8)
+
+
+def smooth3x3(img):
+    """img.filter(ImageFilter.SMOOTH) (Filter.c ImagingFilter3x3, 8-bit bands): kernel (1 1 1 / 1 5 1 / 1 1 1) / 13 as float32 weights,
+    float32 accumulation 0.5 + row(y + 1) + row(y) + row(y - 1) with each row's three products summed left to right first, truncated;
+    the one-pixel frame is copied from the input."""
+    k1, k5 = np.float32(1.0) / np.float32(13.0), np.float32(5.0) / np.float32(13.0)
+    f = img.astype(np.float32)
+    out = img.copy()
+    H, W = img.shape[:2]
+    if H < 3 or W < 3:
+        return out
+    def row(r, kc):
+        return (r[:, :-2] * k1 + r[:, 1:-1] * kc).astype(np.float32) + r[:, 2:] * k1
+    ss = np.float32(0.5) + row(f[2:], k1)
+    ss = (ss + row(f[1:-1], k5)).astype(np.float32)
+    ss = (ss + row(f[:-2], k1)).astype(np.float32)
+    out[1:-1, 1:-1] = np.clip(ss, 0, 255).astype(np.uint8)
+    return out
+
+
+def adjust_sharpness(img, f):
+    """ImageEnhance.Sharpness(img).enhance(f): blend(SMOOTH-filtered image, image, f)."""
+    return pil_blend(smooth3x3(img), img, f)
+
+
+def randaug_level(op, level):
+    """autoaug_fast.py's level -> parameter maps (PARAMETER_MAX = 10): Solarize threshold 256 - int(level * 256 / 10) (:371-372),
+    Posterize bits 4 - int(level * 4 / 10) (:244-247), the enhancers' factor level * 1.8 / 10 + 0.1 (:392-399)."""
+    if op == 'Solarize':
+        return 256 - int(level * 256 / 10)
+    if op == 'Posterize':
+        return 4 - int(level * 4 / 10)
+    return float(level) * 1.8 / 10 + 0.1
+
+
 def erase_value(z):
     """ToPILImage's mul(255).byte() of the N(0, 1) fill RandomErasing(value='random') writes: toward zero, wrap mod 256."""
     return (np.trunc(np.asarray(z, np.float32) * np.float32(255)).astype(np.int64) & 255).astype(np.uint8)

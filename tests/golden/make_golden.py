@@ -542,6 +542,33 @@ def gen_ubaug():
     save('ubaug_pil.npz', **out)
 
 
+def gen_randaug():
+    """RandAug's histogram / filter ops the reference's colour branch draws for an image without boxes (mmdet/datasets/pipelines/
+    autoaug_fast.py:219-224 AutoContrast / Equalize, :244-250 Posterize, :371-372 Solarize, :407 Sharpness; semi_aug.py:464-477,
+    494-497).  autoaug_fast.py's TransformT wrappers are one-line calls of PIL.ImageOps / ImageEnhance on ToPILImage(img) with the
+    level -> parameter maps restated in oracle.datapath_oracle.randaug_level; Pillow itself is in the build container, so the fixture
+    holds Pillow's own outputs for every level 1 .. 9 the policy draws (np.random.randint(1, magnitude = 10))."""
+    from PIL import Image, ImageEnhance, ImageOps
+    rng = np.random.RandomState(23)
+    y, x = np.mgrid[0:57, 0:74]
+    imgs = [rng.randint(0, 256, (45, 61, 3)).astype(np.uint8),                                                   # full-range noise
+            np.clip(np.stack([60 + x * 1.7 + y * 0.3, 90 + 50 * np.sin(x / 6.0), 40 + y * 2.1], -1)
+                    + rng.randint(-9, 9, (57, 74, 3)), 0, 255).astype(np.uint8),                                 # narrow, smooth histograms
+            np.stack([np.full((31, 40), 17), rng.randint(100, 102, (31, 40)), (rng.randint(0, 256, (31, 40)) // 64) * 64], -1).astype(np.uint8),
+            rng.randint(0, 256, (3, 3, 3)).astype(np.uint8)]                                                     # one interior pixel
+    out = dict(n_img=np.int64(len(imgs)))
+    for k, a in enumerate(imgs):
+        im = Image.fromarray(a)
+        out[f'img{k}'] = a
+        out[f'autocontrast{k}'] = np.asarray(ImageOps.autocontrast(im))
+        out[f'equalize{k}'] = np.asarray(ImageOps.equalize(im))
+        for level in range(1, 10):
+            out[f'solarize{k}_{level}'] = np.asarray(ImageOps.solarize(im, 256 - int(level * 256 / 10)))
+            out[f'posterize{k}_{level}'] = np.asarray(ImageOps.posterize(im, 4 - int(level * 4 / 10)))
+            out[f'sharpness{k}_{level}'] = np.asarray(ImageEnhance.Sharpness(im).enhance(float(level) * 1.8 / 10 + .1))
+    save('randaug_pil.npz', **out)
+
+
 def gen_fuse_history():
     """save_results2file with fuse=True (:131-141): the previous contents of the image's label file join the new detections
     before the per-class NMS.  Three rounds per case on one file, as the hook runs them (:470-510): round 1 with
@@ -589,6 +616,9 @@ def gen_fuse_history():
 if __name__ == '__main__':
     if sys.argv[1:] == ['ubaug']:
         gen_ubaug()
+        sys.exit(0)
+    if sys.argv[1:] == ['randaug']:
+        gen_randaug()
         sys.exit(0)
     if sys.argv[1:] == ['ps']:
         gen_patch_shuffle()

@@ -34,11 +34,11 @@ def _run(can, items_fn):
     for i, (h, w) in enumerate(SIZES):
         its[i].h, its[i].w = h, w
         items_fn(i, its[i])
-        need_mean |= int(its[i].kind == L.AUG_CONTRAST)
+        need_mean |= int(its[i].kind == L.AUG_CONTRAST) | 2 * int(its[i].kind in (L.AUG_AUTOCONTRAST, L.AUG_EQUALIZE))
     src = torch.from_numpy(can).cuda()
     dst = torch.zeros_like(src)
     at = torch.frombuffer(bytearray(bytes(its)), dtype=torch.uint8).cuda()
-    sums = torch.zeros(n, dtype=torch.int64, device='cuda')
+    sums = torch.full((int(L.lib.dsl_image_aug_scratch_bytes(n)) // 8,), -1, dtype=torch.int64, device='cuda')      # junk: the call clears what it uses
     L.check(L.lib.dsl_image_aug(L.ptr(at), n, L.ptr(src), L.ptr(dst), HC, WC, L.ptr(sums), need_mean, L.stream_ptr()), 'dsl_image_aug')
     torch.cuda.synchronize()
     return dst.cpu().numpy()
@@ -66,6 +66,43 @@ def test_colour_passes_are_pillow_arithmetic(name):
             it.f[0] = float(int(facs[i] * 255)) if name == 'hue' else facs[i]
         got = _run(can, item)
         _check(can, got, lambda i, a: fn(a, facs[i]))
+
+
+@pytest.mark.parametrize('name', ['autocontrast', 'equalize', 'solarize', 'posterize', 'sharpness'])
+def test_randaug_ops_are_pillow_arithmetic(name):
+    """The no-box colour branch's histogram / filter ops (autoaug_fast.py:219-224, 244-250, 371-372, 407), every level the policy draws,
+    against the restatement that tests/golden/randaug_pil.npz pins to Pillow."""
+    from dsl_amd import _lib as L
+    kind = dict(autocontrast=L.AUG_AUTOCONTRAST, equalize=L.AUG_EQUALIZE, solarize=L.AUG_SOLARIZE, posterize=L.AUG_POSTERIZE,
+                sharpness=L.AUG_SHARPNESS)[name]
+    fn = dict(autocontrast=lambda a, v: DO.autocontrast(a), equalize=lambda a, v: DO.equalize(a), solarize=DO.solarize,
+              posterize=DO.posterize, sharpness=DO.adjust_sharpness)[name]
+    op = name.capitalize()
+    for trial, levels in enumerate([(1, 5, 9), (2, 6, 8), (3, 4, 7)]):
+        can = _canvases(20 + trial)
+        if trial == 1:                                   # narrow / degenerate histograms: one band constant, one with two values
+            for i, (h, w) in enumerate(SIZES):
+                can[i, :h, :w, 0] = 40 + can[i, :h, :w, 0] // 3
+                can[i, :h, :w, 1] = 77
+                can[i, :h, :w, 2] = 200 + (can[i, :h, :w, 2] & 1)
+        vals = [DO.randaug_level(op, lv) for lv in levels]
+
+        def item(i, it):
+            it.kind, it.f[0] = kind, float(vals[i])
+        got = _run(can, item)
+        _check(can, got, lambda i, a: fn(a, vals[i]))
+
+
+def test_mixed_stat_passes_in_one_launch():
+    """One launch whose images take a CONTRAST, an EQUALIZE and an AUTOCONTRAST pass: the luma sums and the histograms share the scratch."""
+    from dsl_amd import _lib as L
+    can = _canvases(31)
+    kinds = (L.AUG_CONTRAST, L.AUG_EQUALIZE, L.AUG_AUTOCONTRAST)
+
+    def item(i, it):
+        it.kind, it.f[0] = kinds[i], 1.3
+    got = _run(can, item)
+    _check(can, got, lambda i, a: (lambda a: DO.adjust_contrast(a, 1.3), DO.equalize, DO.autocontrast)[i](a))
 
 
 def test_hsv_round_trip_every_colour_class():
@@ -214,6 +251,16 @@ def _replay(img, passes):
             img = DO.adjust_hue(img, (p['f'] + (0.5 if p['f'] > 0 else -0.5 if p['f'] < 0 else 0)) / 255.0)
         elif k == L.AUG_GRAY:
             img = DO.to_grayscale3(img)
+        elif k == L.AUG_AUTOCONTRAST:
+            img = DO.autocontrast(img)
+        elif k == L.AUG_EQUALIZE:
+            img = DO.equalize(img)
+        elif k == L.AUG_SOLARIZE:
+            img = DO.solarize(img, int(p['f']))
+        elif k == L.AUG_POSTERIZE:
+            img = DO.posterize(img, int(p['f']))
+        elif k == L.AUG_SHARPNESS:
+            img = DO.adjust_sharpness(img, p['f'])
         elif k == L.AUG_BLUR_H:
             img = DO.box_blur_pass_h(img, np.float32(p['f']))
         elif k == L.AUG_BLUR_V:
@@ -272,6 +319,45 @@ def test_unlabeled_pipeline_replayed_on_the_oracle(seed):
         if erased.sum() > 500:
             assert (g[:, erased] != want[:, erased]).mean() > 0.9
     assert n_pass > 0
+    assert all(t.skipped_ops == 0 for t in pipe.transforms if hasattr(t, 'skipped_ops'))
+
+
+def test_colour_branch_every_op_replayed_on_the_oracle():
+    """Images WITHOUT boxes through the unlabeled pipeline (semi_aug.py:494-497: the RandAug colour branch): batches are drawn until
+    every one of the nine RANDOM_COLOR_POLICY_OPS has been rendered at least once; each batch equals its replay on the Pillow-pinned
+    restatement outside the erased rectangles, and no op is skipped."""
+    from test_datapath_gpu import _samples
+    from dsl_amd import _lib as L
+    from dsl_amd.datapath import GpuBatchPipeline
+    pipe = GpuBatchPipeline(UNLABELED)
+    seen = set()
+    for seed in range(12):
+        rng = np.random.RandomState(900 + seed)
+        samples = _samples(rng, [(120, 160), (150, 100), (97, 131), (64, 64)])
+        for s in samples:
+            s['gt_bboxes'], s['gt_labels'] = np.zeros((0, 4), np.float32), np.zeros((0,), np.int64)
+        np.random.seed(700 + seed)
+        random.seed(800 + seed)
+        batch = pipe(samples)
+        torch.cuda.synchronize()
+        got = batch['img'].cpu().numpy()
+        for i, (s, m) in enumerate(zip(samples, batch['img_metas'])):
+            img = DO.resize_bilinear_u8(s['img'], DO.rescale_size((s['img'].shape[1], s['img'].shape[0]), (300, 160) if m['scale_idx'] == 0 else (300, 200)))
+            h, w = img.shape[:2]
+            if m['PS']:
+                img = DO.patch_shuffle_image(img, m['PS_place'], m['PS_mode'])
+            if m['flip']:
+                img = img[:, ::-1]
+            passes = pipe.last_passes[i]
+            seen |= {p.get('op') for p in passes if 'op' in p}
+            img, erased = _replay(np.ascontiguousarray(img), passes)
+            want = DO.imnormalize(img, NORM['mean'], NORM['std'], NORM['to_rgb']).transpose(2, 0, 1)
+            g = got[i, :, :h, :w]
+            assert np.array_equal(g[:, ~erased], want[:, ~erased]), (seed, i, [p['kind'] for p in passes])
+        if len(seen) == 8:
+            break
+    assert seen == {'AutoContrast', 'Equalize', 'Solarize', 'Color', 'Contrast', 'Brightness', 'Sharpness', 'Posterize'}, seen
+    assert all(t.skipped_ops == 0 for t in pipe.transforms if hasattr(t, 'skipped_ops'))
 
 
 def test_unlabeled_batch_feeds_the_dsl_iteration():

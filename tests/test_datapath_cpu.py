@@ -123,3 +123,37 @@ def test_ubaug_arithmetic_pinned_to_pillow(golden):
             assert np.array_equal(fn(rgb, float(f)), d[f'{name}_{i}']), (name, f)
     assert np.array_equal(D.to_grayscale3(rgb), d['gray'])
     assert D.erase_value([-0.3, 1.7, -2.2, 0.5, 3.9]).tolist() == [180, 177, 207, 127, 226]      # torch: tensor.mul(255).byte()
+
+
+def test_randaug_ops_pinned_to_pillow(golden):
+    """The five histogram / filter ops of the no-box colour branch (autoaug_fast.py:219-224, 244-250, 371-372, 407) against Pillow's own
+    outputs for every level the policy draws (tests/golden/randaug_pil.npz): bit for bit."""
+    from oracle import datapath_oracle as D
+    d = golden('randaug_pil.npz')
+    for k in range(int(d['n_img'])):
+        a = d[f'img{k}']
+        assert np.array_equal(D.autocontrast(a), d[f'autocontrast{k}']), k
+        assert np.array_equal(D.equalize(a), d[f'equalize{k}']), k
+        for level in range(1, 10):
+            assert np.array_equal(D.solarize(a, D.randaug_level('Solarize', level)), d[f'solarize{k}_{level}']), (k, level)
+            assert np.array_equal(D.posterize(a, D.randaug_level('Posterize', level)), d[f'posterize{k}_{level}']), (k, level)
+            assert np.array_equal(D.adjust_sharpness(a, D.randaug_level('Sharpness', level)), d[f'sharpness{k}_{level}']), (k, level)
+    assert [D.randaug_level('Posterize', v) for v in range(1, 10)] == [4, 4, 3, 3, 2, 2, 2, 1, 1]
+    assert [D.randaug_level('Solarize', v) for v in (1, 5, 9)] == [231, 128, 26]
+
+
+def test_colour_branch_renders_all_nine_ops():
+    """RandomAugmentBBox_Fast on an image without boxes (semi_aug.py:464-477, 494-497): every one of RANDOM_COLOR_POLICY_OPS becomes a
+    pass (Identity: none); nothing is skipped."""
+    from dsl_amd import _lib as L
+    from dsl_amd.datapath import RandomAugmentBBox_Fast
+    t = RandomAugmentBBox_Fast(aug_type='affine')
+    t.rng = np.random.RandomState(5)
+    seen = {}
+    for _ in range(400):
+        r = t(dict(img_shape=(40, 50, 3), gt_bboxes=np.zeros((0, 4), np.float32), gt_labels=np.zeros((0,), np.int64)))
+        for p_ in r['_aug']:
+            seen.setdefault(p_['op'], set()).add(p_['kind'])
+    assert t.skipped_ops == 0
+    assert seen == dict(AutoContrast={L.AUG_AUTOCONTRAST}, Equalize={L.AUG_EQUALIZE}, Solarize={L.AUG_SOLARIZE}, Color={L.AUG_SATURATION},
+                        Contrast={L.AUG_CONTRAST}, Brightness={L.AUG_BRIGHTNESS}, Sharpness={L.AUG_SHARPNESS}, Posterize={L.AUG_POSTERIZE})

@@ -340,7 +340,7 @@ def test_full_size_gradients_vs_oracle(monkeypatch, kind, knobs):
             bad.append((k, e_hip, e_emu))
     worst.sort(reverse=True)
     print(kind, knobs, 'parameters compared:', n, 'worst err_hip / bound:', [(round(r, 3), k, round(a, 4), round(b, 4)) for r, k, a, b in worst[:6]])
-    assert n >= 150, n            # every trainable tensor of backbone (layer2-4), FPN and head
+    assert n >= 100, n            # every trainable tensor: 42 backbone convolutions (layer2-4), 16 FPN, 38 head, 5 scales = 101 (one may have a zero reference)
     assert not bad, bad[:10]
     # the whole gradient vector (what clipping and the all-reduce see): norm within the emulated run's own deviation + 2 %
     keys = [k for k in o['g32'] if k in named and named[k].grad is not None]
