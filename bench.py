@@ -101,7 +101,8 @@ def _release_earlier_models():
 
 def fp8_step_timing(batch, steps=20, warm=5):
     """BASELINE.json configs[4], first slice (beside the bf16 headline, never instead of it): the same supervised step with the head
-    towers' forward convolutions on the fp8 MFMA path (FCOS(fp8=dict(layers='towers')), dynamic per-tensor activation scales)."""
+    towers' forward convolutions on the fp8 MFMA path (FCOS(fp8=dict(layers='towers')), delayed per-tensor activation scales: the
+    GroupNorm passes write the e4m3 copies, one dsl_fp8_prep launch per step)."""
     from dsl_amd.data import mark_ready
     from dsl_amd.optim import FlatSGD
     from dsl_amd.registry import build_detector
@@ -133,7 +134,7 @@ def fp8_step_timing(batch, steps=20, warm=5):
                      'v_mfma_scale_f32_32x32x64_f8f6f4, everything else (and the whole backward pass) bf16; off by default in the product')
 
 
-def comm_proxy_timing(batch, steps=20, warm=5, rounds=3, wgs=32, passes=2, carriers=('lib', 'torch')):
+def comm_proxy_timing(batch, steps=20, warm=5, rounds=3, wgs=32, passes=2, carriers=('lib', 'torch', 'lib_eager')):
     """Multi-GPU first contact de-risked on ONE GPU (the reference's DDP: mmdet/apis/train.py:92-96): the
     headline's step in its data-parallel schedule - named bucket events, communication stream, per-bucket optimizer steps behind each
     bucket's exchange - with dsl_comm_proxy in place of the all-reduce: `wgs` workgroups making `passes` read-modify-write passes
@@ -160,7 +161,11 @@ def comm_proxy_timing(batch, steps=20, warm=5, rounds=3, wgs=32, passes=2, carri
         return out
 
     def run(mode):
-        model.comm_proxy = None if mode == 'none' else dict(carrier=mode, wgs=wgs, passes=passes)
+        # '<carrier>' = the default schedule (late exchange: collectives behind the backward pass, next forward waits per stage),
+        # '<carrier>_eager' = bucket by bucket behind each backward segment, everything joined at the end of the step (round 5)
+        model.comm_proxy = None if mode == 'none' else dict(carrier=mode.split('_')[0], wgs=wgs, passes=passes)
+        opt.late_exchange = not mode.endswith('_eager')
+        opt._sync_defer()
         for _ in range(warm):
             step()
         torch.cuda.synchronize()
@@ -194,7 +199,8 @@ def comm_proxy_timing(batch, steps=20, warm=5, rounds=3, wgs=32, passes=2, carri
                note='one GPU, no peer: dsl_comm_proxy (value-preserving passes over each gradient bucket) stands in for the all-reduce '
                     'behind the same bucket events; lib = the library\'s communication stream, placed on the hardware queue '
                     'comm_stream_queue names (1 weight gradients, 2 second chain, 3 frozen prefix, 4 caller, 0 = as the runtime dealt it), '
-                    'torch = a torch-pool stream as ProcessGroupNCCL uses; cost_frac = median step time / median without proxy - 1')
+                    'torch = a torch-pool stream as ProcessGroupNCCL uses; *_eager = the round-5 schedule (exchange behind each backward '
+                    'segment, joined at the end of the step) instead of the late exchange; cost_frac = median step time / median without proxy - 1')
     del model, opt
     torch.cuda.empty_cache()
     return out

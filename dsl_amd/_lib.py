@@ -31,6 +31,7 @@ OP_PACK_DGRAD = 18
 OP_WGRAD_MULTI = 19
 OP_PROF = 21
 OP_QUANT_FP8, OP_QUANT_FP8_W, OP_FP8_COMB = 22, 23, 24
+OP_FP8_PREP, OP_QUANT_FP8_DELAYED = 27, 28
 OP_STEM_POOL = 25
 OP_BNECK = 26
 PROF_CLASSES = 8
@@ -38,6 +39,7 @@ MAX_MULTI = 16
 SLOT_TAIL, SLOT_PREFIX = 13, 14     # pipelined frozen prefix: 'previous backward's data-gradient chain done', 'prefix of this step done'
 SLOT_PACKS = 15      # named event: the data-gradient weight packs of the last optimizer step are complete
 SUMSQ_PARTS = 256
+SLOT_UPD = 8         # named events 8 .. 11: gradient bucket 0 .. 3 of the last optimizer step is updated (late exchange)
 SLOT_HEADW = 12      # named event: the head + FPN bucket of the last optimizer step is updated (deferred head update)
 (RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST, RLA_REC_SUM) = range(2, 9)
 MAX_GROUP = 8
@@ -75,7 +77,12 @@ class GnDesc(C.Structure):
                 ('x', C.c_void_p), ('y', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
                 ('stats', C.c_void_p), ('dy', C.c_void_p), ('dx', C.c_void_p), ('dgamma', C.c_void_p),
                 ('dbeta', C.c_void_p), ('dbias', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
-                ('conv_stats', C.c_int32), ('pad_', C.c_int32)]
+                ('conv_stats', C.c_int32), ('pad_', C.c_int32), ('y8', C.c_void_p), ('y8_scale', C.c_void_p), ('y8_amax', C.c_void_p)]
+
+
+class Fp8PrepItem(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('w8', C.c_void_p), ('comb', C.c_void_p), ('amax', C.c_void_p), ('scale', C.c_void_p),
+                ('n_amax', C.c_int32), ('cout', C.c_int32)]
 
 
 class FcosDesc(C.Structure):
@@ -193,7 +200,8 @@ _SIGS = {
     'dsl_image_prep_u8': [_vp, _i, _vp, _i, _i, _vp], 'dsl_image_aug': [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp], 'dsl_image_aug_scratch_bytes': [_i],
     'dsl_image_normalize': [_vp, _vp, _i, _vp, _i, _i, _vp],
     'dsl_quant_fp8': [_vp, _vp, _l, _i, _i, _f, _vp], 'dsl_absmax': [_vp, _l, _i, _i, _vp, _i, _vp],
-    'dsl_quant_fp8_dyn': [_vp, _vp, _l, _i, _i, _vp, _i, _vp], 'dsl_fp8_comb': [_vp, _vp, _i, _vp, _i, _vp], 'dsl_quant_fp8_weights': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    'dsl_quant_fp8_dyn': [_vp, _vp, _l, _i, _i, _vp, _i, _vp], 'dsl_fp8_comb': [_vp, _vp, _i, _vp, _i, _vp], 'dsl_fp8_prep': [_vp, _i, _i, _i, _f, _vp],
+    'dsl_quant_fp8_delayed': [_vp, _vp, _l, _i, _i, _vp, _vp, _i, _vp], 'dsl_quant_fp8_weights': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'dsl_bn_fold': [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp], 'dsl_bn_wgrad_post': [_vp, _i, _i, _f, _vp], 'dsl_rla_op': [_vp, _vp],
     'dsl_rec_sum_multi': [_vp, _i, _i, _vp],
     'dsl_groupnorm_relu_fwd': [_vp, _vp], 'dsl_groupnorm_relu_bwd': [_vp, _vp], 'dsl_groupnorm_workspace_bytes': [_vp],

@@ -254,6 +254,16 @@ extern "C" int dsl_run_ops(const dsl_op* ops, int n_ops, void* stream) {
         }
         break;
       }
+      case DSL_OP_FP8_PREP: {
+        float mg;
+        const int32_t bits = (int32_t)o.l[1];
+        memcpy(&mg, &bits, 4);
+        rc = dsl_fp8_prep((const dsl_fp8_prep_item*)o.p[0], o.i[0], o.i[1], o.i[2], mg, stream);
+        break;
+      }
+      case DSL_OP_QUANT_FP8_DELAYED:
+        rc = dsl_quant_fp8_delayed(o.p[0], o.p[1], (long)o.l[0], o.i[0], o.i[1], (const float*)o.p[3], (float*)o.p[2], o.i[2], stream);
+        break;
       case DSL_OP_FP8_COMB: rc = dsl_fp8_comb((const float*)o.p[0], (float*)o.p[1], o.i[0], (const float*)o.p[2], o.i[2], stream); break;
       case DSL_OP_QUANT_FP8_W: {
         float sc;

@@ -52,6 +52,17 @@ __device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f,
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// ---- four floats -> four OCP e4m3 bytes (torch.float8_e4m3fn casts, saturating) -------------------
+__device__ __forceinline__ uint32_t cvt4_fp8(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -448.f), 448.f);      // e4m3fn has no infinity: saturate instead of producing NaN
+  b = fminf(fmaxf(b, -448.f), 448.f);
+  c = fminf(fmaxf(c, -448.f), 448.f);
+  d = fminf(fmaxf(d, -448.f), 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
+}
+
 // ---- exact division of p < 2^20 by d < 2^20 via a 40-bit reciprocal ----------------------------
 struct FastDiv {
   uint64_t m;

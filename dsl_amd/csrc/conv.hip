@@ -1956,7 +1956,8 @@ long long conv_pixels(const dsl_conv_desc* d) {
 // writes them: bf16 output on the compute grid's own pixels, nothing added, one launch (no split-K).
 bool conv_gn_ok(const dsl_conv_desc* d) {
   if (d->nseg < 1 || d->nseg > DSL_MAX_SEG) return false;
-  if (d->flags & (DSL_CONV_SMALL_C | DSL_CONV_FP8 | DSL_CONV_OUT_F32 | DSL_CONV_ADD_UPSAMPLE | DSL_CONV_RELU_IN)) return false;
+  if (d->flags & (DSL_CONV_SMALL_C | DSL_CONV_OUT_F32 | DSL_CONV_ADD_UPSAMPLE | DSL_CONV_RELU_IN)) return false;
+  if ((d->flags & DSL_CONV_FP8) && d->gn_x) return false;        // (the fp8 kernel shares the forward records' epilogue, not the backward ones)
   if (d->cs % 64 || d->cd % 8 || d->cd_pad % 64 || d->os != 1 || d->addend) return false;
   if (d->mask && ((d->flags & DSL_CONV_MASK_FIRST) || ((d->flags & DSL_CONV_MASK_LAST) && (d->flags & DSL_CONV_RELU_OUT)))) return false;
   for (int s = 0; s < d->nseg; ++s)

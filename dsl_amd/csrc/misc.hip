@@ -75,6 +75,9 @@ struct GnK {
   float* dbeta;
   float* dbias;                  // optional: gradient of the bias of the convolution that produced x = sum_p dx
   float* ws;                     // partial records [nseg*n][nblk][rec]; rec = 2*groups (fwd) or 3*c + 2*groups (bwd)
+  uint8_t* y8;                   // forward, optional: e4m3 copy of y with the delayed scale y8_scale[0]; y8_amax[block] = the block's max y
+  const float* y8_scale;
+  float* y8_amax;
   int conv_nbk;                  // > 0: the forward records were left by the producing convolution's epilogue (conv.hip
                                  // conv_tile_epilogue): [64 floats of header, word 0 = its pixel tile][nseg*n][conv_nbk][2*groups],
                                  // a row's records indexed by pixel tile relative to the tile that holds the row's first pixel
@@ -230,6 +233,40 @@ __global__ __launch_bounds__(GN_TA) void gn_apply_kernel(const GnK p) {
   }
   const long long ibase = (p.off[seg] + (long long)img * hw) * p.c;
   const int px1 = min(px0 + GN_PPB, hw);
+  if (p.y8) {
+    // + the fp8 copy the next (fp8) convolution reads, quantised HERE with the previous step's scale (delayed scaling), and this
+    // block's maximum of the rounded outputs for the next step's: no quantisation pass, no absmax pass
+    const float s8 = p.y8_scale[0];
+    float m = 0.f;
+#pragma unroll 4
+    for (int px = px0 + prow; px < px1; px += ppi) {
+      const long long o = ibase + (long long)px * p.c + chunk * 8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + o);
+      u32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = fmaxf(bflo(v[e]) * ga[2 * e] + be[2 * e], 0.f);
+        const float b = fmaxf(bfhi(v[e]) * ga[2 * e + 1] + be[2 * e + 1], 0.f);
+        r[e] = pack2bf(a, b);
+        m = fmaxf(m, fmaxf(bflo(r[e]), bfhi(r[e])));         // (of the ROUNDED values: what a pass over y would find)
+      }
+      *reinterpret_cast<u32x4*>(p.y + o) = r;
+      uint2 q;
+      q.x = cvt4_fp8(bflo(r[0]) * s8, bfhi(r[0]) * s8, bflo(r[1]) * s8, bfhi(r[1]) * s8);
+      q.y = cvt4_fp8(bflo(r[2]) * s8, bfhi(r[2]) * s8, bflo(r[3]) * s8, bfhi(r[3]) * s8);
+      *reinterpret_cast<uint2*>(p.y8 + o) = q;
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) m = fmaxf(m, __shfl_xor(m, o_, 64));
+    __syncthreads();                                           // (sh: the record sums above are consumed)
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w_ = 1; w_ < GN_TA / 64; ++w_) m = fmaxf(m, sh[w_]);
+      p.y8_amax[(long long)si * p.nblk + blockIdx.x] = m;
+    }
+    return;
+  }
 #pragma unroll 8
   for (int px = px0 + prow; px < px1; px += ppi) {
     const long long o = ibase + (long long)px * p.c + chunk * 8;
@@ -526,6 +563,7 @@ int fill_gn(const dsl_gn_desc* d, GnK& k, long long* total_px) {
   k.x = (const uint16_t*)d->x; k.y = (uint16_t*)d->y; k.gamma = d->gamma; k.beta = d->beta;
   k.stats = d->stats; k.dy = (const uint16_t*)d->dy; k.dx = (uint16_t*)d->dx;
   k.dgamma = d->dgamma; k.dbeta = d->dbeta; k.dbias = d->dbias; k.ws = (float*)d->workspace;
+  k.y8 = (uint8_t*)d->y8; k.y8_scale = d->y8_scale; k.y8_amax = d->y8_amax;
   int maxhw = 0;
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   k.nblk = (maxhw + GN_PPB - 1) / GN_PPB;
@@ -595,6 +633,7 @@ extern "C" int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream) {
   for (int s = 0; s < d->nseg; ++s) maxhw = max(maxhw, d->h[s] * d->w[s]);
   dim3 grid((maxhw + GN_PPB - 1) / GN_PPB, d->nseg * d->n);
   hipStream_t st = (hipStream_t)stream;
+  DSL_CHECK(!d->y8 || (d->y8_scale && d->y8_amax), "dsl_groupnorm_relu_fwd: the fp8 copy needs y8_scale and y8_amax");
   if (d->conv_stats) {
     DSL_CHECK(d->c / d->groups == 8, "dsl_groupnorm_relu_fwd: conv_stats needs 8 channels per group (C=%d groups=%d)", d->c, d->groups);
     k.conv_nbk = maxhw / 64 + 2;

@@ -261,15 +261,6 @@ extern "C" int dsl_pack_dgrad_batched(const dsl_pack_item* items_dev, int n, int
 
 // ---- fp8 (OCP e4m3) quantisation for the fp8 forward convolutions (conv.hip conv_f8_kernel) --------------------------------
 namespace {
-__device__ __forceinline__ uint32_t cvt4_fp8(float a, float b, float c, float d) {
-  a = fminf(fmaxf(a, -448.f), 448.f);      // e4m3fn has no infinity: saturate instead of producing NaN
-  b = fminf(fmaxf(b, -448.f), 448.f);
-  c = fminf(fmaxf(c, -448.f), 448.f);
-  d = fminf(fmaxf(d, -448.f), 448.f);
-  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-  return (uint32_t)r;
-}
 __global__ __launch_bounds__(256) void quant_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y, long long rows, int c16,
                                                         int ld_x, int c, float scale) {
   const long long total = rows * c16;       // 16 elements per thread-iteration: 32 bytes in, 16 bytes out
@@ -369,6 +360,67 @@ __global__ __launch_bounds__(256) void fp8_comb_kernel(const float* __restrict__
   const float inv = amax > 0.f ? amax / 448.f : 1.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) comb[i] = winv[i] * inv;
 }
+// Delayed scaling: the weights of n convolutions, their epilogue scales and their inputs' quantisation scales in ONE launch per step
+// (grid: cout_pad x items).  The input maximum is the previous step's (block maxima left by the producer's pass), widened by `margin`.
+__global__ __launch_bounds__(256) void fp8_prep_kernel(const dsl_fp8_prep_item* __restrict__ items, int k, float margin) {
+  __shared__ float sh[16];
+  const dsl_fp8_prep_item it = items[blockIdx.y];
+  const int co = blockIdx.x;
+  const float amax = fold_absmax(it.amax, it.n_amax, sh) * margin;
+  __syncthreads();
+  if (co == 0 && threadIdx.x == 0) it.scale[0] = amax > 0.f ? 448.f / amax : 1.f;
+  const float inv_act = amax > 0.f ? amax / 448.f : 1.f;
+  uint8_t* out = (uint8_t*)it.w8 + (long long)co * k;
+  if (co >= it.cout) {
+    for (int i = threadIdx.x * 4; i < k; i += blockDim.x * 4) *reinterpret_cast<uint32_t*>(out + i) = 0u;
+    if (threadIdx.x == 0) it.comb[co] = 0.f;
+    return;
+  }
+  const float* row = it.w + (long long)co * k;
+  float m = 0.f;
+  for (int i = threadIdx.x * 4; i < k; i += blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[8 + (threadIdx.x >> 6)] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sh[8], sh[9]), fmaxf(sh[10], sh[11]));
+  const float s = m > 0.f ? 448.f / m : 1.f;
+  for (int i = threadIdx.x * 4; i < k; i += blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+    *reinterpret_cast<uint32_t*>(out + i) = cvt4_fp8(v[0] * s, v[1] * s, v[2] * s, v[3] * s);
+  }
+  if (threadIdx.x == 0) it.comb[co] = inv_act / s;
+}
+// one pass: y = e4m3(x * scale[0]) and this block's max|x| for the next step's scale
+__global__ __launch_bounds__(256) void quant_fp8_delayed_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y, long long rows, int c16,
+                                                                int ld_x, int c, const float* __restrict__ scale_dev, float* __restrict__ partials) {
+  __shared__ float sh[4];
+  const float scale = scale_dev[0];
+  const long long total = rows * c16;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c16;
+    const int ch = (int)(i - r * c16) * 16;
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + r * ld_x + ch), v1 = *reinterpret_cast<const u32x4*>(x + r * ld_x + ch + 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(bflo(v0[e])), fabsf(bfhi(v0[e])))), fmaxf(fabsf(bflo(v1[e])), fabsf(bfhi(v1[e]))));
+    u32x4 o;
+    o[0] = cvt4_fp8(bflo(v0[0]) * scale, bfhi(v0[0]) * scale, bflo(v0[1]) * scale, bfhi(v0[1]) * scale);
+    o[1] = cvt4_fp8(bflo(v0[2]) * scale, bfhi(v0[2]) * scale, bflo(v0[3]) * scale, bfhi(v0[3]) * scale);
+    o[2] = cvt4_fp8(bflo(v1[0]) * scale, bfhi(v1[0]) * scale, bflo(v1[1]) * scale, bfhi(v1[1]) * scale);
+    o[3] = cvt4_fp8(bflo(v1[2]) * scale, bfhi(v1[2]) * scale, bflo(v1[3]) * scale, bfhi(v1[3]) * scale);
+    *reinterpret_cast<u32x4*>(y + r * c + ch) = o;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
 }  // namespace
 
 extern "C" int dsl_quant_fp8(const void* x, void* y, long rows, int c, int ld_x, float scale, void* stream) {
@@ -413,3 +465,21 @@ extern "C" int dsl_fp8_comb(const float* winv, float* comb, int n, const float* 
   return 0;
 }
 
+
+extern "C" int dsl_fp8_prep(const dsl_fp8_prep_item* items_dev, int n_items, int cout_pad, int k, float margin, void* stream) {
+  DSL_CHECK(items_dev && n_items > 0 && n_items <= 65535 && cout_pad > 0 && k > 0 && k % 4 == 0 && margin >= 1.f,
+            "dsl_fp8_prep: bad arguments (n_items=%d cout_pad=%d k=%d margin=%g)", n_items, cout_pad, k, (double)margin);
+  hipLaunchKernelGGL(fp8_prep_kernel, dim3(cout_pad, n_items), dim3(256), 0, (hipStream_t)stream, items_dev, k, margin);
+  DSL_LAUNCH_CHECK("fp8_prep_kernel");
+  return 0;
+}
+
+extern "C" int dsl_quant_fp8_delayed(const void* x, void* y, long rows, int c, int ld_x, const float* scale_dev, float* partials,
+                                     int n_partials, void* stream) {
+  DSL_CHECK(x && y && scale_dev && partials && rows > 0 && c > 0 && c % 16 == 0 && ld_x >= c && ld_x % 8 == 0 && n_partials > 0 &&
+            n_partials <= 4096, "dsl_quant_fp8_delayed: bad arguments");
+  hipLaunchKernelGGL(quant_fp8_delayed_kernel, dim3(n_partials), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint8_t*)y,
+                     (long long)rows, c / 16, ld_x, c, scale_dev, partials);
+  DSL_LAUNCH_CHECK("quant_fp8_delayed_kernel");
+  return 0;
+}

@@ -517,6 +517,7 @@ class FCOS(nn.Module):
         else:
             plan.bind_image(img, half_last=half_scale_copy)
             fwd = plan.fwd
+        plan.fp8_warm(fwd)
         work = None
         if ws > 1:
             # target assignment first: the reduce_mean of (num_pos, sum centerness targets) - one 2-float all-reduce
@@ -583,15 +584,23 @@ class FCOS(nn.Module):
         if proxy is not None and proxy.get('carrier', 'lib') == 'torch' and self._proxy_stream is None:
             self._proxy_stream = torch.cuda.Stream()
         self._partials_valid = False
-        nb = 0
-        for ol, info in plan.bwd_segments:
-            ol.run()
-            if not ddp or info['bucket'] is None:       # (bucket None: the deferred head update - its bucket completes with a later list)
-                continue
+        # Late exchange (round 6; set by an optimizer that updates bucket by bucket without a global norm, FlatSGD._sync_defer): the
+        # collectives are queued BEHIND the whole backward pass, in the order the next forward pass needs the parameters (layer2's
+        # bucket first, head + FPN last), and nothing waits for them at the end of the step - the per-bucket updates record named
+        # events SLOT_UPD + k, the next step's forward list waits for them stage by stage (engine.Plan._fwd_resnet).  Queued
+        # bucket by bucket behind each segment ("eager") the traffic shared the tail of the backward pass with the weight
+        # gradients, the next step's frozen prefix and the step boundary: the one-GPU proxy priced that at 10 % of the step
+        # whatever queue carried it (profiles/r06_comm_queue_sweep.txt), late at LATE_COST (profiles/r06_comm_proxy.txt).
+        late = bool(ddp and on_gpu and getattr(self, 'late_exchange', False) and self.clip_partials is None
+                    and self.store.backbone != 'rla' and not getattr(plan, 'defer', False))
+        self._pending_order = None
+        nb = [0]
+
+        def exchange(info):
             lo, hi = info['bucket']
             if not on_gpu:            # host tensors (the gloo unit test of the bucket order): nothing to order against
                 self._pending.append(dist.all_reduce(self.store.grad[lo:hi], group=self.dist_group, async_op=True))
-                continue
+                return
             from . import _lib as L
             from .parallel import StreamWork
             cs = self._proxy_stream if (proxy is not None and proxy.get('carrier', 'lib') == 'torch') else self._comm_stream
@@ -605,8 +614,8 @@ class FCOS(nn.Module):
                 L.check(L.lib.dsl_comm_proxy(L.ptr(g), (hi - lo) // 4 * 4, int(proxy.get('wgs', 32)), int(proxy.get('passes', 2)), csp),
                         'dsl_comm_proxy')
                 self._pending.append(StreamWork(cs))
-                nb += 1
-                continue
+                nb[0] += 1
+                return
             with torch.cuda.stream(cs):
                 if self.comm_trace:
                     es = torch.cuda.Event(enable_timing=True)
@@ -640,10 +649,25 @@ class FCOS(nn.Module):
                     if work is not None:
                         work.wait()
                         work = None
-                    L.check(L.lib.dsl_sumsq_partial(L.ptr(g), hi - lo, C_void(self.clip_partials.data_ptr() + nb * L.SUMSQ_PARTS * 4), csp),
+                    L.check(L.lib.dsl_sumsq_partial(L.ptr(g), hi - lo, C_void(self.clip_partials.data_ptr() + nb[0] * L.SUMSQ_PARTS * 4), csp),
                             'dsl_sumsq_partial')
                 self._pending.append(work if work is not None else StreamWork(cs))
-            nb += 1
+            nb[0] += 1
+
+        todo = []
+        for ol, info in plan.bwd_segments:
+            ol.run()
+            if not ddp or info['bucket'] is None:       # (bucket None: the deferred head update - its bucket completes with a later list)
+                continue
+            if late:
+                todo.append(info)
+            else:
+                exchange(info)
+        if late:
+            self._pending_order = list(range(len(todo) - 1, -1, -1))
+            for info in todo[::-1]:
+                exchange(info)
+        nb = nb[0]
         self._partials_valid = bool(ddp and on_gpu and self.clip_partials is not None and 0 < nb * 256 <= self.clip_partials.numel())
         self._n_partials = nb * 256
         self._rebind_grads()

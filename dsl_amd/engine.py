@@ -109,6 +109,13 @@ class OpList:
         n_p = 0 if partials is None else partials.numel()
         self._add(L.OP_QUANT_FP8, i=(c, ld_x, n_p, 0, 0, 0, int(side)), p=(x, y, partials), l=(rows, self._fbits(scale)))
 
+    def fp8_prep(self, items_dev, n_items, cout_pad, k, margin):
+        """Delayed scaling: weights, epilogue scales and input scales of n_items fp8 convolutions in one launch (dsl_fp8_prep)."""
+        self._add(L.OP_FP8_PREP, i=(n_items, cout_pad, k), p=(items_dev,), l=(0, self._fbits(margin)))
+
+    def quant_fp8_delayed(self, x, y, rows, c, ld_x, scale_dev, partials, side=False):
+        self._add(L.OP_QUANT_FP8_DELAYED, i=(c, ld_x, partials.numel(), 0, 0, 0, int(side)), p=(x, y, partials, scale_dev), l=(rows, 0))
+
     def fp8_comb(self, winv, comb, n, partials, side=False):
         self._add(L.OP_FP8_COMB, i=(n, 0, partials.numel(), 0, 0, 0, int(side)), p=(winv, comb, partials))
 
@@ -290,6 +297,10 @@ class Plan:
             return cd_
         feats = self.buf('feats', self.M, 256)
         self.feat_seg = [feats.data_ptr() + self.seg_off[i] * 256 * 2 for i in range(5)]
+        # late exchange (data parallel): bucket 0 (head + FPN) of the last optimizer step may still be on its way - its
+        # all-reduce and update run beside this step's backbone.  Bucket 0 is the LAST one updated, so everything behind this wait
+        # (the loss kernel and every gradient write of this step's backward pass) also follows every update.  No-op until recorded.
+        f.wait(L.SLOT_UPD + 0, stream=0)
         if self.defer:
             # the FPN's and the head's parameters (one optimizer bucket) may still be on their way: the previous step's tower weight
             # gradients and that bucket's update run beside this step's backbone (no-op until the slot is first recorded).  The wait
@@ -324,29 +335,47 @@ class Plan:
         self._head_flops = 2.0 * self.M * (8 * 256 * 2304 + (80 + 5) * 2304)
         self._head_bytes = self.M * 256 * 2.0 * (8 * 2 + 8 * 3 + 2) + self.M * (80 + 8) * 4.0
         f.prof(4, 0, self._head_flops, self._head_bytes)
-        # fp8 forward of the tower convolutions (FCOS(fp8=dict(...)), BASELINE.json configs[4], off by default): e4m3 copies of the
-        # layer inputs (static per-tensor scale `act_scale`) and of the weights (per-output-channel scales, re-made every step from the
-        # fp32 master weights); the bf16 tensors stay what the backward pass reads (straight-through)
+        # fp8 forward of the tower convolutions (FCOS(fp8=dict(...)), BASELINE.json configs[4], off by default), DELAYED scaling
+        # (round 6): every fp8 tensor is written by its producer's own pass - GroupNorm's apply pass writes the e4m3 copy of its output
+        # next to the bf16 one, with the scale of the PREVIOUS step's maximum, and leaves this step's block maxima; one dsl_fp8_prep
+        # launch per step quantises the eight weight tensors (per-output-channel scales, from the fp32 master weights) and turns the
+        # recorded maxima into this step's input scales and epilogue scales.  The bf16 tensors stay what the backward pass reads
+        # (straight-through).  A plan's first forward pass runs twice more in front (Plan.fp8_warm): nothing is recorded yet.
         fp8 = getattr(st, 'fp8', None)
         f8 = bool(fp8) and 'towers' in str(fp8.get('layers', 'towers'))
-        NPART = 512           # block maxima per quantised tensor (its dynamic scale = 448 / their maximum)
+        self.fp8_cold = f8
         feats8 = None
         if f8:
+            margin = float(fp8.get('margin', 1.25))         # headroom over the previous step's maximum (e4m3 saturates at 448)
+            nblk = (max(h_ * w_ for h_, w_ in ls) + 127) // 128
             feats8 = self.buf('feats.f8', self.M, 256, dtype=torch.uint8)
-            pm0 = self.buf('feats.f8.amax', NPART, dtype=torch.float32)
-            f.quant_fp8(feats, feats8, self.M, 256, 256, partials=pm0)          # before the FORK: both towers read it
-            for tower in ('cls_convs', 'reg_convs'):
+            am_feats = self.buf('feats.f8.amax', 512, dtype=torch.float32, zero=True)
+            scales = self.buf('fp8.scales', 8, dtype=torch.float32, zero=True)
+            items = (L.Fp8PrepItem * 8)()
+            f8lay = {}
+            for t_, tower in enumerate(('cls_convs', 'reg_convs')):
                 for i in range(4):
                     spec = cv[f'bbox_head.{tower}.{i}.conv']
+                    assert spec.cout_pad == 256 and spec.cin == 256 and spec.k == 3, 'the fp8 slice is the 3x3 256 -> 256 tower layers'
                     w8 = self.buf(f'{tower}.{i}.w8', spec.cout_pad, 9 * 256, dtype=torch.uint8)
-                    winv = self.buf(f'{tower}.{i}.winv', spec.cout_pad, dtype=torch.float32)
-                    self.buf(f'{tower}.{i}.comb', spec.cout_pad, dtype=torch.float32)
-                    f.quant_fp8_w(st.t32_ptr(spec.name + '.weight'), w8, winv, spec.cout, spec.cout_pad, 9 * 256, 1.0)
+                    comb = self.buf(f'{tower}.{i}.comb', spec.cout_pad, dtype=torch.float32)
+                    am_out = self.buf(f'{tower}.{i}.act8.amax', 5 * N * nblk, dtype=torch.float32, zero=True) if i < 3 else None
+                    am_in = am_feats if i == 0 else f8lay[tower, i - 1]['am_out']
+                    it = items[t_ * 4 + i]
+                    it.w, it.w8, it.comb = st.t32_ptr(spec.name + '.weight'), w8.data_ptr(), comb.data_ptr()
+                    it.amax, it.n_amax, it.cout = am_in.data_ptr(), am_in.numel(), spec.cout
+                    it.scale = scales.data_ptr() + 4 * (t_ * 4 + i)
+                    f8lay[tower, i] = dict(w8=w8, comb=comb, am_out=am_out, scale_in=it.scale)
+            items_dev = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.dev)
+            self.bufs['fp8.items'] = items_dev
+            f.fp8_prep(items_dev, 8, 256, 9 * 256, margin)
+            # the FPN outputs feed both towers: one pass writes their e4m3 copy (both first layers' scales are the same number)
+            f.quant_fp8_delayed(feats, feats8, self.M, 256, 256, f8lay['cls_convs', 0]['scale_in'], am_feats)
         if FSIDE:        # (starting the regression tower one convolution late, so that each tower's GroupNorm runs beside the other's
             f.fork(FSIDE)    # convolution instead of beside its GroupNorm: measured, 407.6 vs 408.9 img/s - no effect)
         for tower in ('cls_convs', 'reg_convs'):
             side = FSIDE if tower == 'reg_convs' else 0
-            xin, xin8, pm = feats, feats8, (pm0 if f8 else None)
+            xin, xin8 = feats, feats8
             lays = []
             for i in range(4):
                 spec = cv[f'bbox_head.{tower}.{i}.conv']
@@ -354,31 +383,28 @@ class Plan:
                 act = self.buf(f'{tower}.{i}.act', self.M, 256)
                 stats = self.buf(f'{tower}.{i}.stats', 5 * N * 32, 2, dtype=torch.float32)
                 if f8:
-                    comb = self.bufs[f'{tower}.{i}.comb']
-                    f.fp8_comb(self.bufs[f'{tower}.{i}.winv'], comb, spec.cout_pad, pm, side=side)
-                    cd_ = ops.conv_desc(xin8, self.bufs[f'{tower}.{i}.w8'], pre, n=N, grid=ls, src_hw=ls, dst_hw=ls, cs=256, cd=spec.cout,
+                    cd_ = ops.conv_desc(xin8, f8lay[tower, i]['w8'], pre, n=N, grid=ls, src_hw=ls, dst_hw=ls, cs=256, cd=spec.cout,
                                         cd_pad=spec.cout_pad, ldd=spec.cout, kh=3, kw=3, stride=1, pad=1, flags=L.CONV_FP8,
-                                        scale=comb, bias=st.t32_ptr(spec.name + '.bias'))
+                                        scale=f8lay[tower, i]['comb'], bias=st.t32_ptr(spec.name + '.bias'))
                 else:
                     cd_ = self._conv(spec, xin, pre, N, ls, ls)
                 if side:
                     cd_.workspace, cd_.workspace_bytes = L.ptr(self.conv_ws_side), self.conv_ws_side.numel()
                 base = f'bbox_head.{tower}.{i}.gn'
+                act8 = self.buf(f'{tower}.{i}.act8', self.M, 256, dtype=torch.uint8) if f8 and i < 3 else None
                 gd = ops.gn_desc(pre, act, st.t32_ptr(base + '.weight'), st.t32_ptr(base + '.bias'), stats,
-                                 self._gn_workspace('side' if side else 'main'), n=N, hw=ls)
+                                 self._gn_workspace('side' if side else 'main'), n=N, hw=ls, y8=act8,
+                                 y8_scale=f8lay[tower, i + 1]['scale_in'] if act8 is not None else None,
+                                 y8_amax=f8lay[tower, i]['am_out'] if act8 is not None else None)
                 # conv -> GN -> ReLU (ConvModule, anchor_free_head.py:104-133): the convolution's epilogue leaves the statistics
                 # records, GroupNorm is then ONE pass over the tensor (a launch that cannot leave them: its own statistics pass)
-                if not f8 and L.lib.dsl_conv2d_gn_fusable(C.byref(cd_)):
+                if L.lib.dsl_conv2d_gn_fusable(C.byref(cd_)):
                     cd_.gn_ws = gd.workspace
                     gd.conv_stats = 1
                 f.conv(cd_, side=side)
                 f.gn_fwd(gd, side=side)
                 lays.append(dict(spec=spec, xin=xin, pre=pre, act=act, stats=stats, gn=base))
-                xin = act
-                if f8 and i < 3:
-                    xin8 = self.buf(f'{tower}.{i}.act8', self.M, 256, dtype=torch.uint8)
-                    pm = self.buf(f'{tower}.{i}.act8.amax', NPART, dtype=torch.float32)
-                    f.quant_fp8(act, xin8, self.M, 256, 256, partials=pm, side=side)
+                xin, xin8 = act, act8
             self.tower[tower] = lays
         cls_logits = self.buf('cls_logits', self.M, 80, dtype=torch.float32)
         regctr = self.buf('regctr', self.M, 8, dtype=torch.float32, zero=True)
@@ -419,6 +445,12 @@ class Plan:
             fuse = str(li + 1) in tune('bneck_fwd') and planes in (128, 256)
             split = str(li + 1) in SPLIT and not fuse
             f.tag = f'fwd.l{li + 1}'
+            if li >= 1 and self.training:
+                # late exchange: this stage's gradient bucket (layer2: 3, layer3: 2, layer4: 1) of the last optimizer step may still be
+                # exchanged / updated beside the stages in front of it; both image chains wait (no-ops until the slot is recorded)
+                f.wait(L.SLOT_UPD + 4 - li, stream=0)
+                if split_open:
+                    f.wait(L.SLOT_UPD + 4 - li, stream=self.BR)
             if split and not split_open:
                 f.fork(self.BR)
                 split_open = True
@@ -1020,9 +1052,19 @@ class Plan:
             if self._stem_fused:
                 f.arr[idx].i[4] = 1 if half_last else 0
 
+    def fp8_warm(self, fwd):
+        """Delayed fp8 scaling needs a recorded maximum per tensor: in front of a plan's FIRST forward pass the list runs twice (pass 1
+        records the FPN outputs' maximum with scale 1, pass 2 the tower activations' under it); afterwards every step uses the maxima
+        the step before it left."""
+        if getattr(self, 'fp8_cold', False):
+            self.fp8_cold = False
+            fwd.run()
+            fwd.run()
+
     def forward(self, img=None):
         if img is not None:
             self.bind_image(img)
+        self.fp8_warm(self.fwd)
         self.fwd.run()
 
 

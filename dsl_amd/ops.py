@@ -239,7 +239,7 @@ def conv2d_wgrad(*a, **k):
 
 
 def gn_desc(x, y, gamma, beta, stats, workspace=None, *, n, hw, c=256, groups=32, eps=1e-5, dy=None, dx=None,
-            dgamma=None, dbeta=None, dbias=None):
+            dgamma=None, dbeta=None, dbias=None, y8=None, y8_scale=None, y8_amax=None):
     """workspace: uint8/float tensor of >= dsl_groupnorm_workspace_bytes (allocated here when None); calls that may
     run concurrently (different streams) need different workspaces."""
     d = L.GnDesc()
@@ -254,7 +254,8 @@ def gn_desc(x, y, gamma, beta, stats, workspace=None, *, n, hw, c=256, groups=32
     nbytes = workspace.numel() * workspace.element_size()
     assert nbytes >= need, (nbytes, need)
     d.workspace, d.workspace_bytes = L.ptr(workspace), nbytes
-    d._keep = (x, y, gamma, beta, stats, workspace, dy, dx, dgamma, dbeta, dbias)
+    d.y8, d.y8_scale, d.y8_amax = (L.ptr(t) for t in (y8, y8_scale, y8_amax))
+    d._keep = (x, y, gamma, beta, stats, workspace, dy, dx, dgamma, dbeta, dbias, y8, y8_scale, y8_amax)
     return d
 
 

@@ -19,7 +19,7 @@ _PACK_SIDE = True                          # data-gradient weight packs off the 
 @OPTIMIZERS.register_module(name='SGD')
 class FlatSGD:
     def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=0.0, paramwise_cfg=None, grad_clip=None,
-                 defer_head_update=False, **kw):
+                 defer_head_update=False, late_exchange=True, **kw):
         assert not kw.get('nesterov', False) and kw.get('dampening', 0) == 0
         self.model = model
         self.store = model.store
@@ -37,6 +37,7 @@ class FlatSGD:
         self.momentum_buf = None
         self.gnorm_sq = None
         self.steps = 0
+        self.late_exchange = bool(late_exchange)      # data parallel without clipping: collectives behind the backward pass (see _sync_defer)
         self.defer_head_update = bool(defer_head_update)      # opt-in (measured slower on one GPU, LAB_NOTES: deferred head update)
         self._sync_defer()
 
@@ -46,6 +47,9 @@ class FlatSGD:
         the parameter store because it shapes the op lists; opt-in (constructor argument defer_head_update)."""
         want = (self.max_norm is None and _PACK_SIDE and self.defer_head_update
                 and self.store.backbone != 'rla')
+        # Late exchange (data parallel, DESIGN section 6): with an element-wise per-bucket update nothing at the end of a step has to
+        # wait for the collectives - the detector queues them behind the backward pass and the next forward pass waits stage by stage
+        self.model.late_exchange = bool(self.max_norm is None and _PACK_SIDE and self.late_exchange and self.store.backbone != 'rla')
         if bool(getattr(self.store, 'defer_head', False)) != want:
             self.store.wait_pending() if self.store.train.is_cuda else None
             self.store.defer_head = want        # plans are keyed by it (Engine.plan): lists built the other way are not reused
@@ -132,10 +136,13 @@ class FlatSGD:
                     self._opt_stream = role_stream('optimizer', st.device)
                 os_ = self._opt_stream
             pend = list(getattr(self.model, '_pending', []) or [])
+            order = getattr(self.model, '_pending_order', None) if pend else None      # late exchange: pend[j] belongs to infos[order[j]]
+            late = order is not None and not deferred and len(order) == len(infos) == len(pend)
+            seq = [(j, infos[k]) for j, k in enumerate(order)] if late else list(enumerate(infos))
             if fresh:
                 for s_ in ([self._side1] if deferred else [os_]):
                     s_.wait_stream(cur)          # the momentum buffer's zero fill (see above)
-            for k, info in enumerate(infos):
+            for k, info in seq:
                 lo, hi = info['bucket']
                 tgt = (self._side1 if info.get('deferred') else cur) if deferred else os_
                 tp = C.c_void_p(tgt.cuda_stream)
@@ -158,8 +165,11 @@ class FlatSGD:
                                            C.c_void_p(self.momentum_buf.data_ptr() + o4), C.c_void_p(st.train16.data_ptr() + o2),
                                            C.c_void_p(st.group.data_ptr() + o1), hi - lo, lr, self.momentum, self.weight_decay, blr,
                                            self.bias_decay_mult, None, 0.0, int(self.steps == 0), tp), 'dsl_sgd_step')
+                if late:          # "gradient bucket <slot> is updated": what the next forward pass waits for in front of that stage
+                    L.check(L.lib.dsl_stream_record_slot(L.SLOT_UPD + int(info['slot']), tp), 'dsl_stream_record_slot')
             if hasattr(self.model, '_pending'):
                 self.model._pending = []
+                self.model._pending_order = None
             if deferred:
                 s1p = C.c_void_p(self._side1.cuda_stream)
                 L.check(L.lib.dsl_stream_record_slot(L.SLOT_HEADW, s1p), 'dsl_stream_record_slot')
@@ -167,6 +177,13 @@ class FlatSGD:
                 st._pending_ev.record(self._side1)
                 # the data-gradient packs read every bucket: behind the caller's stream (its three updates) AND the deferred one,
                 # i.e. forked from the caller's stream onto the weight-gradient stream, in order behind the deferred update
+                st.repack_dgrad(sp, side=True)
+            elif late:
+                # nothing on the caller's stream waits: the next forward pass waits per stage (SLOT_UPD), every other reader of the
+                # parameters calls ParamStore.wait_pending; the data-gradient packs follow the last update on the optimizer's stream
+                # (= side stream 1, where repack_dgrad(side=True) queues them) and mark SLOT_PACKS for the next backward pass
+                st._pending_ev = torch.cuda.Event()
+                st._pending_ev.record(os_)
                 st.repack_dgrad(sp, side=True)
             else:
                 cur.wait_stream(os_)

@@ -205,6 +205,25 @@ int dsl_quant_fp8_dyn(const void* x_bf16, void* y_fp8, long rows, int c, int ld_
 int dsl_fp8_comb(const float* winv, float* comb, int n, const float* partials, int n_partials, void* stream);
 int dsl_quant_fp8_weights(const float* w, void* w8, float* comb, const float* bn_scale, int cout, int cout_pad, int k,
                           float inv_act_scale, void* stream);
+/* Delayed scaling (round 6; what the engine uses for the towers' fp8 forward): an activation is quantised by its PRODUCER's pass with
+ * the scale of the previous step's maximum, and leaves this step's block maxima for the next one - no pass of its own.
+ * dsl_fp8_prep, one launch per step for n_items convolutions that share cout_pad and k: per item and output channel co < cout the
+ *   weight row is quantised as dsl_quant_fp8_weights does (s_w = 448 / max|w[co][:]|); a = margin * max(amax[0 .. n_amax)) is the
+ *   input tensor's expected maximum; scale[0] = 448 / a (1 when a == 0: nothing recorded yet - run the forward pass once to record)
+ *   is what the input's producer multiplies by, comb[co] = a / 448 / s_w[co] the convolution's epilogue scale; rows co >= cout are 0.
+ * dsl_quant_fp8_delayed: y = e4m3(clamp(x * scale[0], +-448)) for a tensor nobody's epilogue can quantise (the FPN outputs),
+ *   partials[b] = block b's max|x| (n_partials blocks, every one written). */
+typedef struct dsl_fp8_prep_item {
+  const float* w;       /* fp32 [cout][k] */
+  void* w8;             /* e4m3 [cout_pad][k] */
+  float* comb;          /* [cout_pad] */
+  const float* amax;    /* block maxima of the convolution's input, left by the previous step */
+  float* scale;         /* [1] */
+  int32_t n_amax, cout;
+} dsl_fp8_prep_item;
+int dsl_fp8_prep(const dsl_fp8_prep_item* items_dev, int n_items, int cout_pad, int k, float margin, void* stream);
+int dsl_quant_fp8_delayed(const void* x_bf16, void* y_fp8, long rows, int c, int ld_x, const float* scale_dev, float* partials,
+                          int n_partials, void* stream);
 
 /* A whole trained bottleneck's forward pass as ONE launch (csrc/bneck.hip; mmdet/models/backbones/resnet.py:262-301 Bottleneck.forward,
  * caffe style: stride on conv1; eval-mode BatchNorms folded to (scale, bias)):
@@ -333,6 +352,13 @@ typedef struct dsl_gn_desc {
                            * workspace): forward, the one that produced x; backward, the data gradient that produced dy (its
                            * gn_x = x).  One pass instead of two; needs c / groups == 8 */
   int32_t pad_;
+  /* forward only, optional (all NULL: off) - the fp8 copy of y that an fp8 convolution reads next (DSL_CONV_FP8), written in the
+   * same pass with a DELAYED scale: y8 = e4m3(clamp(bf16(y) * y8_scale[0], +-448)) [pixel][c]; y8_amax[(segment * n + image) * nblk +
+   * block] = max of this call's bf16(y) over the block's pixels (nblk = ceil(max hw / 128); blocks outside a level never write:
+   * clear the buffer once) - the maxima dsl_fp8_prep turns into the NEXT step's scale */
+  void* y8;
+  const float* y8_scale;
+  float* y8_amax;
 } dsl_gn_desc;
 size_t dsl_groupnorm_workspace_bytes(const dsl_gn_desc* d);
 int dsl_groupnorm_relu_fwd(const dsl_gn_desc* d, void* stream);
@@ -563,6 +589,9 @@ enum { DSL_OP_CONV = 1, DSL_OP_WGRAD = 2, DSL_OP_GN_FWD = 3, DSL_OP_GN_BWD = 4, 
        DSL_OP_WGRAD_MULTI = 19, /* dsl_conv2d_wgrad_multi(p[0] = table_host, p[1] = table_dev) */
        DSL_OP_QUANT_FP8 = 22,  /* p[2] == NULL: dsl_quant_fp8(p[0] = x, p[1] = y, l[0] = rows, i[0] = c, i[1] = ld_x, scale = the float whose bits are
                                 * l[1]); else dsl_absmax(.., p[2] = partials, i[2] = n_partials) + dsl_quant_fp8_dyn(..) */
+       DSL_OP_FP8_PREP = 27,   /* dsl_fp8_prep(p[0] = items_dev, i[0] = n_items, i[1] = cout_pad, i[2] = k, margin = the float whose bits are l[1]) */
+       DSL_OP_QUANT_FP8_DELAYED = 28, /* dsl_quant_fp8_delayed(p[0] = x, p[1] = y, p[2] = partials, p[3] = scale_dev, l[0] = rows, i[0] = c, i[1] = ld_x,
+                                       * i[2] = n_partials) */
        DSL_OP_FP8_COMB = 24,   /* dsl_fp8_comb(p[0] = winv, p[1] = comb, i[0] = n, p[2] = partials, i[2] = n_partials) */
        DSL_OP_QUANT_FP8_W = 23, /* dsl_quant_fp8_weights(p[0] = w, p[1] = w8, p[2] = comb, p[3] = bn_scale, i[0] = cout, i[1] = cout_pad, i[2] = k,
                                 * inv_act_scale = the float whose bits are l[1]) */

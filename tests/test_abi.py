@@ -29,7 +29,7 @@ def test_descriptor_sizes_match_header_layout(tmp_path):
     import subprocess
     from dsl_amd import _lib as L
     pairs = [('dsl_conv_desc', L.ConvDesc, 'gn_stats'), ('dsl_wgrad_desc', L.WgradDesc, 'pixtab_bytes'),
-             ('dsl_gn_desc', L.GnDesc, 'conv_stats'), ('dsl_fcos_desc', L.FcosDesc, 'logvec'),
+             ('dsl_gn_desc', L.GnDesc, 'y8_amax'), ('dsl_fp8_prep_item', L.Fp8PrepItem, 'cout'), ('dsl_fcos_desc', L.FcosDesc, 'logvec'),
              ('dsl_det_desc', L.DetDesc, 'workspace_bytes'), ('dsl_pack_item', L.PackItem, 'tiles_co'), ('dsl_op', L.Op, 'l'),
              ('dsl_rec_sum_item', L.RecSumItem, 'nrec'), ('dsl_bn_post_item', L.BnPostItem, 'row_start')]
     src = tmp_path / 'sizes.c'

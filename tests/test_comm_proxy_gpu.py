@@ -34,11 +34,12 @@ def test_comm_stream_is_placed_on_the_prefix_queue():
     assert L.lib.dsl_comm_stream_queue() == int(L.lib.dsl_comm_stream_queue()) and L.lib.dsl_comm_stream_queue() == 3
 
 
-@pytest.mark.parametrize('carrier', ['lib', 'torch'])
-def test_proxy_schedule_trains_to_the_same_bits(carrier):
+@pytest.mark.parametrize('carrier,late', [('lib', True), ('torch', True), ('lib', False)])
+def test_proxy_schedule_trains_to_the_same_bits(carrier, late):
     """The proxy's passes preserve the values, so three steps in the data-parallel schedule (either carrier) end with bit-identical
     weights to three plain steps: the events order every bucket's exchange behind its weight gradients and every update behind its
-    exchange - a missing edge shows up as a different weight."""
+    exchange - a missing edge shows up as a different weight.  late: the default schedule (collectives queued behind the backward pass,
+    the next forward pass waits per stage for SLOT_UPD + bucket) or the round-5 one (joined at the end of the step)."""
     import bench
     b = bench.synth_batch(0, 2)
     finals = []
@@ -46,7 +47,9 @@ def test_proxy_schedule_trains_to_the_same_bits(carrier):
         torch.manual_seed(0)
         model, opt = _model()
         model.comm_proxy = proxy
-        for _ in range(3):
+        opt.late_exchange = late
+        opt._sync_defer()
+        for _ in range(5):
             out = model.train_step(b, opt)
             out['loss'].backward()
             opt.step()

@@ -112,6 +112,77 @@ def test_dynamic_scale_quantisation(K):
         assert torch.allclose(comb.cpu(), winv.cpu() * (amax / 448.0), rtol=1e-6)
 
 
+def test_delayed_scaling_prep_and_quantiser(K):
+    """Round 6, delayed scaling: dsl_fp8_prep (weights + epilogue scales + input scales of several convolutions in one launch, from the
+    block maxima the previous step left) and dsl_quant_fp8_delayed (quantise with that scale, leave this step's maxima) against torch."""
+    L, _ = K
+    g = torch.Generator().manual_seed(7)
+    co, cop, k, n_items, margin = 250, 256, 2304, 3, 1.25
+    ws = [(torch.randn(co, k, generator=g) * 0.05 * (i + 1)).cuda() for i in range(n_items)]
+    ws[1][5] = 0.0
+    amaxs = [torch.rand(40 + i, generator=g).cuda() * 9.0 for i in range(n_items)]
+    amaxs[2].zero_()                                          # nothing recorded yet: scale 1
+    w8 = [torch.full((cop, k), 7, dtype=torch.uint8, device='cuda') for _ in range(n_items)]
+    comb = [torch.full((cop,), float('nan'), device='cuda') for _ in range(n_items)]
+    scales = torch.full((n_items,), float('nan'), device='cuda')
+    items = (L.Fp8PrepItem * n_items)()
+    for i in range(n_items):
+        it = items[i]
+        it.w, it.w8, it.comb, it.amax, it.n_amax, it.cout = ws[i].data_ptr(), w8[i].data_ptr(), comb[i].data_ptr(), amaxs[i].data_ptr(), amaxs[i].numel(), co
+        it.scale = scales.data_ptr() + 4 * i
+    tab = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).cuda()
+    L.check(L.lib.dsl_fp8_prep(L.ptr(tab), n_items, cop, k, margin, L.stream_ptr()), 'dsl_fp8_prep')
+    torch.cuda.synchronize()
+    for i in range(n_items):
+        w = ws[i].cpu()
+        wmax = w.abs().amax(1)
+        s = torch.where(wmax > 0, 448.0 / wmax, torch.ones_like(wmax))
+        assert torch.equal(w8[i][:co].cpu(), (w * s[:, None]).clamp(-448, 448).to(F8).view(torch.uint8)) and int(w8[i][co:].max()) == 0
+        a = np.float32(float(amaxs[i].max())) * np.float32(margin)
+        want_scale = float(np.float32(448.0) / a) if a > 0 else 1.0
+        assert float(scales[i]) == want_scale, (i, float(scales[i]), want_scale)
+        inv = float(a / np.float32(448.0)) if a > 0 else 1.0
+        assert torch.allclose(comb[i][:co].cpu(), inv / s, rtol=1e-6) and float(comb[i][co:].abs().max()) == 0.0
+    rows, c, ld = 777, 256, 320
+    x = (torch.randn(rows, ld, generator=g) * 5).bfloat16()
+    x[5, 3] = 3000.0                                          # beyond last step's maximum: saturates at 448
+    xd = x.cuda()
+    y = torch.zeros(rows, c, dtype=torch.uint8, device='cuda')
+    part = torch.full((48,), float('nan'), device='cuda')
+    L.check(L.lib.dsl_quant_fp8_delayed(L.ptr(xd), L.ptr(y), rows, c, ld, scales.data_ptr(), L.ptr(part), 48, L.stream_ptr()), 'dsl_quant_fp8_delayed')
+    ref = (x[:, :c].float() * float(scales[0])).clamp(-448, 448).to(F8).view(torch.uint8)
+    assert torch.equal(y.cpu(), ref)
+    assert float(part.max()) == float(x[:, :c].float().abs().max()) and bool(torch.isfinite(part).all())
+
+
+def test_groupnorm_apply_writes_the_fp8_copy(K):
+    """dsl_gn_desc.y8: GroupNorm's apply pass writes the e4m3 copy of its (rounded) output with the given scale and leaves the block
+    maxima - equal to quantising y in a pass of its own, bit for bit; y itself is unchanged by the option."""
+    L, ops = K
+    g = torch.Generator().manual_seed(9)
+    N, sizes, Cc = 2, [(25, 36), (13, 18), (7, 9), (4, 5), (2, 3)], 256
+    P = sum(h * w for h, w in sizes) * N
+    x = (torch.randn(P, Cc, generator=g) * 2.0).bfloat16().cuda()
+    ga, be = (1 + 0.2 * torch.randn(Cc, generator=g)).cuda(), (0.3 * torch.randn(Cc, generator=g)).cuda()
+    ys = []
+    nblk = (max(h * w for h, w in sizes) + 127) // 128
+    for with8 in (False, True):
+        y = torch.empty(P, Cc, dtype=torch.bfloat16, device='cuda')
+        stats = torch.empty(5 * N * 32, 2, device='cuda')
+        y8 = torch.full((P, Cc), 9, dtype=torch.uint8, device='cuda')
+        sc = torch.tensor([150.0], device='cuda')
+        am = torch.zeros(5 * N * nblk, device='cuda')
+        gd = ops.gn_desc(x, y, ga, be, stats, n=N, hw=sizes, **(dict(y8=y8, y8_scale=sc, y8_amax=am) if with8 else {}))
+        L.check(L.lib.dsl_groupnorm_relu_fwd(C.byref(gd), L.stream_ptr()), 'gn')
+        torch.cuda.synchronize()
+        ys.append(y.clone())
+    assert torch.equal(ys[0], ys[1])
+    ref = (ys[1].float().cpu() * 150.0).clamp(-448, 448).to(F8).view(torch.uint8)
+    assert torch.equal(y8.cpu(), ref)
+    assert float(am.max()) == float(ys[1].float().max())
+    assert int((ref.view(F8).float() == 448).sum()) > 0          # (the scale is large enough that some values saturate: the clamp is exercised)
+
+
 def _build(**extra):
     from dsl_amd import detectors  # noqa: F401
     from dsl_amd.registry import build_detector
@@ -162,9 +233,9 @@ def test_fcos_step_with_fp8_towers_vs_bf16_step():
 
 def test_full_size_fp8_towers_step_vs_fp32_oracle():
     """BASELINE.json configs[4]'s slice against the ORACLE, not against the bf16 step (round-4 review item 6): the benchmark's own batch
-    (2 x 3 x 800 x 1344, 44 800 locations) through FCOS(fp8=dict(layers='towers')) - e4m3 tower forward convolutions, dynamic
-    per-tensor activation scales, per-channel weight scales - against the fp32 CPU restatement of the reference step on the same
-    inputs.  Stated tolerance: every loss within 5e-3 relative of fp32 (the all-bf16 step is held to 1e-3 in
+    (2 x 3 x 800 x 1344, 44 800 locations) through FCOS(fp8=dict(layers='towers')) - e4m3 tower forward convolutions, delayed
+    per-tensor activation scales (margin 1.25 over the recorded maximum), per-channel weight scales - against the fp32 CPU restatement of the reference step on the same
+    inputs.  Stated tolerance: every loss within 2e-3 relative of fp32 (5e-3 until round 5) (the all-bf16 step is held to 1e-3 in
     tests/test_step_gpu.py::test_full_size_losses_and_assignment_vs_oracle; e4m3 carries 3 mantissa bits on 8 of the ~70
     convolutions between the image and the losses; measured values are printed), and bit-identical target assignment."""
     import os
@@ -182,9 +253,53 @@ def test_full_size_fp8_towers_step_vs_fp32_oracle():
     got = {k: float(v.detach()) for k, v in losses.items()}
     print('fp8 towers', got, 'fp32 oracle', {k: l32[k] for k in got}, 'relative', {k: abs(got[k] - l32[k]) / abs(l32[k]) for k in got})
     for k, v in got.items():
-        assert v == pytest.approx(l32[k], rel=5e-3), (k, v, l32[k])
+        assert v == pytest.approx(l32[k], rel=2e-3), (k, v, l32[k])
     with torch.no_grad():
         _, raux = O.fcos_loss([t.detach() for t in aux['cls']], [t.detach() for t in aux['reg']], [t.detach() for t in aux['ctr']],
                               b['gt_bboxes'], b['gt_labels'], None, return_aux=True)
     assert torch.equal(plan.lossplan.assign_idx.cpu().long(), raux['assign_idx'])
     assert torch.equal(plan.lossplan.labels.cpu(), raux['labels'])
+
+
+def test_delayed_scales_follow_the_previous_step():
+    """Three optimizer steps with fp8 towers: from the second step on every activation scale is 448 / (1.25 x the maximum the step
+    before recorded), the losses stay within 1e-2 of the all-bf16 run's on the same weights trajectory, nothing saturates badly (the
+    share of e4m3 codes at +-448 in the tower inputs stays under 1e-4)."""
+    from dsl_amd.optim import FlatSGD
+    from oracle import fcos_oracle as O
+    rng = np.random.RandomState(5)
+    g = torch.Generator().manual_seed(6)
+    H, W, B = 192, 256, 2
+    img = (torch.randn(B, 3, H, W, generator=g) * 40).bfloat16().float().cuda()
+    gtb = [T(O.synth_boxes(rng, 4, H=H, W=W, lo=8, hi=150)) for _ in range(B)]
+    gtl = [T(rng.randint(0, 80, len(b)).astype('int64')) for b in gtb]
+    traj = {}
+    for name, extra in (('bf16', {}), ('fp8', dict(fp8=dict(layers='towers')))):
+        model = _build(**extra)
+        opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        vals = []
+        for step in range(3):
+            if name == 'fp8' and step > 0:
+                plan = [p for p in model._engine.plans.values() if p.training][0]
+                prev = {k: float(v.max()) for k, v in plan.bufs.items() if k.endswith('.amax')}
+            losses = model.forward_train(img, [dict()] * B, gtb, gtl)
+            sum(losses.values()).backward()
+            torch.cuda.synchronize()
+            vals.append({k: float(v.detach()) for k, v in losses.items()})
+            if name == 'fp8':
+                plan = [p for p in model._engine.plans.values() if p.training][0]
+                sc = plan.bufs['fp8.scales'].cpu().numpy()
+                if step > 0:
+                    for t_, tower in enumerate(('cls_convs', 'reg_convs')):
+                        for i in range(4):
+                            a = prev['feats.f8.amax'] if i == 0 else prev[f'{tower}.{i - 1}.act8.amax']
+                            assert sc[t_ * 4 + i] == np.float32(448.0) / (np.float32(a) * np.float32(1.25)), (step, tower, i)
+                for k8 in ['feats.f8'] + [f'{tw}.{i}.act8' for tw in ('cls_convs', 'reg_convs') for i in range(3)]:
+                    sat = float((plan.bufs[k8].view(F8).float().abs() == 448).float().mean())
+                    assert sat < 1e-4, (step, k8, sat)
+            opt.step()
+        traj[name] = vals
+    print('bf16', traj['bf16'], 'fp8', traj['fp8'])
+    for a, b in zip(traj['bf16'], traj['fp8']):
+        for k in a:
+            assert b[k] == pytest.approx(a[k], rel=1e-2), (k, a[k], b[k])
