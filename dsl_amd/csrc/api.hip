@@ -29,10 +29,12 @@ Option g_options[] = {
     {"stream_probe", 1},     // 0: the library takes its streams as the runtime deals them instead of probing for distinct hardware queues
     {"debug_sync", 0},       // 1: drain the device after every op of dsl_run_ops and name it on stderr
     {"skip_kinds", 0},       // step-level ablation (tools/step_ablation.sh): bit mask of op kinds dsl_run_ops does not launch - timing only
-    {"comm_queue", 3},       // which hardware queue the communication stream (dsl_side_stream(5)) is PLACED on (round 6; read at side_init):
+    {"comm_queue", 1},       // which hardware queue the communication stream (dsl_side_stream(5)) is PLACED on (round 6; read at side_init):
                              // 0 = any unused candidate (rounds 3 - 5), 1 = the weight-gradient stream's queue, 2 = the second chain's,
                              // 3 = the frozen prefix's, 4 = the caller's.  A fifth busy queue collapses the step, so the
-                             // collectives must share one of the four; default and measurement: DESIGN section 6
+                             // collectives must share one of the four.  Default 1 (round 6, profiles/r06_comm_queue_sweep.txt): with the late
+                             // exchange the weight-gradient queue is idle when the collectives and updates run (under the next forward pass):
+                             // 5.7 % of the step for the one-GPU proxy against 13 - 18 % on the other three; DESIGN section 6
 };
 }  // namespace
 int dsl_option(const char* name) {

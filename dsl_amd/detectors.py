@@ -590,11 +590,10 @@ class FCOS(nn.Module):
         # events SLOT_UPD + k, the next step's forward list waits for them stage by stage (engine.Plan._fwd_resnet).  Queued
         # bucket by bucket behind each segment ("eager") the traffic shared the tail of the backward pass with the weight
         # gradients, the next step's frozen prefix and the step boundary: the one-GPU proxy priced that at 10 % of the step
-        # whatever queue carried it (profiles/r06_comm_queue_sweep.txt), late at LATE_COST (profiles/r06_comm_proxy.txt).
+        # whatever queue carried it, the late exchange on the weight-gradient queue at 5.7 % (profiles/r06_comm_queue_sweep.txt).
         late = bool(ddp and on_gpu and getattr(self, 'late_exchange', False) and self.clip_partials is None
                     and self.store.backbone != 'rla' and not getattr(plan, 'defer', False))
-        self._pending_order = None
-        nb = [0]
+        nbc = [0]
 
         def exchange(info):
             lo, hi = info['bucket']
@@ -614,7 +613,7 @@ class FCOS(nn.Module):
                 L.check(L.lib.dsl_comm_proxy(L.ptr(g), (hi - lo) // 4 * 4, int(proxy.get('wgs', 32)), int(proxy.get('passes', 2)), csp),
                         'dsl_comm_proxy')
                 self._pending.append(StreamWork(cs))
-                nb[0] += 1
+                nbc[0] += 1
                 return
             with torch.cuda.stream(cs):
                 if self.comm_trace:
@@ -649,10 +648,10 @@ class FCOS(nn.Module):
                     if work is not None:
                         work.wait()
                         work = None
-                    L.check(L.lib.dsl_sumsq_partial(L.ptr(g), hi - lo, C_void(self.clip_partials.data_ptr() + nb[0] * L.SUMSQ_PARTS * 4), csp),
+                    L.check(L.lib.dsl_sumsq_partial(L.ptr(g), hi - lo, C_void(self.clip_partials.data_ptr() + nbc[0] * L.SUMSQ_PARTS * 4), csp),
                             'dsl_sumsq_partial')
                 self._pending.append(work if work is not None else StreamWork(cs))
-            nb[0] += 1
+            nbc[0] += 1
 
         todo = []
         for ol, info in plan.bwd_segments:
@@ -663,16 +662,30 @@ class FCOS(nn.Module):
                 todo.append(info)
             else:
                 exchange(info)
-        if late:
-            self._pending_order = list(range(len(todo) - 1, -1, -1))
-            for info in todo[::-1]:
-                exchange(info)
-        nb = nb[0]
+        # late: nothing is queued here - the optimizer asks for each bucket's exchange right in front of that bucket's update
+        # (exchange_late), so that on ONE hardware queue the order is exchange, update, exchange, update ... in the order the next
+        # forward pass needs the parameters; queued all at once the first update sat behind every exchange (measured: 13 - 18 %)
+        self._late_todo = todo[::-1] if late else []
+        self._exchange_fn = exchange if late else None
+        nb = nbc[0]
         self._partials_valid = bool(ddp and on_gpu and self.clip_partials is not None and 0 < nb * 256 <= self.clip_partials.numel())
         self._n_partials = nb * 256
         self._rebind_grads()
 
+    def exchange_late(self):
+        """Late exchange: queues the next bucket's collective (order: layer2, layer3, layer4, head + FPN) and returns (info, work), or
+        None when every bucket of the last backward pass has been handed out."""
+        todo = getattr(self, '_late_todo', None)
+        if not todo:
+            return None
+        info = todo.pop(0)
+        n = len(self._pending)
+        self._exchange_fn(info)
+        return info, self._pending[n]
+
     def wait_grads(self):
+        while self.exchange_late() is not None:      # (a late exchange nobody asked for bucket by bucket: an optimizer with a global norm)
+            pass
         for w in self._pending:
             w.wait()
         self._pending = []

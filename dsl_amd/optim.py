@@ -136,9 +136,9 @@ class FlatSGD:
                     self._opt_stream = role_stream('optimizer', st.device)
                 os_ = self._opt_stream
             pend = list(getattr(self.model, '_pending', []) or [])
-            order = getattr(self.model, '_pending_order', None) if pend else None      # late exchange: pend[j] belongs to infos[order[j]]
-            late = order is not None and not deferred and len(order) == len(infos) == len(pend)
-            seq = [(j, infos[k]) for j, k in enumerate(order)] if late else list(enumerate(infos))
+            # late exchange: the detector queued no collective - each is asked for here, in front of its bucket's update
+            late = bool(getattr(self.model, '_late_todo', None)) and not deferred and not pend
+            seq = list(enumerate(infos[::-1] if late else infos))
             if fresh:
                 for s_ in ([self._side1] if deferred else [os_]):
                     s_.wait_stream(cur)          # the momentum buffer's zero fill (see above)
@@ -146,6 +146,10 @@ class FlatSGD:
                 lo, hi = info['bucket']
                 tgt = (self._side1 if info.get('deferred') else cur) if deferred else os_
                 tp = C.c_void_p(tgt.cuda_stream)
+                if late:
+                    got = self.model.exchange_late()
+                    assert got is not None and got[0] is info, 'late exchange: bucket order'
+                    pend.append(got[1])
                 if pend:
                     with torch.cuda.stream(tgt):
                         pend[k].wait()
@@ -169,7 +173,6 @@ class FlatSGD:
                     L.check(L.lib.dsl_stream_record_slot(L.SLOT_UPD + int(info['slot']), tp), 'dsl_stream_record_slot')
             if hasattr(self.model, '_pending'):
                 self.model._pending = []
-                self.model._pending_order = None
             if deferred:
                 s1p = C.c_void_p(self._side1.cuda_stream)
                 L.check(L.lib.dsl_stream_record_slot(L.SLOT_HEADW, s1p), 'dsl_stream_record_slot')

@@ -26,7 +26,7 @@ DEFAULTS = {
     # ---- C library options (dsl_set_option)
     'lib.wgrad_slots': '128',
     'lib.stream_probe': '1',   # 0: the library takes its streams as the runtime deals them (no hardware-queue probe)
-    'lib.comm_queue': '3',     # hardware queue the communication stream is placed on (1 weight gradients, 2 second chain, 3 prefix, 4 caller; 0 = as dealt)
+    'lib.comm_queue': '1',     # hardware queue the communication stream is placed on (1 weight gradients, 2 second chain, 3 prefix, 4 caller; 0 = as dealt)
     'lib.debug_sync': '0',
     'lib.skip_kinds': '0',
 }

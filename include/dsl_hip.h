@@ -35,7 +35,7 @@ const char* dsl_last_error(void);
 /* Library options - the library reads no environment variable.  Names: "wgrad_slots" (default 128: workgroup budget of a
  * weight-gradient launch whose descriptor leaves `slots` 0), "stream_probe" (1; 0 = the library takes its streams as the runtime deals
  * them instead of probing for hardware queues of their own, dsl_streams_init), "debug_sync" (0; 1 = dsl_run_ops drains the device after every op and
- * names it on stderr), "skip_kinds" (0; timing-only ablation: bit mask of op kinds dsl_run_ops skips), "comm_queue" (3; which of the four
+ * names it on stderr), "skip_kinds" (0; timing-only ablation: bit mask of op kinds dsl_run_ops skips), "comm_queue" (1; which of the four
  * hardware queues the communication stream is placed on, see dsl_comm_stream_queue; set it before the streams exist).  Unknown name: -1. */
 int dsl_set_option(const char* name, int value);
 int dsl_get_option(const char* name, int* value);
@@ -625,7 +625,7 @@ int dsl_side_stream(int id, void** stream_out);
  * whatever other streams the process has created (api.hip side_init).  Optional (the first dsl_run_ops does it).  *distinct_out: how
  * many of the three were found (3 = all, -1 = option "stream_probe" is 0). */
 int dsl_streams_init(void* caller_stream, int* distinct_out);
-/* Which hardware queue the communication stream (dsl_side_stream(5)) shares - it is PLACED, not dealt (option "comm_queue", default 3):
+/* Which hardware queue the communication stream (dsl_side_stream(5)) shares - it is PLACED, not dealt (option "comm_queue", default 1):
  * 1 = the weight-gradient stream's, 2 = the second chain's, 3 = the frozen prefix's, 4 = the caller's; 0 = not placed (probe off or no
  * candidate found), -1 = the streams do not exist yet.  Side ids 2 and 3 are ONE stream (they only add ordering). */
 int dsl_comm_stream_queue(void);

@@ -6,7 +6,7 @@
 OUT=${1:-gpurun_out/comm_queue_sweep.txt}
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT"
-for q in 3 0 1 2 4 3; do
+for q in 1 0 3 2 4 1; do
   echo "== comm_queue=$q" >> "$OUT"
   DSL_TUNE="lib.comm_queue=$q" timeout 600 python - >> "$OUT" 2>&1 <<'PY'
 import json, sys, os
