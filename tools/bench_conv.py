@@ -79,6 +79,9 @@ bench('l3 3x3 256 @50x84', 256, 256, 3, 1, [(50, 84)])
 bench('l3 1x1 256->1024', 256, 1024, 1, 1, [(50, 84)])
 bench('l3 1x1 1024->256', 1024, 256, 1, 1, [(50, 84)])
 bench('l4 3x3 512 @25x42', 512, 512, 3, 1, [(25, 42)])
+bench('l4 1x1 2048->512', 2048, 512, 1, 1, [(25, 42)])
+bench('l4 1x1 512->2048', 512, 2048, 1, 1, [(25, 42)])
+bench('l4 3x3 512 @25x42', 512, 512, 3, 1, [(25, 42)])
 bench('l4 1x1 512->2048', 512, 2048, 1, 1, [(25, 42)])
 bench('l4 1x1 2048->512', 2048, 512, 1, 1, [(25, 42)])
 bench('l3.0 ds 1x1 s2 512->1024', 512, 1024, 1, 2, [(100, 168)])
