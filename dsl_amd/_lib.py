@@ -41,7 +41,7 @@ SLOT_PACKS = 15      # named event: the data-gradient weight packs of the last o
 SUMSQ_PARTS = 256
 SLOT_UPD = 8         # named events 8 .. 11: gradient bucket 0 .. 3 of the last optimizer step is updated (late exchange)
 SLOT_HEADW = 12      # named event: the head + FPN bucket of the last optimizer step is updated (deferred head update)
-(RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST, RLA_REC_SUM) = range(2, 9)
+(RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST, RLA_REC_SUM, RLA_TAIL_FWD) = range(2, 10)
 MAX_GROUP = 8
 
 
@@ -195,7 +195,8 @@ _SIGS = {
     'dsl_maxpool3x3s2_ld': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_avgpool2x2': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_avgpool2x2_bwd': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
-    'dsl_bn_tanh_fwd': [_vp, _i, _vp, _vp, _vp, _i, _l, _i, _vp], 'dsl_bn_tanh_bwd_workspace_bytes': [_l, _i],
+    'dsl_bn_tanh_fwd': [_vp, _i, _vp, _vp, _vp, _i, _l, _i, _vp],
+    'dsl_rla_tail_fwd': [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_bn_tanh_bwd_workspace_bytes': [_l, _i],
     'dsl_bn_tanh_bwd': [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
     'dsl_image_prep_u8': [_vp, _i, _vp, _i, _i, _vp], 'dsl_image_aug': [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp], 'dsl_image_aug_scratch_bytes': [_i],
     'dsl_image_normalize': [_vp, _vp, _i, _vp, _i, _i, _vp],

@@ -29,6 +29,7 @@ Option g_options[] = {
     {"stream_probe", 1},     // 0: the library takes its streams as the runtime deals them instead of probing for distinct hardware queues
     {"debug_sync", 0},       // 1: drain the device after every op of dsl_run_ops and name it on stderr
     {"skip_kinds", 0},       // step-level ablation (tools/step_ablation.sh): bit mask of op kinds dsl_run_ops does not launch - timing only
+    {"rla_tail_form", 0},    // dsl_rla_tail_fwd: 0 = tile form by shape, 1 / 2 = force the 14 x 14 / the 6 x 6 K-split form (measurement)
     {"comm_queue", 1},       // which hardware queue the communication stream (dsl_side_stream(5)) is PLACED on (round 6; read at side_init):
                              // 0 = any unused candidate (rounds 3 - 5), 1 = the weight-gradient stream's queue, 2 = the second chain's,
                              // 3 = the frozen prefix's, 4 = the caller's.  A fifth busy queue collapses the step, so the

@@ -72,11 +72,150 @@ __global__ void bn_tanh_kernel(const uint16_t* __restrict__ u, int ldu, const fl
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float lo = tanhf(bflo(a[e]) * scale[k + 2 * e] + bias[k + 2 * e]);
-      const float hi = tanhf(bfhi(a[e]) * scale[k + 2 * e + 1] + bias[k + 2 * e + 1]);
+      const float lo = tanhf(__builtin_fmaf(bflo(a[e]), scale[k + 2 * e], bias[k + 2 * e]));        // (ONE rounding: rla_tail_fwd_kernel
+      const float hi = tanhf(__builtin_fmaf(bfhi(a[e]), scale[k + 2 * e + 1], bias[k + 2 * e + 1]));   //  below must round the same way)
       o[e] = pack2bf(lo, hi);
     }
     *reinterpret_cast<u32x4*>(t + r * ldt + k) = o;
+  }
+}
+
+// ---- the recurrent path of one block as ONE launch (round 6): u = h' + conv_out(out) (1x1, C4 -> 32), t = tanh(bn(u)),
+// h = recurrent_conv(t) (3x3, 32 -> 32, pad 1) - resnet_rla.py:125-136 - which were three dependent launches on the chain that the next
+// block's conv1 waits for (dsl_conv2d with 32 of 64 padded couts, dsl_bn_tanh_fwd, dsl_conv2d).  A workgroup (8 waves) owns a
+// 14 x 14 pixel tile of one image: phase A computes conv_out for the tile + a one-pixel halo (16 x 16 = 256 slots, 32 per wave: MFMA
+// 32x32x16, A = the 32 weight rows, B = the pixels' rows, both fragments straight from global memory / L2 - 2 x 32 B per pixel row and
+// K step), adds h', rounds u, applies BN + tanh and leaves t in an LDS patch [slot][32] (zero outside the image: the 3x3's padding);
+// phase B reads the nine taps out of the patch (7 waves x 32 pixels).  u and t still go to memory (the backward pass reads them),
+// halo slots are recomputed by the neighbouring tiles (identical values), only a tile's own pixels are stored.
+// Same K order per MFMA chain and the same rounding points as the three launches (u = bf16(acc + h'), t = bf16(tanh(fma(u, s, b))),
+// h = bf16(acc)); the zero-padded K columns of the stored 3x3 weights (32 real of 64 / 128) are skipped (they add 0).
+typedef __bf16 rla_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float rla_f32x16 __attribute__((ext_vector_type(16)));
+struct RlaTailK {
+  const uint16_t* x; const uint16_t* hin; const uint16_t* wco; const float* sc; const float* bi; const uint16_t* wrc;
+  uint16_t* u; uint16_t* t; uint16_t* hout;
+  int ldx, ldh, c4, tw, ldo, n, h, w, tiles_x, tiles_y;
+};
+// <RT, KS>: tile edge RT (halo patch (RT + 2)^2 slots = NS groups of 32) and KS waves per slot group, each taking 1 / KS of conv_out's
+// K range (NS * KS = 8 waves): <14, 1> for the many-pixel stages; <6, 4> where an image is a few tiles and conv_out's K is long
+// (stages 2, 3: a wave's chain of K / 16 dependent load -> MFMA steps is what the launch takes) - the four partial sums of a slot
+// meet in LDS and are added in K order.
+template <int RT, int KS>
+__global__ __launch_bounds__(512) void rla_tail_fwd_kernel(const RlaTailK p) {
+  constexpr int HW = RT + 2, NSLOT = HW * HW, NS = NSLOT / 32;
+  static_assert(NSLOT % 32 == 0 && NS * KS == 8, "eight waves: slot groups x K parts");
+  __shared__ __attribute__((aligned(16))) uint16_t patch[NSLOT * 32];
+  __shared__ __attribute__((aligned(16))) float red[KS > 1 ? (KS - 1) * NSLOT * 32 : 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  int b = blockIdx.x;
+  const int tx = b % p.tiles_x; b /= p.tiles_x;
+  const int ty = b % p.tiles_y;
+  const int img = b / p.tiles_y;
+  const int y0 = ty * RT, x0 = tx * RT;
+  const long long ibase = (long long)img * p.h * p.w;
+  // ---- phase A: conv_out + h' -> u -> t for halo slot s = 32 * (slot group) + col
+  {
+    const int sg = wave % NS, kq = wave / NS;
+    const int s = sg * 32 + col;
+    const int sy = s / HW, sx = s - sy * HW;
+    const int py = y0 - 1 + sy, px = x0 - 1 + sx;
+    const bool valid = (unsigned)py < (unsigned)p.h && (unsigned)px < (unsigned)p.w;
+    const long long pix = ibase + (valid ? (long long)py * p.w + px : 0);
+    const int klen = p.c4 / KS;
+    const uint16_t* xr = p.x + pix * p.ldx + kq * klen + kh * 8;
+    const uint16_t* wr = p.wco + (long long)col * p.c4 + kq * klen + kh * 8;
+    rla_f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    // eight K steps of fragments in flight beside the eight being multiplied (the loop is the loads' latency, not their bandwidth)
+    constexpr int UB = 8;
+    rla_bf16x8 fa[UB], fb[UB];
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const int k0 = i * 16 < klen ? i * 16 : 0;
+      fa[i] = *reinterpret_cast<const rla_bf16x8*>(wr + k0);
+      fb[i] = *reinterpret_cast<const rla_bf16x8*>(xr + k0);
+    }
+    for (int kb = 0; kb < klen; kb += UB * 16) {
+      rla_bf16x8 ca[UB], cb[UB];
+#pragma unroll
+      for (int i = 0; i < UB; ++i) { ca[i] = fa[i]; cb[i] = fb[i]; }
+      const int kn = kb + UB * 16;
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int k0 = kn + i * 16 < klen ? kn + i * 16 : 0;        // (past the end: a harmless re-load, never multiplied)
+        fa[i] = *reinterpret_cast<const rla_bf16x8*>(wr + k0);
+        fb[i] = *reinterpret_cast<const rla_bf16x8*>(xr + k0);
+      }
+#pragma unroll
+      for (int i = 0; i < UB; ++i)
+        if (kb + i * 16 < klen) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], cb[i], acc, 0, 0, 0);
+    }
+    if (KS > 1) {
+      if (kq > 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[((kq - 1) * NSLOT + s) * 32 + (j >> 2) * 8 + 4 * kh + (j & 3)] = acc[j];
+      }
+      __syncthreads();
+      if (kq == 0) {
+#pragma unroll
+        for (int q = 1; q < KS; ++q)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc[j] += red[((q - 1) * NSLOT + s) * 32 + (j >> 2) * 8 + 4 * kh + (j & 3)];
+      }
+    }
+    if (kq == 0) {
+      const bool own = valid && sy >= 1 && sy <= RT && sx >= 1 && sx <= RT;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = 8 * g + 4 * kh;
+        uint2 tq = {0u, 0u};
+        if (valid) {
+          const uint2 hv = *reinterpret_cast<const uint2*>(p.hin + pix * p.ldh + co);
+          const uint32_t u0 = pack2bf(acc[4 * g] + bflo(hv.x), acc[4 * g + 1] + bfhi(hv.x));
+          const uint32_t u1 = pack2bf(acc[4 * g + 2] + bflo(hv.y), acc[4 * g + 3] + bfhi(hv.y));
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.sc + co), b4 = *reinterpret_cast<const f32x4*>(p.bi + co);
+          tq.x = pack2bf(tanhf(__builtin_fmaf(bflo(u0), s4[0], b4[0])), tanhf(__builtin_fmaf(bfhi(u0), s4[1], b4[1])));
+          tq.y = pack2bf(tanhf(__builtin_fmaf(bflo(u1), s4[2], b4[2])), tanhf(__builtin_fmaf(bfhi(u1), s4[3], b4[3])));
+          if (own) {
+            *reinterpret_cast<uint2*>(p.u + pix * 32 + co) = uint2{u0, u1};
+            *reinterpret_cast<uint2*>(p.t + pix * p.tw + co) = tq;
+          }
+        }
+        *reinterpret_cast<uint2*>(patch + s * 32 + co) = tq;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase B: the 3x3 over the patch for own pixel q = 32 * wave + col
+  if (wave * 32 < RT * RT) {
+    const int q = wave * 32 + col;
+    const bool live = q < RT * RT;
+    const int iy = live ? q / RT : 0, ix = live ? q - (q / RT) * RT : 0;
+    const uint16_t* wr = p.wrc + (long long)col * 9 * p.tw + kh * 8;
+    rla_f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const uint16_t* pr = patch + ((iy + ky) * HW + ix + kx) * 32 + kh * 8;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const rla_bf16x8 a = *reinterpret_cast<const rla_bf16x8*>(wr + tap * p.tw + ks * 16);
+        const rla_bf16x8 bb = *reinterpret_cast<const rla_bf16x8*>(pr + ks * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc, 0, 0, 0);
+      }
+    }
+    const int py = y0 + iy, px = x0 + ix;
+    if (live && py < p.h && px < p.w) {
+      uint16_t* o = p.hout + (ibase + (long long)py * p.w + px) * p.ldo + 4 * kh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<uint2*>(o + 8 * g) = uint2{pack2bf(acc[4 * g], acc[4 * g + 1]), pack2bf(acc[4 * g + 2], acc[4 * g + 3])};
+    }
   }
 }
 
@@ -306,6 +445,32 @@ extern "C" int dsl_bn_wgrad_post(const dsl_bn_post_item* items_dev, int n, int t
   return 0;
 }
 
+extern "C" int dsl_rla_tail_fwd(const void* x, int ldx, const void* h_in, int ldh, const void* w_conv_out, int c4, const float* bn_scale,
+                                const float* bn_bias, const void* w_recurrent, int tw, void* u, void* t, void* h_out, int ldo, int n,
+                                int h, int w, void* stream) {
+  DSL_CHECK(x && h_in && w_conv_out && bn_scale && bn_bias && w_recurrent && u && t && h_out, "dsl_rla_tail_fwd: null pointer");
+  DSL_CHECK(n > 0 && h > 0 && w > 0 && c4 > 0 && c4 % 16 == 0 && ldx >= c4 && ldx % 8 == 0 && ldh >= 32 && ldh % 4 == 0 && tw >= 32 &&
+            tw % 8 == 0 && ldo >= 32 && ldo % 4 == 0, "dsl_rla_tail_fwd: bad geometry (c4=%d ldx=%d ldh=%d tw=%d ldo=%d)", c4, ldx, ldh, tw, ldo);
+  DSL_CHECK((((uintptr_t)x | (uintptr_t)w_conv_out | (uintptr_t)w_recurrent) & 15) == 0 && (((uintptr_t)h_in | (uintptr_t)u | (uintptr_t)t |
+            (uintptr_t)h_out) & 7) == 0, "dsl_rla_tail_fwd: x and the weights must be 16-byte aligned, h_in / u / t / h_out 8-byte aligned");
+  // tile form: 14 x 14 tiles unless the image is a few tiles of them and K is long (dsl_set_option "rla_tail_form": 0 = this rule,
+  // 1 / 2 = force <14, 1> / <6, 4>: tools/bench_rla_tail.py)
+  const int form = dsl_option("rla_tail_form");
+  const bool small = form == 2 || (form == 0 && c4 >= 512 && (long long)((w + 13) / 14) * ((h + 13) / 14) * n < 128) ;
+  const int rt = small ? 6 : 14;
+  DSL_CHECK(!small || c4 % 64 == 0, "dsl_rla_tail_fwd: the K-split form needs c4 %% 64 == 0");
+  RlaTailK k{(const uint16_t*)x, (const uint16_t*)h_in, (const uint16_t*)w_conv_out, bn_scale, bn_bias, (const uint16_t*)w_recurrent,
+             (uint16_t*)u, (uint16_t*)t, (uint16_t*)h_out, ldx, ldh, c4, tw, ldo, n, h, w, (w + rt - 1) / rt, (h + rt - 1) / rt};
+  const long long blocks = (long long)k.tiles_x * k.tiles_y * n;
+  DSL_CHECK(blocks < 0x7fffffffLL, "dsl_rla_tail_fwd: grid too large");
+  if (small)
+    hipLaunchKernelGGL((rla_tail_fwd_kernel<6, 4>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, k);
+  else
+    hipLaunchKernelGGL((rla_tail_fwd_kernel<14, 1>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, k);
+  DSL_LAUNCH_CHECK("rla_tail_fwd_kernel");
+  return 0;
+}
+
 extern "C" int dsl_rla_op(const dsl_rla_desc* d, void* stream) {
   DSL_CHECK(d != nullptr, "dsl_rla_op: null descriptor");
   const int32_t* i = d->i;
@@ -322,6 +487,9 @@ extern "C" int dsl_rla_op(const dsl_rla_desc* d, void* stream) {
                          (float*)p[5], i[0], stream);
     case DSL_RLA_BN_POST: return dsl_bn_wgrad_post((const dsl_bn_post_item*)p[0], i[0], i[1], d->f[0], stream);
     case DSL_RLA_REC_SUM: return dsl_rec_sum_multi((const dsl_rec_sum_item*)p[0], i[0], i[1], stream);
+    case DSL_RLA_TAIL_FWD:
+      return dsl_rla_tail_fwd(p[0], i[0], p[1], i[1], p[2], i[2], (const float*)p[3], (const float*)p[4], p[5], i[3], p[6], p[7], p[8], i[4],
+                              i[5], i[6], i[7], stream);
     default: dsl_set_error("dsl_rla_op: unknown kind %d", d->kind); return -1;
   }
 }

@@ -67,6 +67,7 @@ def build_forward(plan, emit_pool, h1, w1):
     # BatchNorms, per-image recurrent state - so the batch runs through these stages as two chains of half-batch launches on two
     # streams (tuning key rla_split: stage indices, default 1, 2, 3; the DSL iteration has N = 3: images [0, 2) and [2, 3))
     SPLIT = tune('rla_split') if (plan.BR and N >= 2 and plan.training) else ''
+    TAIL = tune('rla_tail') != '0'
     split_open = False
 
     def br_ws(d_):
@@ -130,6 +131,12 @@ def build_forward(plan, emit_pool, h1, w1):
                         _rla_op(f, L.RLA_AVGPOOL, p=(h_ptr, hp_g), i=(ldx, RLA_C, n_, h, w, RLA_C), side=sd)
                         h_ptr, h_ld = hp_g, RLA_C
                     u_g, t_g = rows(u, g0, ohw, RLA_C), rows(t, g0, ohw, tw)
+                    if TAIL:
+                        # conv_out -> BN + tanh -> recurrent 3x3 as ONE launch (round 6, csrc/rla.hip rla_tail_fwd_kernel): the chain the
+                        # next block's conv1 waits for is one kernel boundary long instead of three
+                        _rla_op(f, L.RLA_TAIL_FWD, p=(nxt_g, h_ptr, st.w16_ptr(co), sc, bi, st.w16_ptr(rc), u_g, t_g, nxt_g + c4 * 2),
+                                i=(c4 + RLA_PAD, h_ld, c4, tw, c4 + RLA_PAD, n_, oh, ow), side=sd)
+                        continue
                     f.conv(wsf(plan._conv(co, nxt_g, u_g, n_, [(oh, ow)], [(oh, ow)], cs=c4, lds=c4 + RLA_PAD, addend=h_ptr, lda=h_ld,
                                           dst_ld=RLA_C, affine=False)), side=sd)
                     _rla_op(f, L.RLA_BN_TANH, p=(u_g, sc, bi, t_g), i=(RLA_C, tw, RLA_C), rows=n_ * ohw, side=sd)

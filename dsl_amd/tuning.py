@@ -19,6 +19,7 @@ DEFAULTS = {
     'tail_slots': '192',       # ... of the last segment's weight gradients (layer2; the RLA backbone's stage 1)
     # ---- RLA_ResNet engine
     'rla_split': '123',        # forward stages of the RLA backbone that run as two chains
+    'rla_tail': '1',           # 1: a block's recurrent path (conv_out -> BN + tanh -> 3x3) as one launch (dsl_rla_tail_fwd); 0: three
     'rla_split_bwd': '',       # backward stages whose data-gradient chains do (measured slower on the saturated N = 3 iteration: 12.0 -> 12.15 ms)
     # ---- checks / measurement
     'check_backward_grad': '0',    # 1: verify the gradient handed to loss.backward() on every step (default: the first steps only)
@@ -27,6 +28,7 @@ DEFAULTS = {
     'lib.wgrad_slots': '128',
     'lib.stream_probe': '1',   # 0: the library takes its streams as the runtime deals them (no hardware-queue probe)
     'lib.comm_queue': '1',     # hardware queue the communication stream is placed on (1 weight gradients, 2 second chain, 3 prefix, 4 caller; 0 = as dealt)
+    'lib.rla_tail_form': '0',  # dsl_rla_tail_fwd's tile form: 0 by shape, 1 = 14 x 14 tiles, 2 = 6 x 6 tiles with conv_out's K over four waves
     'lib.debug_sync': '0',
     'lib.skip_kinds': '0',
 }

@@ -398,10 +398,18 @@ typedef struct dsl_bn_post_item {
   int32_t rows, k, row_start, pad_;
 } dsl_bn_post_item;
 int dsl_bn_wgrad_post(const dsl_bn_post_item* items_dev, int n, int total_rows, float eps, void* stream);
+/* The recurrent path of one RLA block as ONE launch (resnet_rla.py:125-136): u = h_in + conv_out(x) (1x1, c4 -> 32; w_conv_out rows of c4
+ * elements, 32 used), t = tanh(u * bn_scale + bn_bias), h_out = recurrent_conv(t) (3x3, pad 1; w_recurrent [>= 32][3][3][tw], the first
+ * 32 of every tw input columns used).  x [n*h*w][ldx], h_in [..][ldh], u [..][32], t [..][tw] (first 32 written), h_out [..][ldo] (32 written);
+ * bf16.  Same rounding points as dsl_conv2d (addend h_in) -> dsl_bn_tanh_fwd -> dsl_conv2d, which it replaces. */
+int dsl_rla_tail_fwd(const void* x, int ldx, const void* h_in, int ldh, const void* w_conv_out, int c4, const float* bn_scale,
+                     const float* bn_bias, const void* w_recurrent, int tw, void* u, void* t, void* h_out, int ldo, int n, int h, int w,
+                     void* stream);
 /* one of the above as an op-list entry (DSL_OP_RLA): kind selects the call, the arguments are taken in declaration order
  * from p[] (pointers), i[] (ints: strides / sizes), f[] (eps), rows */
 enum { DSL_RLA_AVGPOOL = 2, DSL_RLA_AVGPOOL_BWD = 3, DSL_RLA_BN_TANH = 4, DSL_RLA_BN_TANH_BWD = 5,
-       DSL_RLA_BN_FOLD = 6, DSL_RLA_BN_POST = 7, DSL_RLA_REC_SUM = 8 /* p[0] = items, i[0] = n, i[1] = c */ };
+       DSL_RLA_BN_FOLD = 6, DSL_RLA_BN_POST = 7, DSL_RLA_REC_SUM = 8 /* p[0] = items, i[0] = n, i[1] = c */,
+       DSL_RLA_TAIL_FWD = 9 /* p[] = x, h_in, w_conv_out, bn_scale, bn_bias, w_recurrent, u, t, h_out; i[] = ldx, ldh, c4, tw, ldo, n, h, w */ };
 typedef struct dsl_rla_desc {
   int32_t kind;
   int32_t i[8];
