@@ -661,9 +661,14 @@ def main():
         dist.all_reduce(t_off, op=dist.ReduceOp.MAX)
         order = 'layer4, layer3, layer2, head+FPN (deferred: under the next forward pass)' if getattr(det.store, 'defer_head', False) \
             else 'head+FPN, layer4, layer3, layer2'
+        if getattr(det, 'late_exchange', False) and det.clip_partials is None:
+            order = ('layer2, layer3, layer4, head+FPN - late exchange: queued behind the backward pass, each bucket in front of its update, the '
+                     'next forward pass waits per stage (DESIGN section 6)')
         extra = dict(comm=dict(carrier='C-ABI rcclComm_t (dsl_allreduce_bucket)' if det.rccl is not None else 'torch.distributed process group',
                                backend=dist.get_backend(), rccl_ranks=int(L.lib.dsl_comm_size(det.rccl.comm)) if det.rccl is not None else dist.get_world_size(),
                                devices=devs, grad_dtype='bf16' if det.grad_bf16 else 'fp32',
+                               exchange='late' if (getattr(det, 'late_exchange', False) and det.clip_partials is None) else 'eager',
+                               comm_stream_queue=int(L.lib.dsl_comm_stream_queue()),
                                wgrad_slots=_lib_option('wgrad_slots'),
                                buckets=bk, step_ms=round(tr['t0'].elapsed_time(ev_end), 3),
                                ms_per_step_comm_disabled=round(float(t_off) / max(5, args.steps // 2) * 1e3, 3),
