@@ -41,7 +41,7 @@ SLOT_PACKS = 15      # named event: the data-gradient weight packs of the last o
 SUMSQ_PARTS = 256
 SLOT_UPD = 8         # named events 8 .. 11: gradient bucket 0 .. 3 of the last optimizer step is updated (late exchange)
 SLOT_HEADW = 12      # named event: the head + FPN bucket of the last optimizer step is updated (deferred head update)
-(RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST, RLA_REC_SUM, RLA_TAIL_FWD) = range(2, 10)
+(RLA_AVGPOOL, RLA_AVGPOOL_BWD, RLA_BN_TANH, RLA_BN_TANH_BWD, RLA_BN_FOLD, RLA_BN_POST, RLA_REC_SUM, RLA_TAIL_FWD, RLA_TAIL_BWD) = range(2, 11)
 MAX_GROUP = 8
 
 
@@ -130,7 +130,7 @@ class BneckDesc(C.Structure):
 
 
 class RlaDesc(C.Structure):
-    _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 8), ('f', C.c_float * 2), ('rows', C.c_int64), ('p', C.c_void_p * 10)]
+    _fields_ = [('kind', C.c_int32), ('i', C.c_int32 * 8), ('f', C.c_float * 2), ('rows', C.c_int64), ('p', C.c_void_p * 12)]
 
 
 class BnPostItem(C.Structure):
@@ -172,6 +172,8 @@ if hasattr(lib, 'dsl_wgrad_group_workspace_bytes'):
 lib.dsl_conv2d_workspace_bytes.restype = C.c_size_t
 if hasattr(lib, 'dsl_image_aug_scratch_bytes'):
     lib.dsl_image_aug_scratch_bytes.restype = C.c_size_t
+if hasattr(lib, 'dsl_rla_tail_bwd_workspace_bytes'):
+    lib.dsl_rla_tail_bwd_workspace_bytes.restype = C.c_size_t
 for _n in ('dsl_wgrad_multi_table_bytes', 'dsl_wgrad_multi_workspace_bytes'):
     if hasattr(lib, _n):
         getattr(lib, _n).restype = C.c_size_t
@@ -196,6 +198,7 @@ _SIGS = {
     'dsl_avgpool2x2': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_avgpool2x2_bwd': [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     'dsl_bn_tanh_fwd': [_vp, _i, _vp, _vp, _vp, _i, _l, _i, _vp],
+    'dsl_rla_tail_bwd': [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp], 'dsl_rla_tail_bwd_workspace_bytes': [_i, _i, _i],
     'dsl_rla_tail_fwd': [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp], 'dsl_bn_tanh_bwd_workspace_bytes': [_l, _i],
     'dsl_bn_tanh_bwd': [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
     'dsl_image_prep_u8': [_vp, _i, _vp, _i, _i, _vp], 'dsl_image_aug': [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp], 'dsl_image_aug_scratch_bytes': [_i],

@@ -275,6 +275,115 @@ __global__ __launch_bounds__(BT_T) void bn_tanh_bwd_kernel(const uint16_t* __res
   }
 }
 
+// ---- backward of the recurrent path's tail as ONE launch (round 6): g_t = recurrent_conv^T(g_h) (3x3 data gradient, 32 <- 32), then
+// bn_tanh_bwd_kernel's arithmetic on it - g_v = g_t (1 - t^2), g_u = g_v * scale, per-tile records of dgamma / dbeta - which were a
+// dsl_conv2d (mode 1, 32 of 64 padded channels) and dsl_bn_tanh_bwd per block on the data-gradient chain.  A workgroup (8 waves) owns a
+// 14 x 14 tile: the g_h rows of the tile + a one-pixel halo go to an LDS patch (zero outside the image), 7 waves x 32 pixels run the
+// nine taps as MFMA chains (A = the dgrad pack's rows [ci][r][s][co], B = the patch row of pixel (y + 1 - r, x + 1 - s): the K order of
+// the convolution kernel, its zero co columns skipped), g_t is rounded to bf16 as the convolution stored it and never leaves the chip.
+struct RlaTailBK {
+  const uint16_t* gh; const uint16_t* wT; const uint16_t* t; const uint16_t* u;
+  const float* scale; const float* mean; const float* var;
+  uint16_t* gu; float* rec;
+  int ldgh, ldw, ldt, ldgu, n, h, w, tiles_x, tiles_y;
+  float eps;
+};
+__global__ __launch_bounds__(512) void rla_tail_bwd_kernel(const RlaTailBK p) {
+  constexpr int RT = 14, HW = 16;
+  __shared__ __attribute__((aligned(16))) uint16_t patch[HW * HW * 32];
+  __shared__ float red[7 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  int b = blockIdx.x;
+  const int tx = b % p.tiles_x; b /= p.tiles_x;
+  const int ty = b % p.tiles_y;
+  const int img = b / p.tiles_y;
+  const int y0 = ty * RT, x0 = tx * RT;
+  const long long ibase = (long long)img * p.h * p.w;
+  // g_h patch: 256 slots x 32 channels = 1024 16-byte chunks, two per thread
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int c16 = tid + it * 512;
+    const int s = c16 >> 2, part = c16 & 3;
+    const int py = y0 - 1 + (s >> 4), px = x0 - 1 + (s & 15);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned)py < (unsigned)p.h && (unsigned)px < (unsigned)p.w)
+      v = *reinterpret_cast<const u32x4*>(p.gh + (ibase + (long long)py * p.w + px) * p.ldgh + part * 8);
+    *reinterpret_cast<u32x4*>(patch + s * 32 + part * 8) = v;
+  }
+  __syncthreads();
+  float dg[16], db[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dg[j] = db[j] = 0.f;
+  if (wave < 7) {
+    const int q = wave * 32 + col;
+    const bool live = q < RT * RT;
+    const int iy = live ? q / RT : 0, ix = live ? q - (q / RT) * RT : 0;
+    const uint16_t* wr = p.wT + (long long)col * 9 * p.ldw + kh * 8;
+    rla_f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, s_ = tap - r * 3;
+      const uint16_t* pr = patch + ((iy + 2 - r) * HW + ix + 2 - s_) * 32 + kh * 8;     // patch row of pixel (y + 1 - r, x + 1 - s)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const rla_bf16x8 a = *reinterpret_cast<const rla_bf16x8*>(wr + tap * p.ldw + ks * 16);
+        const rla_bf16x8 bb = *reinterpret_cast<const rla_bf16x8*>(pr + ks * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc, 0, 0, 0);
+      }
+    }
+    const int py = y0 + iy, px = x0 + ix;
+    if (live && py < p.h && px < p.w) {
+      const long long pix = ibase + (long long)py * p.w + px;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 8 * g + 4 * kh;
+        const uint2 tv = *reinterpret_cast<const uint2*>(p.t + pix * p.ldt + c0);
+        const uint2 uv = *reinterpret_cast<const uint2*>(p.u + pix * 32 + c0);
+        const uint2 gq = {pack2bf(acc[4 * g], acc[4 * g + 1]), pack2bf(acc[4 * g + 2], acc[4 * g + 3])};     // g_t as the convolution stored it
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gg = (e & 1) ? bfhi(e < 2 ? gq.x : gq.y) : bflo(e < 2 ? gq.x : gq.y);
+          const float tt = (e & 1) ? bfhi(e < 2 ? tv.x : tv.y) : bflo(e < 2 ? tv.x : tv.y);
+          const float uu = (e & 1) ? bfhi(e < 2 ? uv.x : uv.y) : bflo(e < 2 ? uv.x : uv.y);
+          const float gvv = gg * (1.f - tt * tt);
+          dg[4 * g + e] = gvv * (uu - p.mean[c0 + e]) * rsqrtf(p.var[c0 + e] + p.eps);
+          db[4 * g + e] = gvv;
+          o[e] = gvv * p.scale[c0 + e];
+        }
+        *reinterpret_cast<uint2*>(p.gu + pix * p.ldgu + c0) = uint2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+      }
+    }
+    // the tile's (dgamma, dbeta) record: the 32 pixels of a wave by shuffles, the 7 waves through LDS, in a fixed order
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+#pragma unroll
+      for (int o_ = 16; o_ > 0; o_ >>= 1) {
+        dg[j] += __shfl_xor(dg[j], o_, 64);
+        db[j] += __shfl_xor(db[j], o_, 64);
+      }
+    }
+    if (col == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int c = 8 * (j >> 2) + 4 * kh + (j & 3);
+        red[wave * 64 + c] = dg[j];
+        red[wave * 64 + 32 + c] = db[j];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < 7; ++w_) a += red[w_ * 64 + tid];
+    p.rec[(long long)blockIdx.x * 64 + tid] = a;
+  }
+}
+
 // out[v] (+)= sum over blocks of rec[b][v], fixed order; one workgroup
 __global__ __launch_bounds__(256) void rec_sum_kernel(const float* __restrict__ rec, int nblocks, int V, float* __restrict__ out_a,
                                                       float* __restrict__ out_b, int half, int accumulate) {
@@ -421,6 +530,30 @@ extern "C" int dsl_bn_tanh_bwd(const void* gt, int ldgt, const void* t, int ldt,
   return 0;
 }
 
+extern "C" size_t dsl_rla_tail_bwd_workspace_bytes(int n, int h, int w) {
+  return n > 0 && h > 0 && w > 0 ? (size_t)n * ((h + 13) / 14) * ((w + 13) / 14) * 64 * sizeof(float) : 0;
+}
+
+extern "C" int dsl_rla_tail_bwd(const void* g_h, int ldgh, const void* wT_recurrent, int ldw, const void* t, int ldt, const void* u,
+                                const float* scale, const float* mean, const float* var, float eps, void* g_u, int ldgu, float* dgamma,
+                                float* dbeta, void* workspace, int n, int h, int w, void* stream) {
+  DSL_CHECK(g_h && wT_recurrent && t && u && scale && mean && var && g_u && workspace && (!dgamma == !dbeta), "dsl_rla_tail_bwd: null pointer");
+  DSL_CHECK(n > 0 && h > 0 && w > 0 && ldgh >= 32 && ldgh % 8 == 0 && ldw >= 32 && ldw % 8 == 0 && ldt >= 32 && ldt % 4 == 0 && ldgu >= 32 &&
+            ldgu % 4 == 0, "dsl_rla_tail_bwd: bad geometry (ldgh=%d ldw=%d ldt=%d ldgu=%d)", ldgh, ldw, ldt, ldgu);
+  DSL_CHECK((((uintptr_t)g_h | (uintptr_t)wT_recurrent) & 15) == 0 && (((uintptr_t)t | (uintptr_t)u | (uintptr_t)g_u) & 7) == 0,
+            "dsl_rla_tail_bwd: g_h and the pack must be 16-byte aligned, t / u / g_u 8-byte aligned");
+  RlaTailBK k{(const uint16_t*)g_h, (const uint16_t*)wT_recurrent, (const uint16_t*)t, (const uint16_t*)u, scale, mean, var, (uint16_t*)g_u,
+              (float*)workspace, ldgh, ldw, ldt, ldgu, n, h, w, (w + 13) / 14, (h + 13) / 14, eps};
+  const long long blocks = (long long)k.tiles_x * k.tiles_y * n;
+  DSL_CHECK(blocks < 0x7fffffffLL, "dsl_rla_tail_bwd: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rla_tail_bwd_kernel, dim3((unsigned)blocks), dim3(512), 0, st, k);
+  if (dgamma)      // NULL: the tile records stay in `workspace` ([tiles][64]: dgamma | dbeta) for dsl_rec_sum_multi
+    hipLaunchKernelGGL(rec_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)blocks, 64, dgamma, dbeta, 32, 0);
+  DSL_LAUNCH_CHECK("rla_tail_bwd_kernel");
+  return 0;
+}
+
 extern "C" int dsl_rec_sum_multi(const dsl_rec_sum_item* items_dev, int n, int c, void* stream) {
   static_assert(sizeof(dsl_rec_sum_item) == sizeof(RecSumItem), "item layout");
   DSL_CHECK(items_dev && n > 0 && c > 0 && 2 * c <= 256 && 256 % (2 * c) == 0, "dsl_rec_sum_multi: bad arguments");
@@ -487,6 +620,9 @@ extern "C" int dsl_rla_op(const dsl_rla_desc* d, void* stream) {
                          (float*)p[5], i[0], stream);
     case DSL_RLA_BN_POST: return dsl_bn_wgrad_post((const dsl_bn_post_item*)p[0], i[0], i[1], d->f[0], stream);
     case DSL_RLA_REC_SUM: return dsl_rec_sum_multi((const dsl_rec_sum_item*)p[0], i[0], i[1], stream);
+    case DSL_RLA_TAIL_BWD:
+      return dsl_rla_tail_bwd(p[0], i[0], p[1], i[1], p[2], i[2], p[3], (const float*)p[4], (const float*)p[5], (const float*)p[6], d->f[0], p[7],
+                              i[3], (float*)p[8], (float*)p[9], p[10], i[4], i[5], i[6], stream);
     case DSL_RLA_TAIL_FWD:
       return dsl_rla_tail_fwd(p[0], i[0], p[1], i[1], p[2], i[2], (const float*)p[3], (const float*)p[4], p[5], i[3], p[6], p[7], p[8], i[4],
                               i[5], i[6], i[7], stream);

@@ -160,7 +160,9 @@ class FlatSGD:
                             tr[-1]['buckets'][k]['done'] = ed
                 elif not (deferred and info.get('deferred')):          # (the deferred bucket's stream IS the one its gradients ran on)
                     never = L.lib.dsl_stream_wait_slot(int(info['slot']), tp)
-                    if (info['main'] or never != 0) and tgt is not cur:
+                    # (data parallel with the exchanges already waited for on the caller's stream - FCOS.wait_grads: the update must
+                    #  follow them, not only its weight gradients)
+                    if (info['main'] or never != 0 or getattr(self.model, 'world_size', 1) > 1) and tgt is not cur:
                         tgt.wait_stream(cur)
                 o4, o2, o1 = lo * 4, lo * 2, lo
                 if 'sgd' in skip_items():          # step-level ablation (tools/step_ablation.sh): timing only

@@ -405,17 +405,28 @@ int dsl_bn_wgrad_post(const dsl_bn_post_item* items_dev, int n, int total_rows, 
 int dsl_rla_tail_fwd(const void* x, int ldx, const void* h_in, int ldh, const void* w_conv_out, int c4, const float* bn_scale,
                      const float* bn_bias, const void* w_recurrent, int tw, void* u, void* t, void* h_out, int ldo, int n, int h, int w,
                      void* stream);
+/* ... and its backward tail as ONE launch: g_t = recurrent_conv^T(g_h) (the 3x3 data gradient; wT_recurrent = the data-gradient pack
+ * [>= 32 ci][3][3][ldw co], 32 co used; g_h [n*h*w][ldgh], 32 used) followed by dsl_bn_tanh_bwd's arithmetic on it (t [..][ldt], u [..][32],
+ * g_u [..][ldgu], 32 written; dgamma / dbeta fp32 [32] overwritten, or NULL: the tile records [tiles][64] stay in `workspace` for
+ * dsl_rec_sum_multi).  workspace >= dsl_rla_tail_bwd_workspace_bytes(n, h, w).  g_t is never stored.  Replaces dsl_conv2d (mode 1) ->
+ * dsl_bn_tanh_bwd; g_u equals theirs bit for bit, dgamma / dbeta differ by the summation order of their records only. */
+size_t dsl_rla_tail_bwd_workspace_bytes(int n, int h, int w);
+int dsl_rla_tail_bwd(const void* g_h, int ldgh, const void* wT_recurrent, int ldw, const void* t, int ldt, const void* u,
+                     const float* scale, const float* mean, const float* var, float eps, void* g_u, int ldgu, float* dgamma, float* dbeta,
+                     void* workspace, int n, int h, int w, void* stream);
 /* one of the above as an op-list entry (DSL_OP_RLA): kind selects the call, the arguments are taken in declaration order
  * from p[] (pointers), i[] (ints: strides / sizes), f[] (eps), rows */
 enum { DSL_RLA_AVGPOOL = 2, DSL_RLA_AVGPOOL_BWD = 3, DSL_RLA_BN_TANH = 4, DSL_RLA_BN_TANH_BWD = 5,
        DSL_RLA_BN_FOLD = 6, DSL_RLA_BN_POST = 7, DSL_RLA_REC_SUM = 8 /* p[0] = items, i[0] = n, i[1] = c */,
-       DSL_RLA_TAIL_FWD = 9 /* p[] = x, h_in, w_conv_out, bn_scale, bn_bias, w_recurrent, u, t, h_out; i[] = ldx, ldh, c4, tw, ldo, n, h, w */ };
+       DSL_RLA_TAIL_FWD = 9 /* p[] = x, h_in, w_conv_out, bn_scale, bn_bias, w_recurrent, u, t, h_out; i[] = ldx, ldh, c4, tw, ldo, n, h, w */,
+       DSL_RLA_TAIL_BWD = 10 /* p[] = g_h, wT_recurrent, t, u, scale, mean, var, g_u, dgamma, dbeta, workspace; i[] = ldgh, ldw, ldt, ldgu, n, h, w;
+                              * f[0] = eps */ };
 typedef struct dsl_rla_desc {
   int32_t kind;
   int32_t i[8];
   float f[2];
   int64_t rows;
-  void* p[10];
+  void* p[12];
 } dsl_rla_desc;
 int dsl_rla_op(const dsl_rla_desc* d, void* stream);
 
