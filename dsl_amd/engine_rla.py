@@ -170,6 +170,7 @@ def build_backward(plan, buckets, SIDE):
     # '' 11.99 / 12.00 / 12.12 ms, '123' 12.17 / 12.16 / 12.15, '23' 12.07 / 12.13 / 12.01: unlike the forward chains and the
     # ResNet engine's backward, the caller's stream is full of kernel time here (10.7 of 12.1 ms busy, profiles/r03_rla_timeline.txt),
     # not of launch gaps, and the weight-gradient grids already hold the CUs a second chain would use.
+    TAIL = tune('rla_tail') != '0'
     BSPLIT = tune('rla_split_bwd')        # default '': built, same gradients (test_rla_image_split_backward_chains_give_the_same_gradients), slower - LAB_NOTES.md
     S2_CLASSES = True         # stride-2 3x3 data gradients as four parity-class launches
     BB = plan.BR
@@ -229,9 +230,21 @@ def build_backward(plan, buckets, SIDE):
                 rec0 = 0
                 for gi, (g0, ge, sd) in enumerate(groups):
                     n_ = ge - g0
+                    whole = len(groups) == 1
+                    if TAIL and whole:
+                        # recurrent-conv data gradient + BN / tanh backward as ONE launch (round 6, csrc/rla.hip rla_tail_bwd_kernel):
+                        # g_t never leaves the chip, the (dgamma, dbeta) records are per 14 x 14 tile
+                        ws2 = plan.buf(p + '.bnws2', int(L.lib.dsl_rla_tail_bwd_workspace_bytes(n_, oh, ow)) // 4, dtype=torch.float32)
+                        _rla_op(ol, L.RLA_TAIL_BWD,
+                                p=(O(gh, g0, ge), st.wT_ptr(rc.name), O(blk['t'], g0, ge), O(blk['u'], g0, ge), sc, bn_f(blk['bn'], 'running_mean'),
+                                   bn_f(blk['bn'], 'running_var'), O(g_u, g0, ge), bn_g(blk['bn'], 'weight'), bn_g(blk['bn'], 'bias'), ws2),
+                                i=(64, rc.cout_pad, blk['tw'], 64, n_, oh, ow), f=(1e-5,), side=sd)
+                        dg(sd, plan._dgrad(co.name, O(g_u, g0, ge), O(g_pre, g0, ge), n_, [(oh, ow)], [(oh, ow)], cs=64, cd=c4, k=1,
+                                           stride=1, pad=0, addend=O(gx, g0, ge), mask=O(blk['out'], g0, ge), ldm=blk['ld_out'],
+                                           mask_last=True, cs_real=RLA_C))
+                        continue
                     dg(sd, plan._dgrad(rc.name, O(gh, g0, ge), O(g_t, g0, ge), n_, [(oh, ow)], [(oh, ow)], cs=64, cd=RLA_C,
                                        cd_pad=rc.cin_store, k=3, stride=1, pad=1, ldd=RLA_C))
-                    whole = len(groups) == 1
                     _rla_op(ol, L.RLA_BN_TANH_BWD,
                             p=(O(g_t, g0, ge), O(blk['t'], g0, ge), O(blk['u'], g0, ge), sc, bn_f(blk['bn'], 'running_mean'),
                                bn_f(blk['bn'], 'running_var'), O(g_u, g0, ge), bn_g(blk['bn'], 'weight') if whole else None,

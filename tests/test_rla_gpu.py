@@ -271,6 +271,55 @@ def test_rla_tail_kernel_vs_three_launches():
         assert float(outs[1][2][:, c4:c4 + 32].abs().max()) > 0 and float(outs[1][2][:, :c4].abs().max()) == 0      # only the h columns are written
 
 
+def test_rla_tail_backward_kernel_vs_two_launches():
+    """dsl_rla_tail_bwd (round 6: the recurrent convolution's data gradient + the BN / tanh backward of a block's recurrent path as one
+    launch) against dsl_conv2d (mode 1) -> dsl_bn_tanh_bwd on the same tensors: g_u bit for bit, (dgamma, dbeta) within their fp32
+    summation order (tile records instead of 256-row records), bit-reproducible."""
+    import ctypes as C
+    from dsl_amd import _lib as L
+    from dsl_amd import ops
+    g = torch.Generator().manual_seed(31)
+    for (n, h, w, tw) in [(2, 25, 42, 128), (1, 14, 14, 64), (3, 9, 31, 128), (1, 50, 84, 128)]:
+        P = n * h * w
+        gh = torch.zeros(P, 64)
+        gh[:, :32] = torch.randn(P, 32, generator=g) * 0.3
+        gh = gh.bfloat16().cuda()
+        wT = torch.zeros(tw, 3, 3, 64)                       # the data-gradient pack [ci][r][s][co]
+        wT[:32, :, :, :32] = torch.randn(32, 3, 3, 32, generator=g) * 0.08
+        wT = wT.bfloat16().cuda()
+        u = (torch.randn(P, 32, generator=g) * 1.2).bfloat16().cuda()
+        gam, mu, var = 1 + 0.2 * torch.randn(32, generator=g), 0.2 * torch.randn(32, generator=g), 0.5 + torch.rand(32, generator=g)
+        sc = (gam / torch.sqrt(var + 1e-5)).cuda()
+        bi = (0.1 * torch.randn(32, generator=g)).cuda()
+        mu_d, var_d = mu.cuda(), var.cuda()
+        t = torch.zeros(P, tw, dtype=torch.bfloat16, device='cuda')
+        L.check(L.lib.dsl_bn_tanh_fwd(L.ptr(u), 32, L.ptr(sc), L.ptr(bi), L.ptr(t), tw, P, 32, L.stream_ptr()), 'bn_tanh')
+        outs = []
+        for mode in ('two', 'fused', 'fused'):
+            gu = torch.zeros(P, 64, dtype=torch.bfloat16, device='cuda')
+            dgam, dbet = torch.full((32,), float('nan'), device='cuda'), torch.full((32,), float('nan'), device='cuda')
+            if mode == 'two':
+                gt = torch.empty(P, 32, dtype=torch.bfloat16, device='cuda')
+                d1 = ops.conv_desc(gh, wT, gt, n=n, grid=[(h, w)], src_hw=[(h, w)], dst_hw=[(h, w)], cs=64, cd=32, cd_pad=tw, ldd=32, kh=3, kw=3,
+                                   stride=1, pad=1, mode=1)
+                L.check(L.lib.dsl_conv2d(C.byref(d1), L.stream_ptr()), 'recurrent dgrad')
+                ws = torch.empty(L.lib.dsl_bn_tanh_bwd_workspace_bytes(P, 32), dtype=torch.uint8, device='cuda')
+                L.check(L.lib.dsl_bn_tanh_bwd(L.ptr(gt), 32, L.ptr(t), tw, L.ptr(u), 32, L.ptr(sc), L.ptr(mu_d), L.ptr(var_d), 1e-5, L.ptr(gu), 64,
+                                              L.ptr(dgam), L.ptr(dbet), L.ptr(ws), P, 32, L.stream_ptr()), 'bn_tanh_bwd')
+            else:
+                ws = torch.full((int(L.lib.dsl_rla_tail_bwd_workspace_bytes(n, h, w)),), 0xff, dtype=torch.uint8, device='cuda')
+                L.check(L.lib.dsl_rla_tail_bwd(L.ptr(gh), 64, L.ptr(wT), 64, L.ptr(t), tw, L.ptr(u), L.ptr(sc), L.ptr(mu_d), L.ptr(var_d), 1e-5,
+                                               L.ptr(gu), 64, L.ptr(dgam), L.ptr(dbet), L.ptr(ws), n, h, w, L.stream_ptr()), 'dsl_rla_tail_bwd')
+            torch.cuda.synchronize()
+            outs.append((gu.clone(), dgam.clone(), dbet.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]), (n, h, w, float((outs[0][0].float() - outs[1][0].float()).abs().max()))
+        assert float(outs[1][0][:, 32:].float().abs().max()) == 0 and float(outs[1][0][:, :32].float().abs().max()) > 0
+        for a, b in zip(outs[0][1:], outs[1][1:]):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(a.abs().max())), (n, h, w, float((a - b).abs().max()))
+        for a, b in zip(outs[1], outs[2]):
+            assert torch.equal(a, b)
+
+
 def test_rla_tail_fused_step_equals_the_three_launch_step(monkeypatch):
     """Tuning key rla_tail (default 1): the whole training step with the fused recurrent path against the step with the three launches
     per block - the same losses, bit for bit, and the same gradients."""

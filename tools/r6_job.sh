@@ -1,5 +1,6 @@
-R=$GRAFT_REPO_ROOT; cd $R; export TMPDIR=/tmp
-bash tools/exp_prof.sh r06 > gpurun_out/r06_exp_prof.log 2>&1
-bash tools/exp_pmc.sh r06 > gpurun_out/r06_exp_pmc.log 2>&1
-python bench.py > gpurun_out/r06_bench_full.log 2>&1
-tail -3 gpurun_out/r06_exp_prof.log; head -5 gpurun_out/r06_pmc_traffic.txt; tail -c 300 gpurun_out/r06_bench_full.log
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/g10
+for rep in 1 2 3; do for v in rla_tail=0 rla_tail=1; do
+  echo "[$v] $(DSL_TUNE=$v python tools/bench_dsl_variant.py 0 1 0 2>&1 | tail -1 | sed 's/, .imgs_per_iter.*//')"
+done; done > gpurun_out/g10/rla_tail_ab2.txt 2>&1
+for v in rla_tail=0 rla_tail=1; do echo "[$v async refresh] $(DSL_TUNE=$v python tools/bench_dsl_variant.py 1 1 1 2>&1 | tail -1 | sed 's/, .imgs_per_iter.*//')"; done >> gpurun_out/g10/rla_tail_ab2.txt 2>&1
+cat gpurun_out/g10/rla_tail_ab2.txt
